@@ -1,0 +1,239 @@
+"""ctypes loader for oracle/_build/libfpca_oracle.so.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see oracle/fpca_oracle.h).  Nothing under flashpca_amd/ imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "libfpca_oracle.so")
+
+STAND = {"binom": 2, "binom2": 3}
+DIVISOR = {"none": 0, "n1": 1, "p": 2}
+
+_lib = None
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="F_CONTIGUOUS")
+_dpc = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(
+        os.path.join(HERE, "fpca_oracle.c")
+    ):
+        subprocess.check_call(["make", "-C", HERE, "-s"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_open_file.restype = C.c_void_p
+        L.orc_open_file.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_int]
+        L.orc_open_mem.restype = C.c_void_p
+        L.orc_open_mem.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+        L.orc_close.argtypes = [C.c_void_p]
+        for f in (L.orc_N, L.orc_nsnps, L.orc_np):
+            f.restype = C.c_uint64
+            f.argtypes = [C.c_void_p]
+        L.orc_set_preloaded_meansd.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_read_snp_block.restype = C.c_int
+        L.orc_read_snp_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_meansd.restype = _dpc
+        L.orc_meansd.argtypes = [C.c_void_p]
+        L.orc_lookup.restype = _dpc
+        L.orc_lookup.argtypes = [C.c_void_p]
+        L.orc_op_new.restype = C.c_void_p
+        L.orc_op_new.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        L.orc_op_free.argtypes = [C.c_void_p]
+        L.orc_perform_op.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_perform_op_mat.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_crossprod.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_prod.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_op_trace.restype = C.c_double
+        L.orc_op_trace.argtypes = [C.c_void_p]
+        L.orc_op_nops.restype = C.c_uint32
+        L.orc_op_nops.argtypes = [C.c_void_p]
+        L.orc_op_nblocks.restype = C.c_uint32
+        L.orc_op_nblocks.argtypes = [C.c_void_p]
+        L.orc_symeigs.restype = C.c_int
+        L.orc_symeigs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_pca_fast.restype = C.c_int
+        L.orc_pca_fast.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        L.orc_check.restype = C.c_int
+        L.orc_check.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_default_block_size.restype = C.c_uint32
+        L.orc_default_block_size.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
+        L.orc_format_number.restype = C.c_int
+        L.orc_format_number.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int]
+        L.orc_decode_plink.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        L.orc_decode_plink_simple.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        _lib = L
+    return _lib
+
+
+def count_fam_rows(path):
+    """N = number of newline-terminated lines (data.cpp:526: an unterminated last line is dropped)."""
+    with open(path, "rb") as f:
+        return f.read().count(b"\n")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleData:
+    """The slice of the reference's Data class this path uses (data.h:60-101)."""
+
+    def __init__(self, bed_path=None, N=None, stand="binom2", packed=None, P=None):
+        L = lib()
+        self._keep = None
+        if bed_path is not None:
+            err = C.create_string_buffer(512)
+            self.h = L.orc_open_file(bed_path.encode(), int(N), STAND[stand], err, 512)
+            if not self.h:
+                raise RuntimeError(err.value.decode())
+        else:
+            packed = np.ascontiguousarray(packed, dtype=np.uint8)
+            self._keep = packed
+            self.h = L.orc_open_mem(_ptr(packed), int(N), int(P), STAND[stand])
+        self.N = int(L.orc_N(self.h))
+        self.P = int(L.orc_nsnps(self.h))
+        self.np_bytes = int(L.orc_np(self.h))
+
+    def close(self):
+        if self.h:
+            lib().orc_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def read_snp_block(self, start, stop):
+        X = np.empty((self.N, stop - start + 1), dtype=np.float64, order="F")
+        rc = lib().orc_read_snp_block(self.h, start, stop, _ptr(X))
+        if rc != 0:
+            raise RuntimeError("orc_read_snp_block rc=%d" % rc)
+        return X
+
+    def dense(self):
+        return self.read_snp_block(0, self.P - 1)
+
+    def meansd(self):
+        p = lib().orc_meansd(self.h)
+        return np.ctypeslib.as_array(p, shape=(2, self.P)).T.copy()
+
+    def lookup(self):
+        p = lib().orc_lookup(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.P, 4)).copy()  # [snp, raw code]
+
+    def set_preloaded_meansd(self, meansd):
+        m = np.asfortranarray(meansd, dtype=np.float64)
+        lib().orc_set_preloaded_meansd(self.h, _ptr(m))
+
+
+class OracleOp:
+    """SVDWideOnline (svdwide.h:40-107)."""
+
+    def __init__(self, data, block_size, nthreads=1):
+        self.data = data
+        self.h = lib().orc_op_new(data.h, int(block_size), int(nthreads))
+        self.N, self.P = data.N, data.P
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_op_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def perform_op(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(self.N)
+        lib().orc_perform_op(self.h, _ptr(x), _ptr(y))
+        return y
+
+    def perform_op_mat(self, X):
+        X = np.asfortranarray(X, dtype=np.float64)
+        Y = np.empty_like(X, order="F")
+        lib().orc_perform_op_mat(self.h, _ptr(X), X.shape[1], _ptr(Y))
+        return Y
+
+    def crossprod(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(self.P)
+        lib().orc_crossprod(self.h, _ptr(x), _ptr(y))
+        return y
+
+    def prod(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        y = np.empty(self.N)
+        lib().orc_prod(self.h, _ptr(v), _ptr(y))
+        return y
+
+    @property
+    def trace(self):
+        return lib().orc_op_trace(self.h)
+
+    @property
+    def nops(self):
+        return lib().orc_op_nops(self.h)
+
+    def symeigs(self, nev, ncv=None, maxit=500, tol=1e-6):
+        ncv = 2 * nev + 1 if ncv is None else ncv
+        evals = np.zeros(nev)
+        evecs = np.zeros((self.N, nev), order="F")
+        info, nrest = C.c_int(0), C.c_int(0)
+        got = lib().orc_symeigs(self.h, nev, ncv, maxit, tol, _ptr(evals), _ptr(evecs), C.byref(info), C.byref(nrest))
+        return got, info.value, nrest.value, evals, evecs
+
+
+def pca_fast(data, ndim, block_size=None, maxiter=500, tol=1e-6, div="p", do_loadings=False, nthreads=1, memory_mb=2048):
+    """RandomPCA::pca_fast(Data&, ...) (randompca.cpp:168-218) with the CLI defaults (flashpca.cpp:237,325,426,440,484)."""
+    L = lib()
+    if block_size is None:
+        block_size = L.orc_default_block_size(data.N, data.P, ndim, int(do_loadings), memory_mb)
+    N, P = data.N, data.P
+    U = np.zeros((N, ndim), order="F")
+    d = np.zeros(ndim)
+    V = np.zeros((P, ndim), order="F") if do_loadings else None
+    Px = np.zeros((N, ndim), order="F")
+    pve = np.zeros(ndim)
+    trace = C.c_double(0)
+    nops = C.c_uint32(0)
+    rc = L.orc_pca_fast(data.h, int(block_size), ndim, maxiter, tol, DIVISOR[div], int(do_loadings), nthreads,
+                        _ptr(U), _ptr(d), _ptr(V) if V is not None else None, _ptr(Px), _ptr(pve),
+                        C.byref(trace), C.byref(nops))
+    if rc != 0:
+        raise RuntimeError("Spectra eigen-decomposition was not successful")  # randompca.cpp:212-217
+    return dict(U=U, d=d, V=V, Px=Px, pve=pve, trace=trace.value, nops=nops.value, block_size=int(block_size),
+                meansd=data.meansd())
+
+
+def check(data, evec, evals, block_size, div="p"):
+    evec = np.asfortranarray(evec, dtype=np.float64)
+    evals = np.ascontiguousarray(evals, dtype=np.float64)
+    k = evec.shape[1]
+    err = np.zeros(k)
+    mse, rmse = C.c_double(0), C.c_double(0)
+    lib().orc_check(data.h, int(block_size), DIVISOR[div], _ptr(evec), _ptr(evals), k, _ptr(err), C.byref(mse), C.byref(rmse))
+    return err, mse.value, rmse.value
+
+
+def format_number(v, precision=7):
+    buf = C.create_string_buffer(64)
+    lib().orc_format_number(buf, 64, float(v), precision)
+    return buf.value.decode()
