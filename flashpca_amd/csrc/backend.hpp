@@ -1,0 +1,44 @@
+// backend.hpp -- the narrow interface the host eigensolver drives.
+//
+// The solver (solver.cpp) never touches matrix data itself: every N-sized object is an opaque "block"
+// (N x b, fp64) owned by a backend.  The product backend is HipBackend (hip_backend.hip): blocks live in
+// HBM and every method enqueues hand-written gfx950 kernels.  oracle/hostsim_backend.cpp implements the
+// same interface on host memory over the CPU oracle -- TEST INFRASTRUCTURE ONLY, used to exercise the
+// solver and the multi-rank sharding logic on machines without a GPU (gloo tests); it is never linked
+// into libfpca.so.
+#pragma once
+#include <cstdint>
+
+namespace fpca {
+
+class BlockBackend {
+ public:
+   virtual ~BlockBackend() {}
+   virtual uint64_t nrows() const = 0; // N (samples)
+   virtual int width() const = 0;      // b (columns per block)
+
+   virtual int alloc_block() = 0;    // handle >= 0
+   virtual void free_block(int h) = 0;
+   virtual void fill_random(int h, uint64_t seed) = 0;
+
+   // out = sum over ranks g of X_g X_g' in    (K2 + K3 + all-reduce); in != out
+   virtual void apply(int in, int out) = 0;
+
+   // C[q][p][c] = sum_s A_q[s][p] W[s][c]   for q < nq  (host result => synchronises)
+   virtual void gram(const int *a, int nq, int w, double *C) = 0;
+   // out = (init >= 0 ? block init : 0) + sum_q A_q C_q, C[q][p][c]; out may alias init or any a[q]
+   virtual void gemm(const int *a, int nq, const double *C, int init, int out) = 0;
+
+   // first ncols columns of a block <-> host column-major N x ncols
+   virtual void download(int h, int ncols, double *host, int64_t ld) = 0;
+   virtual void upload(int h, int ncols, const double *host, int64_t ld) = 0;
+
+   // sum over ranks of the shard traces sum X^2 (svdwide.cpp:44-45, 60-61)
+   virtual double trace() = 0;
+
+   // seconds spent in apply() / in the other device methods since construction (for fpca_pca_info)
+   virtual double seconds_apply() { return 0; }
+   virtual double seconds_other() { return 0; }
+};
+
+} // namespace fpca

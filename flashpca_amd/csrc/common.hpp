@@ -1,0 +1,32 @@
+// common.hpp -- shared constants and error plumbing for libfpca (MI355X / gfx950 only).
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace fpca {
+
+// ---- HBM layout constants (see DESIGN.md "Data layout in HBM") -----------------------------------
+// packed rows are re-pitched to a multiple of ROW_ALIGN bytes so that every SNP record starts on a
+// 128-byte line and a 512-sample tile of one record is exactly one line
+constexpr int ROW_ALIGN = 128;                 // bytes
+constexpr int SAMPLE_ALIGN = ROW_ALIGN * 4;    // 512 samples: N_pad granularity
+constexpr int SNP_ALIGN = 256;                 // P_pad granularity (K2 SNP tile)
+constexpr uint8_t PAD_BYTE = 0x55;             // four "01" (missing) codes: standardises to 0
+
+constexpr int XT_TILE = 256; // K2: SNPs per workgroup (4 waves x 4 m-tiles x 16)
+constexpr int X_KC = 64;     // K3: SNPs per LDS chunk
+
+constexpr int MAX_BLOCKVEC = 64; // widest block the kernels are instantiated for (NT <= 4)
+
+inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+struct Error : std::runtime_error {
+   int code;
+   Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string &msg);
+
+} // namespace fpca

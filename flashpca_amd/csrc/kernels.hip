@@ -1,0 +1,817 @@
+// kernels.hip -- hand-written CDNA4 (gfx950) kernels of the flashpca PCA hot path.
+//
+// The reference computes  y = sum_blocks X_b (X_b' x)  by decoding every SNP block of the PLINK 2-bit
+// stream into a dense fp64 N x bs matrix through a per-SNP 4-entry lookup table and running two Eigen
+// GEMVs over it (svdwide.cpp:21-68, data.cpp:215-335).  Here the packed stream stays resident in HBM and
+// the decode + standardisation is fused into two tall-skinny FP64 MFMA GEMMs on b columns at a time:
+//
+//   K1 bed_stats : per-SNP code counts -> mean, sd, lookup table, sum of squares   (data.cpp:257-322)
+//   K2 xt_b      : T[P x b] = X' B      (first GEMV of svdwide.cpp:42-43, crossprod of :122-153)
+//   K3 x_t       : Y[N x b] = X  T      (second GEMV of svdwide.cpp:42-43, prod of :193-226)
+//   K4 helpers   : Gram / block GEMM / fill / layout changes on N x b blocks for the host eigensolver
+//
+// MFMA: v_mfma_f64_16x16x4_f64, D(16x16) += A(16x4) B(4x16), one f64 of A and of B per lane:
+//   lane l holds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; the 4 accumulator registers r hold
+//   D[row = (l>>4) + 4r][col = l&15].   (cdna_hip_programming.md section 3; checked at run time by
+//   mfma_layout_probe / tests/test_gpu_kernels.py)
+// A wave is 64 lanes; a workgroup is 4 waves (one per SIMD); 2 workgroups per CU hide the staging.
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+#include "synth.hpp"
+
+namespace fpca {
+namespace kern {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));   // 16-byte load/store unit (native vector: stays in VGPRs)
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+#define FPCA_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+#define HIP_CHECK_LAUNCH()                                                                         \
+   do {                                                                                             \
+      hipError_t e__ = hipGetLastError();                                                           \
+      if (e__ != hipSuccess) throw Error(-3, std::string("kernel launch failed: ") + hipGetErrorString(e__)); \
+   } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// padding fix-up: pad bits of the last valid byte -> "01" (missing)
+__global__ void k_fix_last_byte(uint8_t *packed, size_t pitch, uint64_t np, uint32_t keep_mask, uint64_t P_g)
+{
+   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (r >= P_g) return;
+   uint8_t *p = packed + r * pitch + (np - 1);
+   *p = (uint8_t)((*p & keep_mask) | (PAD_BYTE & ~keep_mask));
+}
+
+void fix_last_byte(uint8_t *packed, size_t pitch, uint64_t np, int valid_in_last, uint64_t P_g, hipStream_t stream)
+{
+   if (valid_in_last <= 0 || valid_in_last >= 4 || P_g == 0) return;
+   uint32_t keep = (1u << (2 * valid_in_last)) - 1u;
+   unsigned grid = (unsigned)((P_g + 255) / 256);
+   hipLaunchKernelGGL(k_fix_last_byte, dim3(grid), dim3(256), 0, stream, packed, pitch, np, keep, P_g);
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 bed_stats.  One workgroup per SNP record; 16-byte coalesced loads of the packed stream; the four
+// 2-bit codes are counted with popcount on the even/odd bit planes.  Padding bytes are "01" so they only
+// inflate the missing count, which is not used.  HBM-bound: reads pitch bytes per SNP once.
+__device__ __forceinline__ void count_word(uint32_t w, uint32_t &c01, uint32_t &c10, uint32_t &c11)
+{
+   const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+   c11 += __popc(lo & hi);
+   c10 += __popc(hi & ~lo);
+   c01 += __popc(lo & ~hi);
+}
+
+__device__ __forceinline__ void make_lut(double mean, double sd, double *lut4)
+{
+   // data.cpp:299-320: table indexed by RAW code; all-zero when sd <= VAR_TOL (or NaN)
+   double v0 = 0, v2 = 0, v3 = 0;
+   if (sd > 1e-9) {
+      v3 = (0.0 - mean) / sd;
+      v2 = (1.0 - mean) / sd;
+      v0 = (2.0 - mean) / sd;
+   }
+   lut4[0] = v0;
+   lut4[1] = 0.0;
+   lut4[2] = v2;
+   lut4[3] = v3;
+}
+
+__global__ __launch_bounds__(256) void k_bed_stats(const uint8_t *__restrict__ packed, size_t pitch, int stand_method,
+                                                    double *__restrict__ lut, double *__restrict__ mean_out,
+                                                    double *__restrict__ sd_out, double *__restrict__ sumsq_out)
+{
+   const uint64_t snp = blockIdx.x;
+   const uint4 *row = reinterpret_cast<const uint4 *>(packed + snp * pitch);
+   const uint32_t nvec = (uint32_t)(pitch / 16);
+   uint32_t c01 = 0, c10 = 0, c11 = 0;
+   for (uint32_t v = threadIdx.x; v < nvec; v += 256) {
+      const uint4 q = row[v];
+      count_word(q.x, c01, c10, c11);
+      count_word(q.y, c01, c10, c11);
+      count_word(q.z, c01, c10, c11);
+      count_word(q.w, c01, c10, c11);
+   }
+   for (int off = 32; off > 0; off >>= 1) {
+      c01 += __shfl_down(c01, off);
+      c10 += __shfl_down(c10, off);
+      c11 += __shfl_down(c11, off);
+   }
+   __shared__ uint32_t red[4][3];
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   if (lane == 0) {
+      red[wave][0] = c01;
+      red[wave][1] = c10;
+      red[wave][2] = c11;
+   }
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      uint64_t n01 = 0, n10 = 0, n11 = 0;
+      for (int w = 0; w < 4; w++) {
+         n01 += red[w][0];
+         n10 += red[w][1];
+         n11 += red[w][2];
+      }
+      const uint64_t cells = (uint64_t)pitch * 4;
+      const uint64_t n00 = cells - n01 - n10 - n11; // dosage 2
+      const uint64_t ngood = n00 + n10 + n11;
+      // data.cpp:266-275: mean of the non-missing dosages (exact integer sum, one rounding in the divide)
+      const double mean = (double)(2 * n00 + n10) / (double)ngood;
+      const double pp = mean / 2.0;
+      double sd;
+      if (stand_method == 2)
+         sd = sqrt(pp * (1 - pp)); // STANDARDISE_BINOM  (data.cpp:279)
+      else
+         sd = sqrt(2.0 * pp * (1 - pp)); // STANDARDISE_BINOM2 (data.cpp:281)
+      double l[4];
+      make_lut(mean, sd, l);
+      double *lp = lut + snp * 4;
+      lp[0] = l[0];
+      lp[1] = l[1];
+      lp[2] = l[2];
+      lp[3] = l[3];
+      mean_out[snp] = mean;
+      sd_out[snp] = sd;
+      // sum_i X_ij^2 in closed form from the counts (svdwide.cpp:44-45 sums the dense block)
+      sumsq_out[snp] = (double)n00 * l[0] * l[0] + (double)n10 * l[2] * l[2] + (double)n11 * l[3] * l[3];
+   }
+}
+
+void bed_stats(const uint8_t *packed, size_t pitch, uint64_t N, uint64_t P_g, int stand_method, double *lut,
+               double *mean, double *sd, double *sumsq, hipStream_t stream)
+{
+   (void)N;
+   if (P_g == 0) return;
+   hipLaunchKernelGGL(k_bed_stats, dim3((unsigned)P_g), dim3(256), 0, stream, packed, pitch, stand_method, lut, mean,
+                      sd, sumsq);
+   HIP_CHECK_LAUNCH();
+}
+
+__global__ void k_lut_from_meansd(const double *mean, const double *sd, uint64_t P_g, double *lut)
+{
+   uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (j >= P_g) return;
+   double l[4];
+   make_lut(mean[j], sd[j], l);
+   for (int c = 0; c < 4; c++) lut[j * 4 + c] = l[c];
+}
+
+void lut_from_meansd(const double *mean, const double *sd, uint64_t P_g, double *lut, hipStream_t stream)
+{
+   if (P_g == 0) return;
+   hipLaunchKernelGGL(k_lut_from_meansd, dim3((unsigned)((P_g + 255) / 256)), dim3(256), 0, stream, mean, sd, P_g, lut);
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// standardised value of a raw PLINK code from a per-lane register table (code 01 -> 0)
+__device__ __forceinline__ double lut_sel(uint32_t code, double l0, double l2, double l3)
+{
+   const double hi = (code & 1u) ? l3 : l2;
+   const double lo = (code & 1u) ? 0.0 : l0;
+   return (code & 2u) ? hi : lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 xt_b:  T[snp][c] = sum_s X[s][snp] B[s][c]
+//   workgroup = 256 SNPs x all b columns, wave = 64 SNPs (4 m-tiles of 16), K = samples.
+//   MFMA roles: A[i = SNP in m-tile][k] = decoded genotype, B[k][j = column] = B tile from LDS.
+//   Per 128-sample chunk each lane (i, kq) loads 8 packed bytes of ITS SNP record (samples 32kq..32kq+31
+//   of the chunk) straight into registers -- the K order inside a chunk is permuted so that no cross-lane
+//   shuffle is needed -- and the B tile (128 x b fp64, contiguous in HBM) is staged through LDS once per
+//   workgroup.  Loads of chunk c+1 are issued before the 256 MFMAs of chunk c.
+template <int NT> struct XtCfg {
+   static constexpr int KC = (NT <= 2) ? 128 : 64; // samples per LDS chunk: keeps the prefetch registers <= 32
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ packed, size_t pitch,
+                                                  const double *__restrict__ lut, const double *__restrict__ B,
+                                                  double *__restrict__ Tpart, uint64_t P_pad, int chunks_total,
+                                                  int chunks_per_split)
+{
+   constexpr int b = 16 * NT;
+   constexpr int MT = 4;
+   constexpr int KC = XtCfg<NT>::KC;
+   constexpr int NW = KC / 64;                    // packed dwords per lane per m-tile per chunk (16 samples each)
+   constexpr int NLOAD = KC * b * 8 / (256 * 16); // 16-byte pieces of the B tile per thread
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+   double *sB = reinterpret_cast<double *>(smem_raw); // [KC][b]
+
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int li = lane & 15, kq = lane >> 4;
+   const uint64_t snp0 = (uint64_t)blockIdx.x * XT_TILE + (uint64_t)wave * 64;
+   const int c_begin = blockIdx.y * chunks_per_split;
+   int c_end = c_begin + chunks_per_split;
+   if (c_end > chunks_total) c_end = chunks_total;
+
+   double l0[MT], l2[MT], l3[MT];
+   const uint8_t *rowp[MT];
+#pragma unroll
+   for (int m = 0; m < MT; m++) {
+      const uint64_t snp = snp0 + m * 16 + li;
+      const double *lp = lut + snp * 4;
+      l0[m] = lp[0];
+      l2[m] = lp[2];
+      l3[m] = lp[3];
+      rowp[m] = packed + snp * pitch + kq * (KC / 16); // lane group kq owns samples kq*KC/4 .. +KC/4 of a chunk
+   }
+
+   d4 acc[MT][NT];
+#pragma unroll
+   for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[m][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+
+   uint32_t pk_next[MT][NW];
+   d2 breg[NLOAD];
+#define FPCA_XTB_ISSUE(cc)                                                                                  \
+   {                                                                                                         \
+      _Pragma("unroll") for (int m = 0; m < MT; m++)                                                         \
+      {                                                                                                      \
+         const uint32_t *pp = reinterpret_cast<const uint32_t *>(rowp[m] + (size_t)(cc) * (KC / 4));         \
+         _Pragma("unroll") for (int h = 0; h < NW; h++) pk_next[m][h] = pp[h];                               \
+      }                                                                                                      \
+      const d2 *src = reinterpret_cast<const d2 *>(B + (size_t)(cc) * KC * b);                               \
+      _Pragma("unroll") for (int r = 0; r < NLOAD; r++) breg[r] = src[tid + 256 * r];                        \
+   }
+   if (c_begin < c_end) FPCA_XTB_ISSUE(c_begin);
+
+   const double *sB_lane = sB + (size_t)((KC / 4) * kq) * b + li;
+
+   for (int c = c_begin; c < c_end; c++) {
+      __syncthreads(); // every wave has finished reading the previous B tile
+      {
+         d2 *dst = reinterpret_cast<d2 *>(sB);
+#pragma unroll
+         for (int r = 0; r < NLOAD; r++) dst[tid + 256 * r] = breg[r];
+      }
+      uint32_t pk[MT][NW];
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+         for (int h = 0; h < NW; h++) pk[m][h] = pk_next[m][h];
+      __syncthreads();
+      if (c + 1 < c_end) FPCA_XTB_ISSUE(c + 1);
+#pragma unroll
+      for (int half = 0; half < NW; half++) {
+#pragma unroll
+         for (int t = 0; t < 16; t++) {
+            double bv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) bv[nt] = sB_lane[(size_t)(16 * half + t) * b + nt * 16];
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+               const double a = lut_sel((pk[m][half] >> (2 * t)) & 3u, l0[m], l2[m], l3[m]);
+#pragma unroll
+               for (int nt = 0; nt < NT; nt++) acc[m][nt] = FPCA_MFMA(a, bv[nt], acc[m][nt]);
+            }
+         }
+      }
+   }
+#undef FPCA_XTB_ISSUE
+
+   double *Tout = Tpart + (size_t)blockIdx.y * P_pad * b;
+#pragma unroll
+   for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+         for (int r = 0; r < 4; r++) {
+            const uint64_t row = snp0 + m * 16 + kq + 4 * r;
+            Tout[row * b + nt * 16 + li] = acc[m][nt][r];
+         }
+}
+
+static int pick_splits(uint64_t tiles, uint64_t chunks, int min_chunks, int max_splits)
+{
+   const uint64_t slots = 512; // 256 CUs x 2 resident workgroups
+   uint64_t best_t = ~0ull;
+   int best = 1;
+   for (int s = 1; s <= max_splits && (uint64_t)s <= chunks; s++) {
+      uint64_t cps = (chunks + s - 1) / s;
+      if (s > 1 && cps < (uint64_t)min_chunks) break;
+      uint64_t seff = (chunks + cps - 1) / cps;
+      uint64_t rounds = (tiles * seff + slots - 1) / slots;
+      uint64_t t = rounds * cps * 64 + seff; // ~time in chunk units, small penalty per extra partial
+      if (t < best_t) {
+         best_t = t;
+         best = (int)seff;
+      }
+   }
+   return best;
+}
+
+int xt_b_splits(uint64_t N_pad, uint64_t P_pad, int b)
+{
+   const int kc = b <= 32 ? 128 : 64;
+   return pick_splits(P_pad / XT_TILE, N_pad / kc, 4, 64);
+}
+
+template <int NT>
+static void launch_xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *B, double *Tpart,
+                        uint64_t N_pad, uint64_t P_pad, int nsplit, hipStream_t stream)
+{
+   constexpr int KC = XtCfg<NT>::KC;
+   const int chunks_total = (int)(N_pad / KC);
+   const int cps = (chunks_total + nsplit - 1) / nsplit;
+   const size_t smem = (size_t)KC * 16 * NT * sizeof(double);
+   static bool attr_set = false;
+   if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xt_b<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+   }
+   dim3 grid((unsigned)(P_pad / XT_TILE), (unsigned)nsplit);
+   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xt_b<NT>), grid, dim3(256), smem, stream, packed, pitch, lut, B, Tpart, P_pad,
+                      chunks_total, cps);
+   HIP_CHECK_LAUNCH();
+}
+
+void xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *B, double *Tpart, uint64_t N_pad,
+          uint64_t P_pad, int b, int nsplit, hipStream_t stream)
+{
+   switch (b) {
+   case 16: launch_xt_b<1>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream); break;
+   case 32: launch_xt_b<2>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream); break;
+   case 48: launch_xt_b<3>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream); break;
+   case 64: launch_xt_b<4>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream); break;
+   default: throw Error(-1, "xt_b: block width must be 16, 32, 48 or 64");
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 x_t:  Y[s][c] = sum_snp X[s][snp] T[snp][c]
+//   workgroup = 64*MT samples x all b columns, wave = 16*MT samples (MT m-tiles), K = SNPs.
+//   The reduction runs over SNPs, which are pitch bytes apart in the packed stream, so a
+//   [64 SNP x 16*MT byte] tile of the stream is staged through LDS with 16-byte coalesced loads (128-byte
+//   lines for MT=8), together with the 64 x b tile of T and the 64 x 4 lookup-table tile.  Lane (i, kq) owns
+//   samples MT*i .. MT*i+MT-1 of its wave (one ushort / byte of the record), so m-tile m row i is sample
+//   MT*i + m: again a permutation chosen so that decode needs no cross-lane traffic.  The standardised
+//   value is fetched from the LDS table with the raw 2-bit code as index (ds_read_b64 gather).
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ packed, size_t pitch,
+                                                 const double *__restrict__ lut, const double *__restrict__ T,
+                                                 double *__restrict__ Ypart, uint64_t N_pad, int chunks_total,
+                                                 int chunks_per_split)
+{
+   constexpr int b = 16 * NT;
+   constexpr int ROWB = 16 * MT;                       // bytes of one record inside the workgroup tile
+   constexpr int NP = X_KC * ROWB / (256 * 16);        // packed 16-byte pieces per thread (2 for MT=8, 1 for MT=4)
+   constexpr int NTL = X_KC * b * 8 / (256 * 16);      // T-tile pieces per thread (= 2 NT)
+   constexpr int SEG = ROWB / 16;                      // 16-byte pieces per record row
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+   double *sT = reinterpret_cast<double *>(smem_raw);                  // [X_KC][b]
+   double *sL = sT + X_KC * b;                                         // [X_KC][4]
+   unsigned char *sP = reinterpret_cast<unsigned char *>(sL + X_KC * 4); // [X_KC][ROWB]
+
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int li = lane & 15, kq = lane >> 4;
+   const size_t wg_byte0 = (size_t)blockIdx.x * ROWB;
+   const int c_begin = blockIdx.y * chunks_per_split;
+   int c_end = c_begin + chunks_per_split;
+   if (c_end > chunks_total) c_end = chunks_total;
+
+   d4 acc[MT][NT];
+#pragma unroll
+   for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[m][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+
+   u4 preg[NP];
+   d2 treg[NTL];
+   d2 lreg;
+#define FPCA_XT_ISSUE(cc)                                                                                     \
+   {                                                                                                           \
+      const uint64_t snp_c0 = (uint64_t)(cc) * X_KC;                                                           \
+      _Pragma("unroll") for (int r = 0; r < NP; r++)                                                           \
+      {                                                                                                        \
+         const int p = tid + 256 * r;                                                                          \
+         const int prow = p / SEG, pseg = p % SEG;                                                             \
+         preg[r] = *reinterpret_cast<const u4 *>(packed + (snp_c0 + prow) * pitch + wg_byte0 + pseg * 16);  \
+      }                                                                                                        \
+      const d2 *tsrc = reinterpret_cast<const d2 *>(T + snp_c0 * b);                                 \
+      _Pragma("unroll") for (int r = 0; r < NTL; r++) treg[r] = tsrc[tid + 256 * r];                           \
+      if (tid < X_KC * 2) lreg = reinterpret_cast<const d2 *>(lut + snp_c0 * 4)[tid];                     \
+   }
+
+   if (c_begin < c_end) FPCA_XT_ISSUE(c_begin);
+
+   const unsigned char *sP_lane = sP + (size_t)kq * ROWB + wave * (4 * MT) + li * (MT / 4);
+   const double *sT_lane = sT + (size_t)kq * b + li;
+   const double *sL_lane = sL + (size_t)kq * 4;
+
+   for (int c = c_begin; c < c_end; c++) {
+      __syncthreads();
+      {
+#pragma unroll
+         for (int r = 0; r < NP; r++) reinterpret_cast<u4 *>(sP)[tid + 256 * r] = preg[r];
+#pragma unroll
+         for (int r = 0; r < NTL; r++) reinterpret_cast<d2 *>(sT)[tid + 256 * r] = treg[r];
+         if (tid < X_KC * 2) reinterpret_cast<d2 *>(sL)[tid] = lreg;
+      }
+      __syncthreads();
+      if (c + 1 < c_end) FPCA_XT_ISSUE(c + 1);
+#pragma unroll
+      for (int t = 0; t < X_KC / 4; t++) {
+         uint32_t h;
+         if (MT == 8)
+            h = *reinterpret_cast<const unsigned short *>(sP_lane + (size_t)(4 * t) * ROWB);
+         else
+            h = *(sP_lane + (size_t)(4 * t) * ROWB);
+         double tv[NT];
+#pragma unroll
+         for (int nt = 0; nt < NT; nt++) tv[nt] = sT_lane[(size_t)(4 * t) * b + nt * 16];
+         const double *lrow = sL_lane + (size_t)(4 * t) * 4;
+#pragma unroll
+         for (int m = 0; m < MT; m++) {
+            const double a = lrow[(h >> (2 * m)) & 3u];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[m][nt] = FPCA_MFMA(a, tv[nt], acc[m][nt]);
+         }
+      }
+   }
+#undef FPCA_XT_ISSUE
+
+   double *Yout = Ypart + (size_t)blockIdx.y * N_pad * b;
+   const uint64_t s_wave = (uint64_t)blockIdx.x * (64 * MT) + (uint64_t)wave * (16 * MT);
+#pragma unroll
+   for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+         for (int r = 0; r < 4; r++) {
+            const uint64_t s = s_wave + (uint64_t)MT * (kq + 4 * r) + m;
+            Yout[s * b + nt * 16 + li] = acc[m][nt][r];
+         }
+}
+
+static inline int x_t_mt(int b) { return b <= 32 ? 8 : 4; }
+
+int x_t_splits(uint64_t N_pad, uint64_t P_pad, int b)
+{
+   return pick_splits(N_pad / (64 * x_t_mt(b)), P_pad / X_KC, 4, 64);
+}
+
+template <int MT, int NT>
+static void launch_x_t(const uint8_t *packed, size_t pitch, const double *lut, const double *T, double *Ypart,
+                       uint64_t N_pad, uint64_t P_pad, int nsplit, hipStream_t stream)
+{
+   const int chunks_total = (int)(P_pad / X_KC);
+   const int cps = (chunks_total + nsplit - 1) / nsplit;
+   const size_t smem = (size_t)X_KC * 16 * NT * 8 + X_KC * 32 + (size_t)X_KC * 16 * MT;
+   static bool attr_set = false;
+   if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_x_t<MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)smem);
+      attr_set = true;
+   }
+   dim3 grid((unsigned)(N_pad / (64 * MT)), (unsigned)nsplit);
+   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_x_t<MT, NT>), grid, dim3(256), smem, stream, packed, pitch, lut, T, Ypart,
+                      N_pad, chunks_total, cps);
+   HIP_CHECK_LAUNCH();
+}
+
+void x_t(const uint8_t *packed, size_t pitch, const double *lut, const double *T, double *Ypart, uint64_t N_pad,
+         uint64_t P_pad, int b, int nsplit, hipStream_t stream)
+{
+   switch (b) {
+   case 16: launch_x_t<8, 1>(packed, pitch, lut, T, Ypart, N_pad, P_pad, nsplit, stream); break;
+   case 32: launch_x_t<8, 2>(packed, pitch, lut, T, Ypart, N_pad, P_pad, nsplit, stream); break;
+   case 48: launch_x_t<4, 3>(packed, pitch, lut, T, Ypart, N_pad, P_pad, nsplit, stream); break;
+   case 64: launch_x_t<4, 4>(packed, pitch, lut, T, Ypart, N_pad, P_pad, nsplit, stream); break;
+   default: throw Error(-1, "x_t: block width must be 16, 32, 48 or 64");
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic split-K combine: out[i] = sum_s part[s][i]
+__global__ __launch_bounds__(256) void k_reduce_sum(const double2 *__restrict__ part, double2 *__restrict__ out,
+                                                     uint64_t count2, int nsplit)
+{
+   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count2; i += (uint64_t)gridDim.x * 256) {
+      double2 s = part[i];
+      for (int k = 1; k < nsplit; k++) {
+         const double2 v = part[(uint64_t)k * count2 + i];
+         s.x += v.x;
+         s.y += v.y;
+      }
+      out[i] = s;
+   }
+}
+
+void reduce_sum(const double *part, double *out, uint64_t count, int nsplit, hipStream_t stream)
+{
+   if (count == 0) return;
+   const uint64_t count2 = count / 2; // all our buffers have even element counts
+   uint64_t blocks = (count2 + 255) / 256;
+   if (blocks > 4096) blocks = 4096;
+   hipLaunchKernelGGL(k_reduce_sum, dim3((unsigned)blocks), dim3(256), 0, stream,
+                      reinterpret_cast<const double2 *>(part), reinterpret_cast<double2 *>(out), count2, nsplit);
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 gram: part[(split*4+wave)][q][p][c] = sum_{rows of the wave} A_q[s][p] W[s][c]
+//   MFMA roles: A[i = p][k = sample] and B[k = sample][j = c] are both read straight from HBM, 16 lanes
+//   covering 128 contiguous bytes of a row; HBM-bound (each A_q read once, W once per q).
+template <int NT>
+__global__ __launch_bounds__(256) void k_gram(const double *const *__restrict__ blocks, const double *__restrict__ W,
+                                               double *__restrict__ part, uint64_t N_pad, int rows_per_split, int nq)
+{
+   constexpr int b = 16 * NT;
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int li = lane & 15, kq = lane >> 4;
+   const int q = blockIdx.y;
+   const double *__restrict__ A = blocks[q];
+   uint64_t r0 = (uint64_t)blockIdx.x * rows_per_split;
+   uint64_t r1 = r0 + rows_per_split;
+   if (r1 > N_pad) r1 = N_pad;
+   const uint64_t per_wave = (r1 - r0) / 4;
+   const uint64_t ws = r0 + wave * per_wave, we = ws + per_wave;
+
+   d4 acc[NT][NT];
+#pragma unroll
+   for (int pt = 0; pt < NT; pt++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[pt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+
+   for (uint64_t s = ws; s < we; s += 4) {
+      const uint64_t row = s + kq;
+      double a[NT], w[NT];
+#pragma unroll
+      for (int pt = 0; pt < NT; pt++) a[pt] = A[row * b + pt * 16 + li];
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) w[nt] = W[row * b + nt * 16 + li];
+#pragma unroll
+      for (int pt = 0; pt < NT; pt++)
+#pragma unroll
+         for (int nt = 0; nt < NT; nt++) acc[pt][nt] = FPCA_MFMA(a[pt], w[nt], acc[pt][nt]);
+   }
+   double *out = part + ((size_t)(blockIdx.x * 4 + wave) * nq + q) * (size_t)(b * b);
+#pragma unroll
+   for (int pt = 0; pt < NT; pt++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+         for (int r = 0; r < 4; r++) out[(size_t)(pt * 16 + kq + 4 * r) * b + nt * 16 + li] = acc[pt][nt][r];
+}
+
+static constexpr int GRAM_ROWS = 2048;
+int gram_splits(uint64_t N_pad) { return (int)((N_pad + GRAM_ROWS - 1) / GRAM_ROWS); }
+
+void gram(const double *const *blocks, int nq, const double *W, double *part, uint64_t N_pad, int b, int nsplit,
+          hipStream_t stream)
+{
+   if (nq <= 0) return;
+   dim3 grid((unsigned)nsplit, (unsigned)nq);
+   switch (b) {
+   case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<1>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, GRAM_ROWS, nq); break;
+   case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<2>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, GRAM_ROWS, nq); break;
+   case 48: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<3>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, GRAM_ROWS, nq); break;
+   case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<4>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, GRAM_ROWS, nq); break;
+   default: throw Error(-1, "gram: block width must be 16, 32, 48 or 64");
+   }
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 block_gemm: Out = Init + sum_q A_q C_q.  A wave owns 16 rows; lane (i, kq) loads the contiguous
+// quarter kq of row i of A_q (b/4 doubles), so a wave reads 16 full rows = 16*b*8 contiguous bytes, and the
+// K order is permuted accordingly (k-step t of lane group kq is column kq*b/4 + t).  C is tiny and stays
+// in L1/L2.  Reads of a wave's rows all precede its stores, so Out may alias Init or any A_q.
+template <int NT>
+__global__ __launch_bounds__(256) void k_block_gemm(const double *const *__restrict__ blocks, int nq,
+                                                     const double *__restrict__ C, const double *Init, double *Out,
+                                                     uint64_t N_pad)
+{
+   constexpr int b = 16 * NT;
+   constexpr int KS = b / 4;
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int li = lane & 15, kq = lane >> 4;
+   const uint64_t s0 = ((uint64_t)blockIdx.x * 4 + wave) * 16;
+   if (s0 >= N_pad) return;
+   d4 acc[NT];
+#pragma unroll
+   for (int nt = 0; nt < NT; nt++) {
+      if (Init) {
+#pragma unroll
+         for (int r = 0; r < 4; r++) acc[nt][r] = Init[(s0 + kq + 4 * r) * b + nt * 16 + li];
+      } else
+         acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
+   }
+   for (int q = 0; q < nq; q++) {
+      const double *A = blocks[q];
+      const double *Cq = C + (size_t)q * b * b;
+      double areg[KS];
+      const d2 *src = reinterpret_cast<const d2 *>(A + (s0 + li) * b + kq * KS);
+#pragma unroll
+      for (int r = 0; r < KS / 2; r++) {
+         const d2 v = src[r];
+         areg[2 * r] = v.x;
+         areg[2 * r + 1] = v.y;
+      }
+#pragma unroll
+      for (int t = 0; t < KS; t++) {
+         const int p = kq * KS + t;
+#pragma unroll
+         for (int nt = 0; nt < NT; nt++) acc[nt] = FPCA_MFMA(areg[t], Cq[(size_t)p * b + nt * 16 + li], acc[nt]);
+      }
+   }
+#pragma unroll
+   for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) Out[(s0 + kq + 4 * r) * b + nt * 16 + li] = acc[nt][r];
+}
+
+void block_gemm(const double *const *blocks, int nq, const double *C, const double *Init, double *Out, uint64_t N_pad,
+                int b, hipStream_t stream)
+{
+   dim3 grid((unsigned)(N_pad / 64));
+   switch (b) {
+   case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm<1>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad); break;
+   case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm<2>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad); break;
+   case 48: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm<3>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad); break;
+   case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm<4>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad); break;
+   default: throw Error(-1, "block_gemm: block width must be 16, 32, 48 or 64");
+   }
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fill_random(double *blk, uint64_t N, uint64_t total, int b, uint64_t seed)
+{
+   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+      const uint64_t s = i / b;
+      double v = 0.0;
+      if (s < N) {
+         const uint64_t h = synth::mix64(synth::mix64(seed ^ 0x5851F42D4C957F2Dull) ^ (i * 0x9E3779B97F4A7C15ull));
+         v = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+      }
+      blk[i] = v;
+   }
+}
+
+void fill_random(double *blk, uint64_t N, uint64_t N_pad, int b, uint64_t seed, hipStream_t stream)
+{
+   const uint64_t total = N_pad * b;
+   uint64_t blocks = (total + 255) / 256;
+   if (blocks > 8192) blocks = 8192;
+   hipLaunchKernelGGL(k_fill_random, dim3((unsigned)blocks), dim3(256), 0, stream, blk, N, total, b, seed);
+   HIP_CHECK_LAUNCH();
+}
+
+__global__ void k_block_to_colmajor(const double *blk, uint64_t N, int b, int ncols, double *out, uint64_t ld)
+{
+   const uint64_t total = N * ncols;
+   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+      const uint64_t s = i / ncols;
+      const int c = (int)(i % ncols);
+      out[(uint64_t)c * ld + s] = blk[s * b + c];
+   }
+}
+
+void block_to_colmajor(const double *blk, uint64_t N, int b, int ncols, double *out, uint64_t ld, hipStream_t stream)
+{
+   uint64_t blocks = (N * ncols + 255) / 256;
+   if (blocks == 0) return;
+   if (blocks > 8192) blocks = 8192;
+   hipLaunchKernelGGL(k_block_to_colmajor, dim3((unsigned)blocks), dim3(256), 0, stream, blk, N, b, ncols, out, ld);
+   HIP_CHECK_LAUNCH();
+}
+
+__global__ void k_colmajor_to_block(const double *in, uint64_t ld, uint64_t N, uint64_t N_pad, int b, int ncols,
+                                    double *blk)
+{
+   const uint64_t total = N_pad * b;
+   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+      const uint64_t s = i / b;
+      const int c = (int)(i % b);
+      blk[i] = (s < N && c < ncols) ? in[(uint64_t)c * ld + s] : 0.0;
+   }
+}
+
+void colmajor_to_block(const double *in, uint64_t ld, uint64_t N, uint64_t N_pad, int b, int ncols, double *blk,
+                       hipStream_t stream)
+{
+   uint64_t blocks = (N_pad * b + 255) / 256;
+   if (blocks > 8192) blocks = 8192;
+   hipLaunchKernelGGL(k_colmajor_to_block, dim3((unsigned)blocks), dim3(256), 0, stream, in, ld, N, N_pad, b, ncols, blk);
+   HIP_CHECK_LAUNCH();
+}
+
+__global__ void k_t_to_colmajor(const double *T, uint64_t P_g, int b, int ncols, const double *colscale, double *out,
+                                uint64_t ld)
+{
+   const uint64_t total = P_g * ncols;
+   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+      const uint64_t j = i / ncols;
+      const int c = (int)(i % ncols);
+      const double sc = colscale ? colscale[c] : 1.0;
+      out[(uint64_t)c * ld + j] = T[j * b + c] * sc;
+   }
+}
+
+void t_to_colmajor(const double *T, uint64_t P_g, int b, int ncols, const double *colscale, double *out, uint64_t ld,
+                   hipStream_t stream)
+{
+   uint64_t blocks = (P_g * ncols + 255) / 256;
+   if (blocks == 0) return;
+   if (blocks > 8192) blocks = 8192;
+   hipLaunchKernelGGL(k_t_to_colmajor, dim3((unsigned)blocks), dim3(256), 0, stream, T, P_g, b, ncols, colscale, out, ld);
+   HIP_CHECK_LAUNCH();
+}
+
+__global__ void k_colmajor_to_t(const double *in, uint64_t ld, uint64_t P_g, uint64_t P_pad, int b, int ncols, double *T)
+{
+   const uint64_t total = P_pad * b;
+   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+      const uint64_t j = i / b;
+      const int c = (int)(i % b);
+      T[i] = (j < P_g && c < ncols) ? in[(uint64_t)c * ld + j] : 0.0;
+   }
+}
+
+void colmajor_to_t(const double *in, uint64_t ld, uint64_t P_g, uint64_t P_pad, int b, int ncols, double *T,
+                   hipStream_t stream)
+{
+   uint64_t blocks = (P_pad * b + 255) / 256;
+   if (blocks > 8192) blocks = 8192;
+   hipLaunchKernelGGL(k_colmajor_to_t, dim3((unsigned)blocks), dim3(256), 0, stream, in, ld, P_g, P_pad, b, ncols, T);
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic genotypes straight into HBM: one workgroup per SNP record, one 32-bit word (16 samples) per
+// thread per iteration; integer-only model of synth.hpp, so the host can reproduce any record bit for bit.
+__global__ __launch_bounds__(256) void k_synth_generate(uint8_t *packed, size_t pitch, uint64_t N, uint64_t snp_begin,
+                                                         uint64_t seed, int n_pop, uint32_t fst_fp, uint32_t miss_thr)
+{
+   __shared__ uint32_t thr[synth::MAX_POP];
+   __shared__ uint64_t bnd[synth::MAX_POP + 1];
+   const uint64_t snp = snp_begin + blockIdx.x;
+   const uint32_t pj = synth::snp_freq(seed, snp);
+   if ((int)threadIdx.x < n_pop) thr[threadIdx.x] = synth::pop_freq(seed, snp, pj, fst_fp, (int)threadIdx.x);
+   if ((int)threadIdx.x <= n_pop) bnd[threadIdx.x] = synth::pop_boundary(N, n_pop, (int)threadIdx.x);
+   __syncthreads();
+   uint32_t *row = reinterpret_cast<uint32_t *>(packed + (size_t)blockIdx.x * pitch);
+   const uint32_t nwords = (uint32_t)(pitch / 4);
+   for (uint32_t w = threadIdx.x; w < nwords; w += 256) {
+      const uint64_t s0 = (uint64_t)w * 16;
+      uint32_t out = 0x55555555u; // padding = missing
+      if (s0 < N) {
+         int lo = 0, hi = n_pop; // population of s0: largest c with bnd[c] <= s0
+         while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (bnd[mid] <= s0)
+               lo = mid;
+            else
+               hi = mid;
+         }
+         int pop = lo;
+         out = 0;
+         for (int s = 0; s < 16; s++) {
+            const uint64_t smp = s0 + s;
+            uint32_t code = 1u;
+            if (smp < N) {
+               while (pop + 1 < n_pop && smp >= bnd[pop + 1]) pop++;
+               code = synth::cell_code(seed, snp, smp, thr[pop], miss_thr);
+            }
+            out |= code << (2 * s);
+         }
+      }
+      row[w] = out;
+   }
+}
+
+void synth_generate(uint8_t *packed, size_t pitch, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed,
+                    int n_pop, uint32_t fst_fp, uint32_t miss_thr, hipStream_t stream)
+{
+   if (P_g == 0) return;
+   hipLaunchKernelGGL(k_synth_generate, dim3((unsigned)P_g), dim3(256), 0, stream, packed, pitch, N, snp_begin, seed,
+                      n_pop, fst_fp, miss_thr);
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mfma_layout_probe(const double *A /*16x4 row-major*/, const double *B /*4x16 row-major*/,
+                                    double *D /*16x16 row-major*/)
+{
+   const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+   acc = FPCA_MFMA(A[li * 4 + kq], B[kq * 16 + li], acc);
+   for (int r = 0; r < 4; r++) D[(kq + 4 * r) * 16 + li] = acc[r];
+}
+
+void mfma_layout_probe(const double *A, const double *B, double *D, hipStream_t stream)
+{
+   hipLaunchKernelGGL(k_mfma_layout_probe, dim3(1), dim3(64), 0, stream, A, B, D);
+   HIP_CHECK_LAUNCH();
+}
+
+} // namespace kern
+} // namespace fpca

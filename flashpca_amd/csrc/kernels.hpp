@@ -1,0 +1,64 @@
+// kernels.hpp -- launch wrappers of the hand-written gfx950 kernels (kernels.hip).
+// All pointers are DEVICE pointers; every launch is asynchronous on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace fpca {
+namespace kern {
+
+// rewrite the pad bits of the last valid byte of every record to the "missing" code (N % 4 != 0)
+void fix_last_byte(uint8_t *packed, size_t pitch, uint64_t np, int valid_in_last, uint64_t P_g, hipStream_t stream);
+
+// K1: per-SNP code counts -> mean, sd, lookup table (by raw PLINK code), sum of squares
+//   lut [P_pad][4], mean/sd/sumsq [P_pad]; rows >= P_g untouched (must be pre-zeroed)
+void bed_stats(const uint8_t *packed, size_t pitch, uint64_t N, uint64_t P_g, int stand_method, double *lut,
+               double *mean, double *sd, double *sumsq, hipStream_t stream);
+// lookup table from preloaded mean/sd (projection path, data.cpp:293-320)
+void lut_from_meansd(const double *mean, const double *sd, uint64_t P_g, double *lut, hipStream_t stream);
+
+// K2: Tpart[split][P_pad][b] = X^T B over the split's sample chunks.   b = 16*NT, NT in 1..4
+//   B: [N_pad][b] row-major.  nsplit==1 writes the final T directly.
+void xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *B, double *Tpart, uint64_t N_pad,
+          uint64_t P_pad, int b, int nsplit, hipStream_t stream);
+// K3: Ypart[split][N_pad][b] = X T over the split's SNP chunks.  T: [P_pad][b] row-major
+void x_t(const uint8_t *packed, size_t pitch, const double *lut, const double *T, double *Ypart, uint64_t N_pad,
+         uint64_t P_pad, int b, int nsplit, hipStream_t stream);
+// out[i] = sum_s part[s*count + i]   (deterministic split-K combine)
+void reduce_sum(const double *part, double *out, uint64_t count, int nsplit, hipStream_t stream);
+
+// heuristics (host): number of splits for K2 / K3 given the problem and the chip (256 CUs, 2 WGs/CU)
+int xt_b_splits(uint64_t N_pad, uint64_t P_pad, int b);
+int x_t_splits(uint64_t N_pad, uint64_t P_pad, int b);
+
+// K4 helpers on row-major [N_pad][b] blocks ------------------------------------------------------------
+// part[split][q][b][b] (row-major p,c) = A_q^T W over the split's rows; `blocks` = device array of nq pointers
+void gram(const double *const *blocks, int nq, const double *W, double *part, uint64_t N_pad, int b, int nsplit,
+          hipStream_t stream);
+int gram_splits(uint64_t N_pad);
+// Out = (Init ? Init : 0) + sum_q A_q C_q,   C: [nq][b][b] row-major (C_q[p][c]); Out may alias Init or any A_q
+void block_gemm(const double *const *blocks, int nq, const double *C, const double *Init, double *Out, uint64_t N_pad,
+                int b, hipStream_t stream);
+// uniform(-0.5, 0.5) entries for rows < N, zero for rows in [N, N_pad)
+void fill_random(double *blk, uint64_t N, uint64_t N_pad, int b, uint64_t seed, hipStream_t stream);
+// row-major [N_pad][b] block <-> column-major N x ncols (ld) device staging buffer
+void block_to_colmajor(const double *blk, uint64_t N, int b, int ncols, double *out, uint64_t ld, hipStream_t stream);
+void colmajor_to_block(const double *in, uint64_t ld, uint64_t N, uint64_t N_pad, int b, int ncols, double *blk,
+                       hipStream_t stream);
+// T [P_pad][b] row-major -> column-major P_g x ncols, scaled per column
+void t_to_colmajor(const double *T, uint64_t P_g, int b, int ncols, const double *colscale, double *out, uint64_t ld,
+                   hipStream_t stream);
+void colmajor_to_t(const double *in, uint64_t ld, uint64_t P_g, uint64_t P_pad, int b, int ncols, double *T,
+                   hipStream_t stream);
+
+// synthetic genotype generator (synth.hpp model), one workgroup per SNP record
+void synth_generate(uint8_t *packed, size_t pitch, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed,
+                    int n_pop, uint32_t fst_fp, uint32_t miss_thr, hipStream_t stream);
+
+// diagnostic: D(16x16) = A(16x4) B(4x16) through v_mfma_f64_16x16x4_f64 with this file's operand mapping
+void mfma_layout_probe(const double *A, const double *B, double *D, hipStream_t stream);
+
+} // namespace kern
+} // namespace fpca

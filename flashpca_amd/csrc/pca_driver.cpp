@@ -1,0 +1,89 @@
+// pca_driver.cpp -- see pca_driver.hpp.  Post-processing follows randompca.cpp:180-208 line by line.
+#include "pca_driver.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+#include "solver.hpp"
+
+namespace fpca {
+
+int choose_blockvec(int ndim, int requested)
+{
+   if (ndim < 1) throw Error(FPCA_EINVAL, "ndim must be >= 1");
+   if (ndim > MAX_BLOCKVEC) throw Error(FPCA_EINVAL, "ndim > 64 is not supported by this build");
+   int b = requested;
+   if (b <= 0) {
+      b = (int)round_up((uint64_t)ndim + 4, 16);
+      if (b > MAX_BLOCKVEC) b = MAX_BLOCKVEC;
+   }
+   if (b % 16 != 0 || b < 16 || b > MAX_BLOCKVEC) throw Error(FPCA_EINVAL, "blockvec must be 16, 32, 48 or 64");
+   if (b < ndim) throw Error(FPCA_EINVAL, "blockvec must be >= ndim");
+   return b;
+}
+
+int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaOutputs &out, fpca_pca_info *info,
+            int *ritz_block, double *div_out)
+{
+   auto t0 = std::chrono::steady_clock::now();
+   const uint64_t N = be.nrows();
+   const int k = o.ndim;
+   SolverOpts so;
+   so.k = k;
+   so.max_applies = o.maxiter > 0 ? o.maxiter : 500;
+   so.tol = o.tol > 0 ? o.tol : 1e-6;
+   so.max_blocks = o.max_blocks;
+   so.seed = o.seed ? o.seed : 1;
+   so.verbose = o.verbose;
+   SolverResult r = block_krylov_schur(be, so);
+
+   double div = 1; // randompca.cpp:180-184
+   if (o.divisor == FPCA_DIVISOR_N1)
+      div = (double)N - 1;
+   else if (o.divisor == FPCA_DIVISOR_P)
+      div = (double)P_div;
+   if (div_out) *div_out = div;
+   const double trace = be.trace() / div; // :205
+   std::vector<double> d(k);
+   for (int j = 0; j < k; j++) d[j] = r.evals[j] / div; // :190
+   if (out.d)
+      for (int j = 0; j < k; j++) out.d[j] = d[j];
+   if (out.pve)
+      for (int j = 0; j < k; j++) out.pve[j] = d[j] / trace; // :206
+   if (out.U || out.Px) {
+      std::vector<double> tmp;
+      double *U = out.U;
+      if (!U) {
+         tmp.resize((size_t)N * k);
+         U = tmp.data();
+      }
+      be.download(r.ritz_block, k, U, (int64_t)N);
+      if (out.Px)
+         for (int j = 0; j < k; j++) { // :207  Px = U diag(sqrt(d))
+            const double sq = std::sqrt(d[j]);
+            for (uint64_t i = 0; i < N; i++) out.Px[i + (size_t)j * N] = U[i + (size_t)j * N] * sq;
+         }
+   }
+   if (ritz_block)
+      *ritz_block = r.ritz_block;
+   else
+      be.free_block(r.ritz_block);
+   if (info) {
+      info->converged = r.converged ? 1 : 0;
+      info->block_applies = r.block_applies;
+      info->vector_ops = r.block_applies * be.width();
+      info->restarts = r.restarts;
+      info->blockvec = be.width();
+      info->trace = trace;
+      info->max_residual = r.max_rel_residual;
+      info->seconds_apply = be.seconds_apply();
+      info->seconds_ortho = be.seconds_other();
+      info->seconds_host = r.seconds_host;
+      info->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+   }
+   return r.converged ? FPCA_OK : FPCA_ENOTCONVERGED;
+}
+
+} // namespace fpca

@@ -1,0 +1,23 @@
+// pca_driver.hpp -- RandomPCA::pca_fast(Data&, ...) (randompca.cpp:168-218) on top of a BlockBackend:
+// eigensolve, then d = lambda/div, pve = d/trace, Px = U diag(sqrt(d)), optional loadings.
+#pragma once
+#include "../../include/fpca.h"
+#include "backend.hpp"
+
+namespace fpca {
+
+// block width for ndim wanted components: requested (validated) or the smallest multiple of 16 >= ndim + 4
+int choose_blockvec(int ndim, int requested);
+
+struct PcaOutputs {
+   double *U = nullptr, *d = nullptr, *Px = nullptr, *pve = nullptr;
+};
+
+// Runs the solver on `be` (whose width must equal choose_blockvec(...)).  N_div/P_div are the N and the TOTAL
+// SNP count used by the divisor (randompca.cpp:180-184).  On return *ritz_block (if non-null) holds the backend
+// block with the eigenvectors (caller frees it; used for the loadings), otherwise it is freed here.
+// Returns FPCA_OK or FPCA_ENOTCONVERGED (outputs are still filled with the current Ritz pairs).
+int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaOutputs &out, fpca_pca_info *info,
+            int *ritz_block, double *div_out);
+
+} // namespace fpca

@@ -1,0 +1,338 @@
+// solver.cpp -- block Krylov-Schur driver (see solver.hpp).
+//
+// Relation to the reference: RandomPCA::pca_fast hands the operator y = X X' x to Spectra's single-vector
+// implicitly restarted Lanczos with ncv = 2k+1 (randompca.cpp:173-178), which applies the operator one
+// vector at a time (a GEMV per SNP block).  Here the Krylov space is built b vectors at a time:
+//
+//   V_0 = orth(random N x b)
+//   repeat:  W = A V_{m-1}                                   one pass over the packed matrix (K2 + K3)
+//            H = [V_0..V_{m-1}]' W ; W -= [V_0..V_{m-1}] H   classical Gram-Schmidt, repeated (full re-orth.)
+//            W = Q R                                         scaled eigen-orthonormalisation (SVQB), twice
+//            T[:, m-1] = H (+ symmetric mirror)              projected matrix T = V' A V, explicitly computed
+//            (theta, S) = eig(T)                             host, (m b) x (m b)
+//            res_i = || R S[last block, i] ||                == || A u_i - theta_i u_i ||, u_i = V S[:, i]
+//            stop when res_i < tol * max(eps^(2/3), |theta_i|) for the k largest (Spectra's rule)
+//            V_m = Q, or thick restart keeping the b best Ritz vectors when the basis is full
+//
+// All N-sized work is delegated to the backend; this file only does (m b)-sized dense algebra.
+#include "solver.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "common.hpp"
+#include "symeig.hpp"
+
+namespace fpca {
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+inline double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+// small column-major helpers ------------------------------------------------------------------------
+inline void matmul(int m, int n, int k, const double *A, int lda, const double *B, int ldb, double *C, int ldc)
+{
+   for (int j = 0; j < n; j++) {
+      double *cj = C + (size_t)j * ldc;
+      for (int i = 0; i < m; i++) cj[i] = 0;
+      for (int p = 0; p < k; p++) {
+         const double bpj = B[(size_t)p + (size_t)j * ldb];
+         if (bpj == 0.0) continue;
+         const double *ap = A + (size_t)p * lda;
+         for (int i = 0; i < m; i++) cj[i] += ap[i] * bpj;
+      }
+   }
+}
+
+// Orthonormalise the columns of backend block w in place: W_in = W_out * R (R b x b, column-major, general).
+// Column-scaled eigen-orthonormalisation of the Gram matrix (robust to residual columns of very different
+// norms, which a plain Cholesky QR is not).  Directions whose scaled Gram eigenvalue is below the noise
+// floor are zeroed (returned count); their rows of R are zero.
+int svqb_pass(BlockBackend &be, int w, double zero_scale, std::vector<double> &R, std::vector<unsigned char> &dead_col)
+{
+   const int b = be.width();
+   std::vector<double> G((size_t)b * b), Gs((size_t)b * b), lam(b), d(b), M((size_t)b * b, 0.0);
+   be.gram(&w, 1, w, G.data()); // G[p][c] row-major == symmetric
+   for (int i = 0; i < b; i++)
+      for (int j = 0; j < i; j++) {
+         const double a = 0.5 * (G[(size_t)i * b + j] + G[(size_t)j * b + i]);
+         G[(size_t)i * b + j] = G[(size_t)j * b + i] = a;
+      }
+   const double tiny = zero_scale * zero_scale;
+   std::vector<unsigned char> zero_in(b, 0);
+   for (int i = 0; i < b; i++) {
+      const double g = G[(size_t)i * b + i];
+      if (!(g > tiny) || !std::isfinite(g)) {
+         zero_in[i] = 1;
+         d[i] = 1.0;
+      } else
+         d[i] = std::sqrt(g);
+   }
+   for (int i = 0; i < b; i++)
+      for (int j = 0; j < b; j++)
+         Gs[(size_t)i + (size_t)j * b] = (zero_in[i] || zero_in[j]) ? 0.0 : G[(size_t)i * b + j] / (d[i] * d[j]);
+   if (symeig_desc(b, Gs.data(), b, lam.data()) != 0) throw Error(-3, "svqb: small eigensolver failed");
+   const double floor_rel = 64.0 * b * DBL_EPSILON;
+   const double lmax = std::max(lam[0], 0.0);
+   int ndead = 0;
+   R.assign((size_t)b * b, 0.0);
+   dead_col.assign(b, 0);
+   // new column j of W = sum_p W[:, p] * M[p][j],  M = D^-1 Z Lambda^-1/2 ; R = Lambda^1/2 Z' D
+   for (int j = 0; j < b; j++) {
+      if (!(lam[j] > floor_rel * lmax) || lmax == 0.0) {
+         ndead++;
+         dead_col[j] = 1;
+         continue;
+      }
+      const double sq = std::sqrt(lam[j]);
+      for (int p = 0; p < b; p++) {
+         const double z = Gs[(size_t)p + (size_t)j * b];
+         M[(size_t)p * b + j] = zero_in[p] ? 0.0 : z / (d[p] * sq); // row-major [p][c] for gemm
+         R[(size_t)j + (size_t)p * b] = zero_in[p] ? 0.0 : sq * z * d[p]; // column-major R(j, p)
+      }
+   }
+   be.gemm(&w, 1, M.data(), -1, w);
+   return ndead;
+}
+
+} // namespace
+
+SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
+{
+   const int b = be.width();
+   const int k = o.k;
+   const uint64_t N = be.nrows();
+   if (k < 1 || k > b) throw Error(-1, "solver: need 1 <= k <= block width");
+   int mcap = o.max_blocks > 0 ? o.max_blocks : std::max(4, 512 / b);
+   // the basis [V_0..V_{m-1}, Q] must fit in N dimensions
+   const int fit = (int)std::min<uint64_t>(N / (uint64_t)b, 1u << 20) - 1;
+   if (fit < 2) throw Error(-1, "solver: too few samples for this block width (need N >= 3 b)");
+   mcap = std::min(mcap, fit);
+   if (mcap < 2) mcap = 2;
+   const int nmax = mcap * b;
+   const double eps23 = std::pow(DBL_EPSILON, 2.0 / 3.0);
+
+   SolverResult res;
+   double host_s = 0;
+   std::vector<int> V;
+   std::vector<double> T((size_t)nmax * nmax, 0.0), Tw((size_t)nmax * nmax), theta(nmax);
+   std::vector<double> H((size_t)nmax * b), C((size_t)nmax * b), negC((size_t)nmax * b);
+   std::vector<double> R1, R2, R3, R((size_t)b * b), tmp((size_t)b * b);
+   std::vector<unsigned char> dead, dead2;
+   auto Tat = [&](int i, int j) -> double & { return T[(size_t)i + (size_t)j * nmax]; };
+
+   // project W against all basis blocks once; accumulate coefficients into H (row-major [q][p][c])
+   auto project_out = [&](int w, bool accumulate) {
+      const int m = (int)V.size();
+      be.gram(V.data(), m, w, C.data());
+      const size_t cnt = (size_t)m * b * b;
+      for (size_t i = 0; i < cnt; i++) negC[i] = -C[i];
+      be.gemm(V.data(), m, negC.data(), w, w);
+      if (accumulate)
+         for (size_t i = 0; i < cnt; i++) H[i] += C[i];
+   };
+
+   // ---- start block ----------------------------------------------------------------------------
+   int v0 = be.alloc_block();
+   be.fill_random(v0, o.seed);
+   {
+      int nd = svqb_pass(be, v0, 0.0, R1, dead);
+      nd += svqb_pass(be, v0, 0.0, R2, dead);
+      if (nd) throw Error(-3, "solver: random start block is rank deficient");
+   }
+   V.push_back(v0);
+   int W = be.alloc_block();
+   double scale = 0; // running estimate of ||A|| (largest Ritz value)
+   std::vector<double> S; // eigenvectors of T (n x n, ld n)
+   int n = 0;
+   uint64_t reseed = o.seed * 7919 + 13;
+
+   while (res.block_applies < o.max_applies) {
+      const int m = (int)V.size();
+      be.apply(V[m - 1], W);
+      res.block_applies++;
+      std::fill(H.begin(), H.begin() + (size_t)m * b * b, 0.0);
+      project_out(W, true);
+      project_out(W, true);
+
+      // ---- orthonormalise the residual block: W = Q R --------------------------------------------
+      auto t0 = clk::now();
+      if (scale == 0) {
+         // first step: ||A|| estimate from the diagonal block H_00 (Rayleigh quotients)
+         for (int i = 0; i < b; i++) scale = std::max(scale, std::fabs(H[(size_t)i * b + i]));
+      }
+      host_s += since(t0);
+      const double zero_scale = scale * 16 * DBL_EPSILON * std::sqrt((double)N);
+      int ndead = svqb_pass(be, W, zero_scale, R1, dead);
+      // third projection (the normalisation may have amplified components along V), folded into H
+      {
+         be.gram(V.data(), m, W, C.data());
+         const size_t cnt = (size_t)m * b * b;
+         for (size_t i = 0; i < cnt; i++) negC[i] = -C[i];
+         be.gemm(V.data(), m, negC.data(), W, W);
+         // H += C * R1   (C: [q][p][c] row-major b x b per q; R1 column-major)
+         t0 = clk::now();
+         for (int q = 0; q < m; q++)
+            for (int p = 0; p < b; p++)
+               for (int c = 0; c < b; c++) {
+                  double s = 0;
+                  const double *cr = &C[((size_t)q * b + p) * b];
+                  for (int j = 0; j < b; j++) s += cr[j] * R1[(size_t)j + (size_t)c * b];
+                  H[((size_t)q * b + p) * b + c] += s;
+               }
+         host_s += since(t0);
+      }
+      ndead = std::max(ndead, 0);
+      int nd2 = svqb_pass(be, W, 0.0, R2, dead2);
+      // R = R2 * R1
+      matmul(b, b, b, R2.data(), b, R1.data(), b, R.data(), b);
+      // columns that died in either pass carry no information from A V: refill them with fresh random
+      // directions orthogonal to everything, so that the basis keeps full width (invariant-subspace case)
+      if (ndead + nd2 > 0) {
+         std::vector<double> E((size_t)b * b, 0.0);
+         int ndeadcols = 0;
+         // after pass 2 the dead directions are the zero columns of W: detect through its Gram diagonal
+         std::vector<double> G((size_t)b * b);
+         be.gram(&W, 1, W, G.data());
+         for (int c = 0; c < b; c++)
+            if (!(G[(size_t)c * b + c] > 0.5)) {
+               E[(size_t)c * b + c] = 1.0;
+               ndeadcols++;
+            }
+         if (ndeadcols > 0) {
+            if (o.verbose) std::fprintf(stderr, "[fpca] step %d: %d deflated direction(s) refilled\n", res.block_applies, ndeadcols);
+            int rnd = be.alloc_block();
+            for (int attempt = 0; attempt < 3; attempt++) {
+               be.fill_random(rnd, reseed++);
+               // zero the dead columns, add random ones there: W = W (I - E) + rnd E
+               std::vector<double> IE((size_t)b * b, 0.0);
+               for (int c = 0; c < b; c++) IE[(size_t)c * b + c] = 1.0 - E[(size_t)c * b + c];
+               be.gemm(&W, 1, IE.data(), -1, W);
+               be.gemm(&rnd, 1, E.data(), W, W);
+               project_out(W, false);
+               project_out(W, false);
+               std::vector<double> Ra, Rb;
+               std::vector<unsigned char> da;
+               int bad = svqb_pass(be, W, 0.0, Ra, da);
+               bad += svqb_pass(be, W, 0.0, Rb, da);
+               // the good columns were already orthonormal: the rotation mixes them, so fold it into R
+               // (rows of R belonging to refilled columns are zero, and stay zero in exact arithmetic)
+               matmul(b, b, b, Rb.data(), b, Ra.data(), b, tmp.data(), b);
+               // mask the contribution of the random columns: R_new = tmp * (I-E) * R
+               std::vector<double> t2((size_t)b * b);
+               for (int j = 0; j < b; j++)
+                  for (int i = 0; i < b; i++) t2[(size_t)i + (size_t)j * b] = tmp[(size_t)i + (size_t)j * b] * (1.0 - E[(size_t)j * b + j]);
+               std::vector<double> Rn((size_t)b * b);
+               matmul(b, b, b, t2.data(), b, R.data(), b, Rn.data(), b);
+               R = Rn;
+               if (bad == 0) break;
+               if (attempt == 2) throw Error(-3, "solver: could not complete the basis after deflation");
+            }
+            be.free_block(rnd);
+         }
+      }
+
+      // ---- projected matrix and Rayleigh-Ritz ------------------------------------------------------
+      t0 = clk::now();
+      n = m * b;
+      for (int q = 0; q < m; q++)
+         for (int p = 0; p < b; p++)
+            for (int c = 0; c < b; c++) {
+               const double h = H[((size_t)q * b + p) * b + c];
+               if (q == m - 1) continue;
+               Tat(q * b + p, (m - 1) * b + c) = h;
+               Tat((m - 1) * b + c, q * b + p) = h;
+            }
+      for (int p = 0; p < b; p++)
+         for (int c = 0; c < b; c++) {
+            const double h = 0.5 * (H[((size_t)(m - 1) * b + p) * b + c] + H[((size_t)(m - 1) * b + c) * b + p]);
+            Tat((m - 1) * b + p, (m - 1) * b + c) = h;
+         }
+      for (int j = 0; j < n; j++) std::memcpy(&Tw[(size_t)j * n], &T[(size_t)j * nmax], sizeof(double) * n);
+      if (symeig_desc(n, Tw.data(), n, theta.data()) != 0) throw Error(-3, "solver: projected eigensolver failed");
+      S.assign(Tw.begin(), Tw.begin() + (size_t)n * n);
+      scale = std::max(scale, std::fabs(theta[0]));
+      // residual estimates: || R * S[(m-1)b : mb, i] ||
+      res.residuals.assign(k, 0.0);
+      res.evals.assign(theta.begin(), theta.begin() + k);
+      bool all_conv = true;
+      double worst = 0;
+      for (int i = 0; i < k; i++) {
+         const double *s = &S[(size_t)(m - 1) * b + (size_t)i * n];
+         double r2 = 0;
+         for (int r = 0; r < b; r++) {
+            double acc = 0;
+            for (int c = 0; c < b; c++) acc += R[(size_t)r + (size_t)c * b] * s[c];
+            r2 += acc * acc;
+         }
+         const double rn = std::sqrt(r2);
+         res.residuals[i] = rn;
+         const double thr = o.tol * std::max(eps23, std::fabs(theta[i]));
+         worst = std::max(worst, rn / std::max(eps23, std::fabs(theta[i])));
+         if (!(rn < thr)) all_conv = false;
+      }
+      res.max_rel_residual = worst;
+      host_s += since(t0);
+      if (o.verbose)
+         std::fprintf(stderr, "[fpca] apply %3d  basis %4d  theta1 %.6g  theta_k %.6g  max rel resid %.3e\n",
+                      res.block_applies, n, theta[0], theta[k - 1], worst);
+      if (all_conv) {
+         res.converged = true;
+         break;
+      }
+      if (res.block_applies >= o.max_applies) break;
+
+      if (m + 1 > mcap) {
+         // ---- thick restart: keep the b best Ritz vectors + the new residual block -----------------
+         t0 = clk::now();
+         std::vector<double> Sk((size_t)m * b * b);
+         for (int q = 0; q < m; q++)
+            for (int p = 0; p < b; p++)
+               for (int c = 0; c < b; c++) Sk[((size_t)q * b + p) * b + c] = S[(size_t)(q * b + p) + (size_t)c * n];
+         std::vector<double> Cpl((size_t)b * b); // R * S[last block, 0:b]  (b x b, column-major)
+         matmul(b, b, b, R.data(), b, &S[(size_t)(m - 1) * b], n, Cpl.data(), b);
+         host_s += since(t0);
+         int Y = be.alloc_block();
+         be.gemm(V.data(), m, Sk.data(), -1, Y);
+         for (int q = 0; q < m; q++) be.free_block(V[q]);
+         V.clear();
+         V.push_back(Y);
+         V.push_back(W);
+         W = be.alloc_block();
+         std::fill(T.begin(), T.end(), 0.0);
+         for (int i = 0; i < b; i++) Tat(i, i) = theta[i];
+         for (int r = 0; r < b; r++)
+            for (int c = 0; c < b; c++) {
+               Tat(b + r, c) = Cpl[(size_t)r + (size_t)c * b];
+               Tat(c, b + r) = Cpl[(size_t)r + (size_t)c * b];
+            }
+         res.restarts++;
+      } else {
+         V.push_back(W);
+         W = be.alloc_block();
+      }
+   }
+
+   // ---- Ritz vectors of the last Rayleigh-Ritz: U = V S[:, 0:b] -----------------------------------
+   {
+      const int m = n / b;
+      std::vector<double> Sk((size_t)m * b * b);
+      for (int q = 0; q < m; q++)
+         for (int p = 0; p < b; p++)
+            for (int c = 0; c < b; c++) Sk[((size_t)q * b + p) * b + c] = S[(size_t)(q * b + p) + (size_t)c * n];
+      int U = be.alloc_block();
+      be.gemm(V.data(), m, Sk.data(), -1, U);
+      res.ritz_block = U;
+   }
+   for (int h : V) be.free_block(h);
+   be.free_block(W);
+   res.seconds_host = host_s;
+   return res;
+}
+
+} // namespace fpca

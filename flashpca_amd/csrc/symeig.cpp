@@ -1,0 +1,208 @@
+// symeig.cpp -- dense symmetric eigensolver (Householder tridiagonalisation + implicit-shift QL) and
+// small triangular helpers, used on the host for the (m*b x m*b) Rayleigh-Ritz problem of the block
+// Krylov-Schur driver (the "k x k Rayleigh-Ritz / small SVD stays on the host" part of the design).
+#include "symeig.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace fpca {
+
+namespace {
+
+// A = Q T Q', T tridiagonal (d, e).  On return A holds Q (column-major).
+void tridiagonalise(int n, double *A, int lda, double *d, double *e)
+{
+#define AA(i, j) A[(size_t)(i) + (size_t)(j) * lda]
+   std::vector<double> v(n), p(n), beta(n, 0.0);
+   // Householder vectors are stored below the sub-diagonal of A (column k, rows k+2..n-1; v[k+1] implicit 1)
+   for (int k = 0; k < n - 2; k++) {
+      const int m = n - k - 1; // length of x = A[k+1.., k]
+      double *x = &AA(k + 1, k);
+      double nrm = 0;
+      for (int i = 1; i < m; i++) nrm += x[i] * x[i];
+      if (nrm == 0.0) {
+         e[k] = x[0];
+         d[k] = AA(k, k);
+         beta[k] = 0;
+         continue;
+      }
+      const double x0 = x[0];
+      const double alpha = -std::copysign(std::sqrt(x0 * x0 + nrm), x0);
+      // v = x - alpha e1, scaled so that v[0] = 1
+      const double v0 = x0 - alpha;
+      v[0] = 1.0;
+      for (int i = 1; i < m; i++) v[i] = x[i] / v0;
+      const double bk = -v0 / alpha; // 2 / (v'v) with v[0] = 1
+      beta[k] = bk;
+      // p = bk * A22 v
+      for (int i = 0; i < m; i++) p[i] = 0;
+      for (int j = 0; j < m; j++) {
+         const double vj = v[j];
+         const double *col = &AA(k + 1, k + 1 + j);
+         for (int i = 0; i < m; i++) p[i] += col[i] * vj;
+      }
+      double vp = 0;
+      for (int i = 0; i < m; i++) {
+         p[i] *= bk;
+         vp += v[i] * p[i];
+      }
+      const double kk = 0.5 * bk * vp;
+      for (int i = 0; i < m; i++) p[i] -= kk * v[i]; // q
+      // A22 -= v q' + q v'
+      for (int j = 0; j < m; j++) {
+         double *col = &AA(k + 1, k + 1 + j);
+         const double vj = v[j], qj = p[j];
+         for (int i = 0; i < m; i++) col[i] -= v[i] * qj + p[i] * vj;
+      }
+      d[k] = AA(k, k);
+      e[k] = alpha;
+      for (int i = 1; i < m; i++) x[i] = v[i]; // keep the reflector (x[0] slot is not needed)
+   }
+   if (n >= 2) {
+      d[n - 2] = AA(n - 2, n - 2);
+      e[n - 2] = AA(n - 1, n - 2);
+   }
+   d[n - 1] = AA(n - 1, n - 1);
+   // accumulate Q = H_0 H_1 ... H_{n-3} into A (overwriting the reduced matrix), back to front
+   std::vector<double> Q((size_t)n * n, 0.0);
+   for (int i = 0; i < n; i++) Q[(size_t)i + (size_t)i * n] = 1.0;
+   for (int k = n - 3; k >= 0; k--) {
+      if (beta[k] == 0.0) continue;
+      const int m = n - k - 1;
+      v[0] = 1.0;
+      for (int i = 1; i < m; i++) v[i] = AA(k + 1 + i, k);
+      // Q[k+1.., k+1..] -= beta v (v' Q[k+1.., k+1..])
+      for (int j = 0; j < m; j++) {
+         double *col = &Q[(size_t)(k + 1) + (size_t)(k + 1 + j) * n];
+         double s = 0;
+         for (int i = 0; i < m; i++) s += v[i] * col[i];
+         s *= beta[k];
+         for (int i = 0; i < m; i++) col[i] -= s * v[i];
+      }
+   }
+   for (int j = 0; j < n; j++) std::memcpy(&AA(0, j), &Q[(size_t)j * n], sizeof(double) * n);
+#undef AA
+}
+
+// implicit-shift QL on (d, e) accumulating the rotations into the columns of Z (n x n, ld ldz)
+int tridiag_ql(int n, double *d, double *e_in, double *Z, int ldz)
+{
+   std::vector<double> e(n + 1, 0.0);
+   for (int i = 0; i < n - 1; i++) e[i] = e_in[i];
+   for (int l = 0; l < n; l++) {
+      int iter = 0, m;
+      do {
+         for (m = l; m < n - 1; m++) {
+            const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+            if (std::fabs(e[m]) <= DBL_EPSILON * dd) break;
+         }
+         if (m != l) {
+            if (iter++ == 300) return 1;
+            double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+            double r = std::hypot(g, 1.0);
+            g = d[m] - d[l] + e[l] / (g + std::copysign(r, g));
+            double s = 1.0, c = 1.0, p = 0.0;
+            int i;
+            for (i = m - 1; i >= l; i--) {
+               double f = s * e[i];
+               const double bb = c * e[i];
+               r = std::hypot(f, g);
+               e[i + 1] = r;
+               if (r == 0.0) {
+                  d[i + 1] -= p;
+                  e[m] = 0.0;
+                  break;
+               }
+               s = f / r;
+               c = g / r;
+               g = d[i + 1] - p;
+               r = (d[i] - g) * s + 2.0 * c * bb;
+               p = s * r;
+               d[i + 1] = g + p;
+               g = c * r - bb;
+               double *z0 = Z + (size_t)i * ldz, *z1 = Z + (size_t)(i + 1) * ldz;
+               for (int k = 0; k < n; k++) {
+                  f = z1[k];
+                  z1[k] = s * z0[k] + c * f;
+                  z0[k] = c * z0[k] - s * f;
+               }
+            }
+            if (r == 0.0 && i >= l) continue;
+            d[l] -= p;
+            e[l] = g;
+            e[m] = 0.0;
+         }
+      } while (m != l);
+   }
+   return 0;
+}
+
+} // namespace
+
+int symeig_desc(int n, double *A, int lda, double *w)
+{
+   if (n <= 0) return 0;
+   if (n == 1) {
+      w[0] = A[0];
+      A[0] = 1.0;
+      return 0;
+   }
+   std::vector<double> d(n), e(n, 0.0);
+   tridiagonalise(n, A, lda, d.data(), e.data());
+   int rc = tridiag_ql(n, d.data(), e.data(), A, lda);
+   if (rc) return rc;
+   std::vector<int> idx(n);
+   std::iota(idx.begin(), idx.end(), 0);
+   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return d[a] > d[b]; });
+   std::vector<double> Z((size_t)n * n);
+   for (int j = 0; j < n; j++) {
+      w[j] = d[idx[j]];
+      std::memcpy(&Z[(size_t)j * n], A + (size_t)idx[j] * lda, sizeof(double) * n);
+   }
+   for (int j = 0; j < n; j++) std::memcpy(A + (size_t)j * lda, &Z[(size_t)j * n], sizeof(double) * n);
+   return 0;
+}
+
+int cholesky_upper(int n, double *G, int ld, double rel_tol)
+{
+#define GG(i, j) G[(size_t)(i) + (size_t)(j) * ld]
+   double dmax = 0;
+   for (int i = 0; i < n; i++) dmax = std::max(dmax, std::fabs(GG(i, i)));
+   const double thresh = rel_tol * dmax;
+   for (int j = 0; j < n; j++) {
+      double s = GG(j, j);
+      for (int k = 0; k < j; k++) s -= GG(k, j) * GG(k, j);
+      if (!(s > thresh) || !std::isfinite(s)) return j + 1;
+      const double rjj = std::sqrt(s);
+      GG(j, j) = rjj;
+      for (int c = j + 1; c < n; c++) {
+         double t = GG(j, c);
+         for (int k = 0; k < j; k++) t -= GG(k, j) * GG(k, c);
+         GG(j, c) = t / rjj;
+      }
+   }
+   for (int j = 0; j < n; j++)
+      for (int i = j + 1; i < n; i++) GG(i, j) = 0.0;
+#undef GG
+   return 0;
+}
+
+void upper_inverse(int n, const double *R, int ldr, double *Rinv, int ldi)
+{
+   for (int j = 0; j < n; j++)
+      for (int i = 0; i < n; i++) Rinv[(size_t)i + (size_t)j * ldi] = 0.0;
+   for (int j = 0; j < n; j++) {
+      Rinv[(size_t)j + (size_t)j * ldi] = 1.0 / R[(size_t)j + (size_t)j * ldr];
+      for (int i = j - 1; i >= 0; i--) {
+         double s = 0;
+         for (int k = i + 1; k <= j; k++) s += R[(size_t)i + (size_t)k * ldr] * Rinv[(size_t)k + (size_t)j * ldi];
+         Rinv[(size_t)i + (size_t)j * ldi] = -s / R[(size_t)i + (size_t)i * ldr];
+      }
+   }
+}
+
+} // namespace fpca

@@ -1,0 +1,22 @@
+// symeig.hpp -- small dense host linear algebra for the projected (Rayleigh-Ritz) problem.
+// The reference delegates this to Spectra/Eigen (TridiagEigen, UpperHessenbergQR); here it is own code,
+// no third-party dependency.  All matrices column-major.
+#pragma once
+#include <vector>
+
+namespace fpca {
+
+// Eigen-decomposition of a dense symmetric n x n matrix (full storage, leading dimension lda).
+// On return w[0..n) holds the eigenvalues in DESCENDING order and column j of A the unit eigenvector of w[j].
+// Returns 0 on success, nonzero if the QL iteration failed to converge.
+int symeig_desc(int n, double *A, int lda, double *w);
+
+// Upper Cholesky factor: G = R' R, R overwrites the upper triangle of G (strict lower part zeroed).
+// Returns 0 on success, j+1 if the pivot of column j is not sufficiently positive (relative to rel_tol *
+// the largest original diagonal entry).
+int cholesky_upper(int n, double *G, int ld, double rel_tol);
+
+// inverse of an upper-triangular matrix (Rinv may not alias R)
+void upper_inverse(int n, const double *R, int ldr, double *Rinv, int ldi);
+
+} // namespace fpca

@@ -1,0 +1,202 @@
+/*
+ * include/fpca.h -- C ABI of the MI355X-native flashpca PCA hot path (libfpca.so).
+ *
+ * The reference (gabraham/flashpca 2.1) has no C ABI of its own on this path; its seams are
+ *   (1) the Spectra operator concept implemented by SVDWideOnline:
+ *          unsigned rows(); unsigned cols(); void perform_op(const double* x_in, double* y_out);
+ *                                                                    (svdwide.h:77-81, svdwide.cpp:21-68)
+ *   (2) the C++ driver  RandomPCA::pca_fast(Data&, block_size, ndim, maxiter, tol, seed, do_loadings)
+ *          with inputs  stand_method_x / divisor and outputs U, d, V, Px, pve, trace, X_meansd
+ *                                                                    (randompca.h:56-80, randompca.cpp:168-218)
+ *   (3) the data object  Data::{get_size, prepare, read_snp_block}   (data.h:60-101, data.cpp:150-335)
+ * Every entry point below names the reference interface it replaces.  Conventions:
+ *   - plain pointers and sizes only; no C++/torch types;
+ *   - host matrices are fp64 COLUMN-major with an explicit leading dimension (what Eigen::MatrixXd /
+ *     Map<VectorXd> hand to the reference operator);
+ *   - functions return 0 on success, a negative FPCA_E* code on failure; fpca_last_error() returns the
+ *     message of the last failure on the calling thread (the reference throws std::runtime_error,
+ *     flashpca.cpp:882-892 turns that into EXIT_FAILURE);
+ *   - a context owns ONE SNP shard [snp_begin, snp_begin+P_g) of the genotype matrix on ONE GPU:
+ *     packed 2-bit stream resident in HBM, per-SNP mean/sd/lookup table, workspaces and a HIP stream.
+ *     Multi-GPU = one context per process per GPU; the N x b product is summed across ranks either by
+ *     RCCL inside the library (fpca_comm_init_rank) or by a caller-supplied all-reduce (fpca_set_allreduce);
+ *   - there is NO CPU fallback: fpca_create* fail with FPCA_ENODEVICE when no gfx950 device is usable.
+ */
+#ifndef FPCA_H
+#define FPCA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPCA_VERSION "0.1.0"
+
+/* standardisation methods: same numeric values as the reference (util.h:34-38) */
+#define FPCA_STANDARDISE_BINOM 2
+#define FPCA_STANDARDISE_BINOM2 3
+/* eigenvalue divisor: same numeric values as the reference (randompca.h:41-43) */
+#define FPCA_DIVISOR_NONE 0
+#define FPCA_DIVISOR_N1 1
+#define FPCA_DIVISOR_P 2
+/* accumulate type of the two genotype GEMMs */
+#define FPCA_ACCUM_FP64 64
+#define FPCA_ACCUM_FP32 32
+
+#define FPCA_OK 0
+#define FPCA_EINVAL -1      /* bad argument */
+#define FPCA_ENODEVICE -2   /* no usable gfx950 device / HIP runtime error at init */
+#define FPCA_EHIP -3        /* HIP runtime or kernel failure */
+#define FPCA_ENOMEM -4      /* host or device allocation failed */
+#define FPCA_ENOTCONVERGED -5 /* eigensolver hit maxiter (reference: "Spectra eigen-decomposition was not successful", randompca.cpp:212-217) */
+#define FPCA_ECOMM -6       /* RCCL / all-reduce failure */
+#define FPCA_EIO -7         /* file error (reference: "[Data::read_bed] Error reading file", data.cpp:156-161) */
+
+typedef struct fpca_ctx fpca_ctx;
+
+const char *fpca_last_error(void);
+const char *fpca_version(void);
+/* number of visible HIP devices (<0 on error); name/arch of one device into buf */
+int fpca_device_count(void);
+int fpca_device_name(int device, char *buf, int buflen);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data: replaces Data::get_size + Data::prepare (data.cpp:150-206).  `packed` is the body of a SNP-major
+ * PLINK .bed for this shard: P_g records of ceil(N/4) bytes (i.e. file offset 3 + ceil(N/4)*snp_begin),
+ * sample 4i+s of a record in bits 2s..2s+1 of byte i (data.cpp:128-148).  The bytes are copied to HBM
+ * (re-pitched to 128-byte rows, pad positions rewritten to the "missing" code so they contribute 0);
+ * the caller may free `packed` on return. */
+int fpca_create(fpca_ctx **out, const uint8_t *packed, uint64_t N, uint64_t P_g, int stand_method,
+                int device, int accum);
+
+/* Same, reading the shard straight from a .bed file: records [snp_begin, snp_begin + P_g) (P_g = 0 means
+ * "to the end of the file").  N comes from the .fam as in the reference (flashpca.cpp:589). The total SNP
+ * count of the file, (filesize-3)/ceil(N/4) by integer division (data.cpp:165-170), is returned in *P_total. */
+int fpca_create_from_bed(fpca_ctx **out, const char *bed_path, uint64_t N, uint64_t snp_begin, uint64_t P_g,
+                         int stand_method, int device, int accum, uint64_t *P_total);
+
+/* Synthetic shard generated directly in HBM (bench / scale tests): structured
+ * population model, counter-based RNG keyed by (seed, snp, sample) so that any SNP range of the same
+ * (N, seed, n_pop, fst, missing_rate) matrix can be generated independently on any rank. */
+int fpca_create_synthetic(fpca_ctx **out, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed,
+                          int n_pop, double fst, double missing_rate, int stand_method, int device, int accum);
+
+void fpca_destroy(fpca_ctx *ctx);
+
+uint64_t fpca_nsamples(const fpca_ctx *ctx);   /* Data::N */
+uint64_t fpca_nsnps(const fpca_ctx *ctx);      /* shard's P_g (Data::nsnps for a 1-shard run) */
+/* copy the shard's packed stream back (P_g * ceil(N/4) bytes, .bed body layout) -- used by the tests to feed
+ * the CPU oracle the exact matrix a synthetic context holds */
+int fpca_download_packed(fpca_ctx *ctx, uint8_t *out);
+
+/* K1.  Replaces the first-visit branch of Data::read_snp_block (data.cpp:257-322): per-SNP mean over
+ * non-missing dosages, sd = sqrt(2P(1-P)) [binom2] / sqrt(P(1-P)) [binom], lookup table by raw code, and
+ * trace = sum X^2 (svdwide.cpp:44-45,60-61) for this shard.  mean_sd: P_g x 2 column-major (mean | sd), may be
+ * NULL; trace_out may be NULL.  Called implicitly by the first apply if the caller did not. */
+int fpca_stats(fpca_ctx *ctx, double *mean_sd, double *trace_out);
+/* preloaded mean/sd (projection path, data.cpp:293-297, randompca.cpp:753-788); P_g x 2 column-major */
+int fpca_set_meansd(fpca_ctx *ctx, const double *mean_sd);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator.  b columns at a time; b = 1 is exactly the reference's perform_op.
+ *   fpca_apply_xxt : Y = X_g X_g' B        replaces SVDWideOnline::perform_op / perform_op_mat
+ *                                           (svdwide.cpp:21-68, 71-118); summed over ranks when a
+ *                                           communicator / all-reduce hook is installed
+ *   fpca_apply_xt  : T = X_g' B  (P_g x b)  replaces SVDWideOnline::crossprod / crossprod2 (svdwide.cpp:122-188)
+ *   fpca_apply_x   : Y = X_g T   (N x b)    replaces SVDWideOnline::prod / prod3 (svdwide.cpp:193-226, 312-343)
+ * B, Y: N x b; T: P_g x b; host pointers, column-major, leading dimensions ldb/ldy/ldt (>= rows). */
+int fpca_apply_xxt(fpca_ctx *ctx, const double *B, int64_t ldb, int b, double *Y, int64_t ldy);
+int fpca_apply_xt(fpca_ctx *ctx, const double *B, int64_t ldb, int b, double *T, int64_t ldt);
+int fpca_apply_x(fpca_ctx *ctx, const double *T, int64_t ldt, int b, double *Y, int64_t ldy);
+
+/* Device-resident variants: B/Y are DEVICE pointers to row-major [fpca_block_rows()][b] fp64 blocks (rows
+ * >= N must be zero on input and are zero on output); T lives in the context.  The kernels are enqueued on
+ * `stream` (a hipStream_t; NULL = the context's own stream) and the call returns without synchronising.
+ * This is what the solver and bench.py use so that B and Y never leave HBM during the iteration. */
+uint64_t fpca_block_rows(const fpca_ctx *ctx); /* N rounded up to the kernels' sample tile (512) */
+int fpca_apply_xxt_dev(fpca_ctx *ctx, const double *dB, int b, double *dY, void *stream);
+/* contexts' own stream handle (hipStream_t) and a device-wide synchronise */
+void *fpca_stream(fpca_ctx *ctx);
+int fpca_synchronize(fpca_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU (SNP-sharded; one rank per GPU).  Two transports for the sum of the N x b partial products: */
+#define FPCA_UNIQUE_ID_BYTES 128
+/* (a) RCCL inside the library: rank 0 makes an id, the launcher broadcasts it, every rank joins. */
+int fpca_comm_unique_id(uint8_t id[FPCA_UNIQUE_ID_BYTES]);
+int fpca_comm_init_rank(fpca_ctx *ctx, int nranks, int rank, const uint8_t id[FPCA_UNIQUE_ID_BYTES]);
+/* (b) caller-supplied in-place sum all-reduce of `count` fp64 at device pointer `dbuf`, ordered on `stream`
+ * (e.g. torch.distributed over RCCL).  Must return 0 on success. */
+typedef int (*fpca_allreduce_fn)(void *user, double *dbuf, uint64_t count, void *stream);
+int fpca_set_allreduce(fpca_ctx *ctx, fpca_allreduce_fn fn, void *user);
+/* total SNP count over all shards (the divisor "p", randompca.cpp:183) -- defaults to the shard's P_g */
+int fpca_set_total_snps(fpca_ctx *ctx, uint64_t P_total);
+
+/* ------------------------------------------------------------------------------------------------
+ * Driver.  Replaces RandomPCA::pca_fast(Data&, block_size, ndim, maxiter, tol, seed, do_loadings)
+ * (randompca.cpp:168-218) with a block Krylov-Schur eigensolver whose basis stays in HBM; the projected
+ * (m*b x m*b) Rayleigh-Ritz problem is solved on the host.  Convergence rule per Ritz pair is the one the
+ * reference's Spectra solver applies: ||A u - theta u|| < tol * max(eps^(2/3), |theta|) for the ndim largest. */
+typedef struct fpca_pca_opts {
+   int ndim;        /* --ndim (flashpca.cpp:325 default 10) */
+   int blockvec;    /* block width b (multiple of 16, <= 64); 0 = smallest multiple of 16 >= ndim + 4 */
+   int maxiter;     /* maximum block applies (reference: 500 restarts, flashpca.cpp:426) */
+   double tol;      /* --tol (flashpca.cpp:440 default 1e-6) */
+   int divisor;     /* FPCA_DIVISOR_* (flashpca.cpp:484 default p) */
+   int do_loadings; /* --outload given */
+   int max_blocks;  /* basis cap in blocks before a thick restart; 0 = automatic */
+   int verbose;
+   uint64_t seed;   /* start block seed; the reference ignores --seed for PCA (randompca.cpp:168-218) */
+} fpca_pca_opts;
+
+typedef struct fpca_pca_info {
+   int converged;         /* all ndim pairs met the rule */
+   int block_applies;     /* passes over the packed matrix (each = b single-vector operator applications) */
+   int vector_ops;        /* block_applies * b  == the reference's nops unit (svdwide.cpp:67) */
+   int restarts;          /* thick restarts */
+   int blockvec;          /* b actually used */
+   double trace;          /* sum X^2 / div (randompca.cpp:205) */
+   double max_residual;   /* max_i ||A u_i - theta_i u_i|| / max(eps^(2/3), theta_i) at exit */
+   double seconds_apply;  /* device time in the operator (K2+K3+all-reduce) */
+   double seconds_ortho;  /* device time in basis orthogonalisation / Ritz rotation */
+   double seconds_host;   /* host time in the projected eigenproblem */
+   double seconds_total;
+} fpca_pca_info;
+
+void fpca_pca_default_opts(fpca_pca_opts *opts);
+/* Outputs (host, column-major, caller-allocated; any may be NULL):
+ *   U  N x ndim eigenvectors (unit 2-norm, sign arbitrary like Spectra's) ..... RandomPCA::U
+ *   d  ndim eigenvalues of X X'/div, descending .............................. RandomPCA::d
+ *   Px N x ndim = U diag(sqrt(d)) ............................................. RandomPCA::Px
+ *   pve ndim = d / trace ....................................................... RandomPCA::pve
+ *   V  P_g x ndim loadings rows of this shard = X_g' U diag(1/sqrt(d))/sqrt(div)  RandomPCA::V (randompca.cpp:191-204)
+ *   mean_sd P_g x 2 ............................................................. RandomPCA::X_meansd */
+int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, double *Px, double *pve,
+             double *V, double *mean_sd, fpca_pca_info *info);
+
+/* Replaces RandomPCA::check(Data&, block_size, evec, eval) (randompca.cpp:663-703):
+ * err[j] = || X X' u_j / div - u_j lambda_j ||^2, mse = sum(err)/(N k), rmse = sqrt(mse). */
+int fpca_check(fpca_ctx *ctx, const double *evec, int64_t ldu, const double *eval, int k, int divisor,
+               double *err, double *mse, double *rmse);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): run `steps` block-applies of width b on device-resident random blocks after
+ * `warmup` untimed ones; HIP events on the context's stream bracket every kernel.  Times in milliseconds. */
+typedef struct fpca_bench_result {
+   double ms_total;      /* wall (event) time of the timed region, all steps */
+   double ms_xt;         /* average per step in K2 (xt_b), incl. its split-K reduce */
+   double ms_x;          /* average per step in K3 (x_t), incl. its split-K reduce */
+   double ms_allreduce;  /* average per step in the all-reduce (0 for one rank) */
+   double flops_per_step;           /* 4 N P_g b */
+   double packed_bytes_per_step;    /* 2 ceil(N/4) P_g */
+} fpca_bench_result;
+int fpca_bench_apply(fpca_ctx *ctx, int b, int steps, int warmup, fpca_bench_result *res);
+/* time the one-off statistics pass (K1) the same way: milliseconds per launch, bytes read */
+int fpca_bench_stats(fpca_ctx *ctx, int reps, double *ms_per_launch, double *bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPCA_H */
