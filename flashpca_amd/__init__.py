@@ -1,0 +1,10 @@
+"""flashpca_amd -- MI355X-native implementation of flashpca's PCA hot path.
+
+The product is the C-ABI library flashpca_amd/_build/libfpca.so (include/fpca.h; hand-written gfx950 HIP kernels
++ C++ host eigensolver) and the drop-in `flashpca` CLI next to it.  This package is the thin Python mirror used
+by tests and bench.py.  There is no CPU fallback.
+"""
+from ._lib import LIB_PATH, CLI_PATH, build, lib, FpcaError  # noqa: F401
+from .api import Context, flashpca, count_fam_rows  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,137 @@
+"""ctypes binding of libfpca.so (include/fpca.h).  Plumbing only: every call goes straight through the C ABI.
+
+The library is built in-tree (flashpca_amd/_build/libfpca.so) by `make -C flashpca_amd/csrc` (see
+__graft_entry__.build()).  There is no fallback: if the library is missing this module raises, and if no
+gfx950 device is usable every fpca_create* call fails with FPCA_ENODEVICE.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "libfpca.so")
+CLI_PATH = os.path.join(HERE, "_build", "flashpca")
+CSRC = os.path.join(HERE, "csrc")
+
+STANDARDISE = {"binom": 2, "binom2": 3}
+DIVISOR = {"none": 0, "n1": 1, "p": 2}
+UNIQUE_ID_BYTES = 128
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+
+class PcaOpts(C.Structure):
+    _fields_ = [
+        ("ndim", C.c_int),
+        ("blockvec", C.c_int),
+        ("maxiter", C.c_int),
+        ("tol", C.c_double),
+        ("divisor", C.c_int),
+        ("do_loadings", C.c_int),
+        ("max_blocks", C.c_int),
+        ("verbose", C.c_int),
+        ("seed", C.c_uint64),
+    ]
+
+
+class PcaInfo(C.Structure):
+    _fields_ = [
+        ("converged", C.c_int),
+        ("block_applies", C.c_int),
+        ("vector_ops", C.c_int),
+        ("restarts", C.c_int),
+        ("blockvec", C.c_int),
+        ("trace", C.c_double),
+        ("max_residual", C.c_double),
+        ("seconds_apply", C.c_double),
+        ("seconds_ortho", C.c_double),
+        ("seconds_host", C.c_double),
+        ("seconds_total", C.c_double),
+    ]
+
+
+class BenchResult(C.Structure):
+    _fields_ = [
+        ("ms_total", C.c_double),
+        ("ms_xt", C.c_double),
+        ("ms_x", C.c_double),
+        ("ms_allreduce", C.c_double),
+        ("flops_per_step", C.c_double),
+        ("packed_bytes_per_step", C.c_double),
+    ]
+
+
+# every function include/fpca.h declares: name -> (restype, argtypes)
+_P, _U64, _I, _D = C.c_void_p, C.c_uint64, C.c_int, C.c_double
+SIGNATURES = {
+    "fpca_last_error": (C.c_char_p, []),
+    "fpca_version": (C.c_char_p, []),
+    "fpca_device_count": (_I, []),
+    "fpca_device_name": (_I, [_I, C.c_char_p, _I]),
+    "fpca_create": (_I, [C.POINTER(_P), _P, _U64, _U64, _I, _I, _I]),
+    "fpca_create_from_bed": (_I, [C.POINTER(_P), C.c_char_p, _U64, _U64, _U64, _I, _I, _I, C.POINTER(_U64)]),
+    "fpca_create_synthetic": (_I, [C.POINTER(_P), _U64, _U64, _U64, _U64, _I, _D, _D, _I, _I, _I]),
+    "fpca_destroy": (None, [_P]),
+    "fpca_nsamples": (_U64, [_P]),
+    "fpca_nsnps": (_U64, [_P]),
+    "fpca_download_packed": (_I, [_P, _P]),
+    "fpca_stats": (_I, [_P, _P, C.POINTER(_D)]),
+    "fpca_set_meansd": (_I, [_P, _P]),
+    "fpca_apply_xxt": (_I, [_P, _P, C.c_int64, _I, _P, C.c_int64]),
+    "fpca_apply_xt": (_I, [_P, _P, C.c_int64, _I, _P, C.c_int64]),
+    "fpca_apply_x": (_I, [_P, _P, C.c_int64, _I, _P, C.c_int64]),
+    "fpca_block_rows": (_U64, [_P]),
+    "fpca_apply_xxt_dev": (_I, [_P, _P, _I, _P, _P]),
+    "fpca_stream": (_P, [_P]),
+    "fpca_synchronize": (_I, [_P]),
+    "fpca_comm_unique_id": (_I, [_P]),
+    "fpca_comm_init_rank": (_I, [_P, _I, _I, _P]),
+    "fpca_set_allreduce": (_I, [_P, ALLREDUCE_FN, _P]),
+    "fpca_set_total_snps": (_I, [_P, _U64]),
+    "fpca_pca_default_opts": (None, [C.POINTER(PcaOpts)]),
+    "fpca_pca": (_I, [_P, C.POINTER(PcaOpts), _P, _P, _P, _P, _P, _P, C.POINTER(PcaInfo)]),
+    "fpca_check": (_I, [_P, _P, C.c_int64, _P, _I, _I, _P, C.POINTER(_D), C.POINTER(_D)]),
+    "fpca_bench_apply": (_I, [_P, _I, _I, _I, C.POINTER(BenchResult)]),
+    "fpca_bench_stats": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D)]),
+    "fpca_debug_mfma_probe": (_I, [_P, _P, _P]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libfpca.so and the flashpca CLI for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    if not verbose:
+        cmd.append("-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """Load the C-ABI library; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libfpca.so not found at %s -- build it with `make -C flashpca_amd/csrc` "
+                "(or __graft_entry__.build()); this package has no CPU fallback" % LIB_PATH
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class FpcaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("fpca error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise FpcaError(rc, lib().fpca_last_error().decode(errors="replace"))

@@ -1,0 +1,904 @@
+// device_ctx.hip -- the C ABI of include/fpca.h: device context, HBM-resident data, operator launches,
+// the HIP BlockBackend that the host eigensolver drives, RCCL plumbing and the measurement hooks.
+// MI355X / gfx950 only; there is no CPU fallback anywhere in this file.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h> // types only: the library is dlopen()ed on first use (fpca_comm_*)
+
+#include "../../include/fpca.h"
+#include "backend.hpp"
+#include "common.hpp"
+#include "kernels.hpp"
+#include "pca_driver.hpp"
+#include "synth.hpp"
+
+namespace fpca {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+
+#define HIP_CHECK(expr)                                                                                      \
+   do {                                                                                                      \
+      hipError_t e__ = (expr);                                                                               \
+      if (e__ != hipSuccess)                                                                                 \
+         throw Error(FPCA_EHIP, std::string(#expr) + " failed: " + hipGetErrorString(e__));                  \
+   } while (0)
+
+// ---- RCCL, loaded lazily ----------------------------------------------------------------------------
+struct RcclApi {
+   void *handle = nullptr;
+   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi &rccl()
+{
+   static RcclApi api;
+   if (!api.handle) {
+      const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+      for (const char *n : names) {
+         api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+         if (api.handle) break;
+      }
+      if (!api.handle) throw Error(FPCA_ECOMM, std::string("cannot load librccl: ") + dlerror());
+      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
+      api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy)
+         throw Error(FPCA_ECOMM, "librccl is missing expected symbols");
+   }
+   return api;
+}
+
+#define RCCL_CHECK(expr)                                                                                     \
+   do {                                                                                                      \
+      ncclResult_t r__ = (expr);                                                                             \
+      if (r__ != ncclSuccess)                                                                                \
+         throw Error(FPCA_ECOMM, std::string(#expr) + " failed: " +                                          \
+                                     (rccl().GetErrorString ? rccl().GetErrorString(r__) : "rccl error"));   \
+   } while (0)
+
+} // namespace fpca
+
+using namespace fpca;
+
+// ---- the context ---------------------------------------------------------------------------------------
+struct fpca_ctx {
+   int device = 0;
+   hipStream_t stream = nullptr;
+   uint64_t N = 0, P_g = 0, np = 0, N_pad = 0, P_pad = 0, P_total = 0;
+   size_t pitch = 0;
+   int stand = FPCA_STANDARDISE_BINOM2, accum = FPCA_ACCUM_FP64;
+   uint8_t *d_packed = nullptr;
+   double *d_lut = nullptr, *d_mean = nullptr, *d_sd = nullptr, *d_sumsq = nullptr;
+   bool stats_done = false;
+   double trace_local = 0;
+   // workspaces (grown on demand)
+   double *d_T = nullptr;
+   size_t T_cap = 0;
+   double *d_part = nullptr;
+   size_t part_cap = 0;
+   double *d_stage = nullptr; // column-major staging for the host-pointer API
+   size_t stage_cap = 0;
+   double *d_io_a = nullptr, *d_io_b = nullptr; // [N_pad][64] blocks for the host-pointer API
+   double *d_small = nullptr;                   // small device scratch (scalars, column scales)
+   // communication
+   ncclComm_t comm = nullptr;
+   int nranks = 1, rank = 0;
+   fpca_allreduce_fn ar_fn = nullptr;
+   void *ar_user = nullptr;
+
+   void ensure(double *&p, size_t &cap, size_t need)
+   {
+      if (need <= cap) return;
+      if (p) HIP_CHECK(hipFree(p));
+      p = nullptr;
+      cap = 0;
+      HIP_CHECK(hipMalloc(&p, need * sizeof(double)));
+      cap = need;
+   }
+   bool multi() const { return comm != nullptr || ar_fn != nullptr; }
+   void allreduce(double *dbuf, uint64_t count, hipStream_t s)
+   {
+      if (comm)
+         RCCL_CHECK(rccl().AllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, comm, s));
+      else if (ar_fn) {
+         if (ar_fn(ar_user, dbuf, count, (void *)s) != 0) throw Error(FPCA_ECOMM, "caller-supplied all-reduce failed");
+      }
+   }
+};
+
+namespace {
+
+void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int device, int accum)
+{
+   if (N == 0) throw Error(FPCA_EINVAL, "N must be > 0");
+   if (stand != FPCA_STANDARDISE_BINOM && stand != FPCA_STANDARDISE_BINOM2)
+      throw Error(FPCA_EINVAL, "unknown standardisation method: " + std::to_string(stand)); // data.cpp:283-288
+   if (accum != FPCA_ACCUM_FP64) throw Error(FPCA_EINVAL, "only FPCA_ACCUM_FP64 is implemented in this build");
+   int ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw Error(FPCA_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+   if (device < 0 || device >= ndev) throw Error(FPCA_ENODEVICE, "device index out of range");
+   hipDeviceProp_t prop;
+   if (hipGetDeviceProperties(&prop, device) != hipSuccess) throw Error(FPCA_ENODEVICE, "hipGetDeviceProperties failed");
+   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+      throw Error(FPCA_ENODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+   if (hipSetDevice(device) != hipSuccess) throw Error(FPCA_ENODEVICE, "hipSetDevice failed");
+   c->device = device;
+   c->N = N;
+   c->P_g = P_g;
+   c->P_total = P_g;
+   c->np = (N + 3) / 4;
+   c->pitch = (size_t)round_up(c->np, ROW_ALIGN);
+   c->N_pad = (uint64_t)c->pitch * 4;
+   c->P_pad = round_up(std::max<uint64_t>(P_g, 1), SNP_ALIGN);
+   c->stand = stand;
+   c->accum = accum;
+   HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+   HIP_CHECK(hipMalloc(&c->d_packed, c->pitch * c->P_pad));
+   HIP_CHECK(hipMemsetAsync(c->d_packed, PAD_BYTE, c->pitch * c->P_pad, c->stream));
+   HIP_CHECK(hipMalloc(&c->d_lut, c->P_pad * 4 * sizeof(double)));
+   HIP_CHECK(hipMalloc(&c->d_mean, c->P_pad * sizeof(double)));
+   HIP_CHECK(hipMalloc(&c->d_sd, c->P_pad * sizeof(double)));
+   HIP_CHECK(hipMalloc(&c->d_sumsq, c->P_pad * sizeof(double)));
+   HIP_CHECK(hipMemsetAsync(c->d_lut, 0, c->P_pad * 4 * sizeof(double), c->stream));
+   HIP_CHECK(hipMemsetAsync(c->d_mean, 0, c->P_pad * sizeof(double), c->stream));
+   HIP_CHECK(hipMemsetAsync(c->d_sd, 0, c->P_pad * sizeof(double), c->stream));
+   HIP_CHECK(hipMemsetAsync(c->d_sumsq, 0, c->P_pad * sizeof(double), c->stream));
+   HIP_CHECK(hipMalloc(&c->d_small, 4096 * sizeof(double)));
+}
+
+void ctx_finish_upload(fpca_ctx *c)
+{
+   kern::fix_last_byte(c->d_packed, c->pitch, c->np, (int)(c->N % 4), c->P_g, c->stream);
+   HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+void ctx_free(fpca_ctx *c)
+{
+   if (!c) return;
+   (void)hipSetDevice(c->device);
+   if (c->comm) {
+      try {
+         rccl().CommDestroy(c->comm);
+      } catch (...) {
+      }
+   }
+   void *ptrs[] = {c->d_packed, c->d_lut, c->d_mean, c->d_sd,   c->d_sumsq, c->d_T,
+                   c->d_part,   c->d_stage, c->d_io_a, c->d_io_b, c->d_small};
+   for (void *p : ptrs)
+      if (p) (void)hipFree(p);
+   if (c->stream) (void)hipStreamDestroy(c->stream);
+   delete c;
+}
+
+void ensure_stats(fpca_ctx *c)
+{
+   if (c->stats_done) return;
+   HIP_CHECK(hipSetDevice(c->device));
+   kern::bed_stats(c->d_packed, c->pitch, c->N, c->P_g, c->stand, c->d_lut, c->d_mean, c->d_sd, c->d_sumsq, c->stream);
+   std::vector<double> ss(c->P_g);
+   HIP_CHECK(hipMemcpyAsync(ss.data(), c->d_sumsq, c->P_g * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+   HIP_CHECK(hipStreamSynchronize(c->stream));
+   // pairwise-ish (blocked) summation for a reproducible, accurate trace
+   double tot = 0;
+   for (size_t i0 = 0; i0 < ss.size(); i0 += 1024) {
+      double s = 0;
+      const size_t i1 = std::min(ss.size(), i0 + 1024);
+      for (size_t i = i0; i < i1; i++) s += ss[i];
+      tot += s;
+   }
+   c->trace_local = tot;
+   c->stats_done = true;
+}
+
+// the operator on device-resident blocks: dY = X_g X_g' dB (+ all-reduce).  ev (optional): 4 events recorded
+// at [start, after K2(+reduce), after K3(+reduce), after all-reduce].
+void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t s, hipEvent_t *ev)
+{
+   ensure_stats(c);
+   const int s2 = kern::xt_b_splits(c->N_pad, c->P_pad, b);
+   const int s3 = kern::x_t_splits(c->N_pad, c->P_pad, b);
+   c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
+   size_t need = 0;
+   if (s2 > 1) need = std::max(need, (size_t)s2 * c->P_pad * b);
+   if (s3 > 1) need = std::max(need, (size_t)s3 * c->N_pad * b);
+   if (need) c->ensure(c->d_part, c->part_cap, need);
+   if (ev) HIP_CHECK(hipEventRecord(ev[0], s));
+   kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, s);
+   if (s2 > 1) kern::reduce_sum(c->d_part, c->d_T, (uint64_t)c->P_pad * b, s2, s);
+   if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
+   kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, s);
+   if (s3 > 1) kern::reduce_sum(c->d_part, dY, (uint64_t)c->N_pad * b, s3, s);
+   if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
+   if (c->multi()) c->allreduce(dY, (uint64_t)c->N_pad * b, s);
+   if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
+}
+
+void xt_dev(fpca_ctx *c, const double *dB, int b, hipStream_t s)
+{
+   ensure_stats(c);
+   const int s2 = kern::xt_b_splits(c->N_pad, c->P_pad, b);
+   c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
+   if (s2 > 1) c->ensure(c->d_part, c->part_cap, (size_t)s2 * c->P_pad * b);
+   kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, s);
+   if (s2 > 1) kern::reduce_sum(c->d_part, c->d_T, (uint64_t)c->P_pad * b, s2, s);
+}
+
+void x_dev(fpca_ctx *c, int b, double *dY, hipStream_t s)
+{
+   ensure_stats(c);
+   const int s3 = kern::x_t_splits(c->N_pad, c->P_pad, b);
+   if (s3 > 1) c->ensure(c->d_part, c->part_cap, (size_t)s3 * c->N_pad * b);
+   kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, s);
+   if (s3 > 1) kern::reduce_sum(c->d_part, dY, (uint64_t)c->N_pad * b, s3, s);
+}
+
+inline int pad16(int b) { return (int)round_up((uint64_t)b, 16); }
+
+void ensure_io(fpca_ctx *c)
+{
+   if (!c->d_io_a) HIP_CHECK(hipMalloc(&c->d_io_a, (size_t)c->N_pad * MAX_BLOCKVEC * sizeof(double)));
+   if (!c->d_io_b) HIP_CHECK(hipMalloc(&c->d_io_b, (size_t)c->N_pad * MAX_BLOCKVEC * sizeof(double)));
+}
+
+// ---- HIP backend for the eigensolver ---------------------------------------------------------------
+class HipBackend : public BlockBackend {
+ public:
+   HipBackend(fpca_ctx *c, int b) : c_(c), b_(b)
+   {
+      HIP_CHECK(hipSetDevice(c->device));
+      ensure_stats(c);
+      nsplit_gram_ = kern::gram_splits(c->N_pad);
+      HIP_CHECK(hipMalloc(&d_ptrs_, 1024 * sizeof(double *)));
+      HIP_CHECK(hipEventCreate(&e0_));
+      HIP_CHECK(hipEventCreate(&e1_));
+   }
+   ~HipBackend() override
+   {
+      for (double *p : blocks_)
+         if (p) (void)hipFree(p);
+      if (d_ptrs_) (void)hipFree(d_ptrs_);
+      if (d_C_) (void)hipFree(d_C_);
+      if (d_gpart_) (void)hipFree(d_gpart_);
+      (void)hipEventDestroy(e0_);
+      (void)hipEventDestroy(e1_);
+   }
+   uint64_t nrows() const override { return c_->N; }
+   int width() const override { return b_; }
+   int alloc_block() override
+   {
+      for (size_t i = 0; i < used_.size(); i++)
+         if (!used_[i]) {
+            used_[i] = 1;
+            return (int)i;
+         }
+      double *p = nullptr;
+      HIP_CHECK(hipMalloc(&p, (size_t)c_->N_pad * b_ * sizeof(double)));
+      blocks_.push_back(p);
+      used_.push_back(1);
+      return (int)blocks_.size() - 1;
+   }
+   void free_block(int h) override { used_[h] = 0; }
+   double *ptr(int h) { return blocks_[h]; }
+   void fill_random(int h, uint64_t seed) override { kern::fill_random(blocks_[h], c_->N, c_->N_pad, b_, seed, c_->stream); }
+   void apply(int in, int out) override
+   {
+      HIP_CHECK(hipEventRecord(e0_, c_->stream));
+      apply_xxt_dev(c_, blocks_[in], b_, blocks_[out], c_->stream, nullptr);
+      HIP_CHECK(hipEventRecord(e1_, c_->stream));
+      HIP_CHECK(hipEventSynchronize(e1_));
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, e0_, e1_));
+      sec_apply_ += ms * 1e-3;
+   }
+   void push_ptrs(const int *a, int nq)
+   {
+      if (nq > 1024) throw Error(FPCA_EINVAL, "too many basis blocks");
+      std::vector<const double *> hp(nq);
+      for (int q = 0; q < nq; q++) hp[q] = blocks_[a[q]];
+      HIP_CHECK(hipMemcpyAsync(d_ptrs_, hp.data(), nq * sizeof(double *), hipMemcpyHostToDevice, c_->stream));
+   }
+   void gram(const int *a, int nq, int w, double *C) override
+   {
+      auto t0 = std::chrono::steady_clock::now();
+      const size_t cnt = (size_t)nq * b_ * b_;
+      const int ns = nsplit_gram_ * 4;
+      grow(d_gpart_, gpart_cap_, cnt * ns);
+      grow(d_C_, C_cap_, std::max(cnt, (size_t)1024 * b_ * 4));
+      push_ptrs(a, nq);
+      kern::gram(d_ptrs_, nq, blocks_[w], d_gpart_, c_->N_pad, b_, nsplit_gram_, c_->stream);
+      kern::reduce_sum(d_gpart_, d_C_, cnt, ns, c_->stream);
+      HIP_CHECK(hipMemcpyAsync(C, d_C_, cnt * sizeof(double), hipMemcpyDeviceToHost, c_->stream));
+      HIP_CHECK(hipStreamSynchronize(c_->stream));
+      sec_other_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+   }
+   void gemm(const int *a, int nq, const double *C, int init, int out) override
+   {
+      auto t0 = std::chrono::steady_clock::now();
+      const size_t cnt = (size_t)nq * b_ * b_;
+      grow(d_C_, C_cap_, std::max(cnt, (size_t)1024 * b_ * 4));
+      push_ptrs(a, nq);
+      HIP_CHECK(hipMemcpyAsync(d_C_, C, cnt * sizeof(double), hipMemcpyHostToDevice, c_->stream));
+      kern::block_gemm(d_ptrs_, nq, d_C_, init >= 0 ? blocks_[init] : nullptr, blocks_[out], c_->N_pad, b_, c_->stream);
+      // d_C_/d_ptrs_ are reused by the next call: keep it simple and drain here (the kernel is HBM-bound, short)
+      HIP_CHECK(hipStreamSynchronize(c_->stream));
+      sec_other_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+   }
+   void download(int h, int ncols, double *host, int64_t ld) override
+   {
+      c_->ensure(c_->d_stage, c_->stage_cap, (size_t)c_->N * ncols);
+      kern::block_to_colmajor(blocks_[h], c_->N, b_, ncols, c_->d_stage, c_->N, c_->stream);
+      HIP_CHECK(hipMemcpy2DAsync(host, (size_t)ld * sizeof(double), c_->d_stage, c_->N * sizeof(double),
+                                 c_->N * sizeof(double), ncols, hipMemcpyDeviceToHost, c_->stream));
+      HIP_CHECK(hipStreamSynchronize(c_->stream));
+   }
+   void upload(int h, int ncols, const double *host, int64_t ld) override
+   {
+      c_->ensure(c_->d_stage, c_->stage_cap, (size_t)c_->N * ncols);
+      HIP_CHECK(hipMemcpy2DAsync(c_->d_stage, c_->N * sizeof(double), host, (size_t)ld * sizeof(double),
+                                 c_->N * sizeof(double), ncols, hipMemcpyHostToDevice, c_->stream));
+      kern::colmajor_to_block(c_->d_stage, c_->N, c_->N, c_->N_pad, b_, ncols, blocks_[h], c_->stream);
+      HIP_CHECK(hipStreamSynchronize(c_->stream));
+   }
+   double trace() override
+   {
+      double t = c_->trace_local;
+      if (c_->multi()) {
+         HIP_CHECK(hipMemcpyAsync(c_->d_small, &t, sizeof(double), hipMemcpyHostToDevice, c_->stream));
+         c_->allreduce(c_->d_small, 1, c_->stream);
+         HIP_CHECK(hipMemcpyAsync(&t, c_->d_small, sizeof(double), hipMemcpyDeviceToHost, c_->stream));
+         HIP_CHECK(hipStreamSynchronize(c_->stream));
+      }
+      return t;
+   }
+   double seconds_apply() override { return sec_apply_; }
+   double seconds_other() override { return sec_other_; }
+
+ private:
+   void grow(double *&p, size_t &cap, size_t need)
+   {
+      if (need <= cap) return;
+      if (p) HIP_CHECK(hipFree(p));
+      p = nullptr;
+      HIP_CHECK(hipMalloc(&p, need * sizeof(double)));
+      cap = need;
+   }
+   fpca_ctx *c_;
+   int b_;
+   int nsplit_gram_ = 1;
+   std::vector<double *> blocks_;
+   std::vector<unsigned char> used_;
+   const double **d_ptrs_ = nullptr;
+   double *d_C_ = nullptr, *d_gpart_ = nullptr;
+   size_t C_cap_ = 0, gpart_cap_ = 0;
+   hipEvent_t e0_, e1_;
+   double sec_apply_ = 0, sec_other_ = 0;
+};
+
+template <typename F> int guarded(F &&f)
+{
+   try {
+      f();
+      return FPCA_OK;
+   } catch (const Error &e) {
+      set_last_error(e.what());
+      return e.code;
+   } catch (const std::bad_alloc &) {
+      set_last_error("host allocation failed");
+      return FPCA_ENOMEM;
+   } catch (const std::exception &e) {
+      set_last_error(e.what());
+      return FPCA_EHIP;
+   }
+}
+
+} // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char *fpca_last_error(void) { return fpca::g_last_error.c_str(); }
+const char *fpca_version(void) { return FPCA_VERSION; }
+
+int fpca_device_count(void)
+{
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+   return n;
+}
+
+int fpca_device_name(int device, char *buf, int buflen)
+{
+   return guarded([&] {
+      hipDeviceProp_t prop;
+      HIP_CHECK(hipGetDeviceProperties(&prop, device));
+      std::snprintf(buf, buflen, "%s (%s, %d CUs, %.1f GiB)", prop.name, prop.gcnArchName, prop.multiProcessorCount,
+                    (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+   });
+}
+
+int fpca_create(fpca_ctx **out, const uint8_t *packed, uint64_t N, uint64_t P_g, int stand_method, int device, int accum)
+{
+   if (!out) return FPCA_EINVAL;
+   *out = nullptr;
+   fpca_ctx *c = new fpca_ctx();
+   int rc = guarded([&] {
+      if (!packed && P_g > 0) throw Error(FPCA_EINVAL, "packed is NULL");
+      ctx_alloc_common(c, N, P_g, stand_method, device, accum);
+      if (P_g > 0)
+         HIP_CHECK(hipMemcpy2DAsync(c->d_packed, c->pitch, packed, c->np, c->np, P_g, hipMemcpyHostToDevice, c->stream));
+      ctx_finish_upload(c);
+   });
+   if (rc != FPCA_OK) {
+      ctx_free(c);
+      return rc;
+   }
+   *out = c;
+   return FPCA_OK;
+}
+
+int fpca_create_from_bed(fpca_ctx **out, const char *bed_path, uint64_t N, uint64_t snp_begin, uint64_t P_g,
+                         int stand_method, int device, int accum, uint64_t *P_total)
+{
+   if (!out) return FPCA_EINVAL;
+   *out = nullptr;
+   fpca_ctx *c = new fpca_ctx();
+   int fd = -1;
+   int rc = guarded([&] {
+      if (N == 0) throw Error(FPCA_EINVAL, "N must be > 0");
+      fd = open(bed_path, O_RDONLY);
+      if (fd < 0) // data.cpp:156-161
+         throw Error(FPCA_EIO, std::string("[Data::read_bed] Error reading file ") + bed_path + ", error " + strerror(errno));
+      struct stat st;
+      if (fstat(fd, &st) != 0 || st.st_size < 3) throw Error(FPCA_EIO, std::string("cannot stat ") + bed_path);
+      const uint64_t len = (uint64_t)st.st_size - 3; // data.cpp:165
+      const uint64_t np = (N + 3) / 4;               // data.cpp:168
+      const uint64_t nsnps = len / np;               // data.cpp:170 (integer division; .bim is not consulted)
+      if (P_total) *P_total = nsnps;
+      if (snp_begin > nsnps) throw Error(FPCA_EINVAL, "snp_begin beyond the end of the file");
+      uint64_t pg = P_g ? P_g : nsnps - snp_begin;
+      if (snp_begin + pg > nsnps) throw Error(FPCA_EINVAL, "SNP range beyond the end of the file");
+      ctx_alloc_common(c, N, pg, stand_method, device, accum);
+      c->P_total = nsnps;
+      // stream the shard through a pinned bounce buffer: contiguous byte range [3 + np*begin, 3 + np*(begin+pg))
+      const uint64_t rows_per_chunk = std::max<uint64_t>(1, (64ull << 20) / np);
+      uint8_t *bounce[2] = {nullptr, nullptr};
+      hipEvent_t done[2];
+      for (int i = 0; i < 2; i++) {
+         HIP_CHECK(hipHostMalloc(&bounce[i], rows_per_chunk * np, hipHostMallocDefault));
+         HIP_CHECK(hipEventCreate(&done[i]));
+      }
+      try {
+         int slot = 0;
+         for (uint64_t r0 = 0; r0 < pg; r0 += rows_per_chunk, slot ^= 1) {
+            const uint64_t nr = std::min(rows_per_chunk, pg - r0);
+            HIP_CHECK(hipEventSynchronize(done[slot])); // the previous copy out of this slot has finished
+            uint64_t want = nr * np, got = 0;
+            const off_t off = (off_t)(3 + np * (snp_begin + r0)); // data.cpp:218
+            while (got < want) {
+               ssize_t k = pread(fd, bounce[slot] + got, want - got, off + (off_t)got);
+               if (k <= 0) throw Error(FPCA_EIO, std::string("short read from ") + bed_path);
+               got += (uint64_t)k;
+            }
+            HIP_CHECK(hipMemcpy2DAsync(c->d_packed + r0 * c->pitch, c->pitch, bounce[slot], np, np, nr,
+                                       hipMemcpyHostToDevice, c->stream));
+            HIP_CHECK(hipEventRecord(done[slot], c->stream));
+         }
+         HIP_CHECK(hipStreamSynchronize(c->stream));
+      } catch (...) {
+         for (int i = 0; i < 2; i++) {
+            (void)hipHostFree(bounce[i]);
+            (void)hipEventDestroy(done[i]);
+         }
+         throw;
+      }
+      for (int i = 0; i < 2; i++) {
+         (void)hipHostFree(bounce[i]);
+         (void)hipEventDestroy(done[i]);
+      }
+      ctx_finish_upload(c);
+   });
+   if (fd >= 0) close(fd);
+   if (rc != FPCA_OK) {
+      ctx_free(c);
+      return rc;
+   }
+   *out = c;
+   return FPCA_OK;
+}
+
+int fpca_create_synthetic(fpca_ctx **out, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed, int n_pop,
+                          double fst, double missing_rate, int stand_method, int device, int accum)
+{
+   if (!out) return FPCA_EINVAL;
+   *out = nullptr;
+   fpca_ctx *c = new fpca_ctx();
+   int rc = guarded([&] {
+      if (n_pop < 1 || n_pop > synth::MAX_POP) throw Error(FPCA_EINVAL, "n_pop must be in 1..64");
+      if (!(fst >= 0 && fst < 1) || !(missing_rate >= 0 && missing_rate < 1)) throw Error(FPCA_EINVAL, "fst / missing_rate out of range");
+      ctx_alloc_common(c, N, P_g, stand_method, device, accum);
+      const uint32_t fst_fp = (uint32_t)std::llround(fst * 65536.0);
+      const uint32_t miss_thr = (uint32_t)std::llround(missing_rate * 65536.0);
+      kern::synth_generate(c->d_packed, c->pitch, N, snp_begin, P_g, seed, n_pop, fst_fp, miss_thr, c->stream);
+      HIP_CHECK(hipStreamSynchronize(c->stream));
+   });
+   if (rc != FPCA_OK) {
+      ctx_free(c);
+      return rc;
+   }
+   *out = c;
+   return FPCA_OK;
+}
+
+void fpca_destroy(fpca_ctx *ctx) { ctx_free(ctx); }
+
+uint64_t fpca_nsamples(const fpca_ctx *ctx) { return ctx ? ctx->N : 0; }
+uint64_t fpca_nsnps(const fpca_ctx *ctx) { return ctx ? ctx->P_g : 0; }
+uint64_t fpca_block_rows(const fpca_ctx *ctx) { return ctx ? ctx->N_pad : 0; }
+void *fpca_stream(fpca_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int fpca_synchronize(fpca_ctx *ctx)
+{
+   return guarded([&] {
+      HIP_CHECK(hipSetDevice(ctx->device));
+      HIP_CHECK(hipDeviceSynchronize());
+   });
+}
+
+int fpca_download_packed(fpca_ctx *ctx, uint8_t *out)
+{
+   return guarded([&] {
+      HIP_CHECK(hipSetDevice(ctx->device));
+      if (ctx->P_g == 0) return;
+      HIP_CHECK(hipMemcpy2D(out, ctx->np, ctx->d_packed, ctx->pitch, ctx->np, ctx->P_g, hipMemcpyDeviceToHost));
+      // the pad bits of the last byte were rewritten to "missing" on upload; PLINK writes them as 0
+      if (ctx->N % 4) {
+         const uint8_t keep = (uint8_t)((1u << (2 * (ctx->N % 4))) - 1u);
+         for (uint64_t j = 0; j < ctx->P_g; j++) out[j * ctx->np + ctx->np - 1] &= keep;
+      }
+   });
+}
+
+int fpca_stats(fpca_ctx *ctx, double *mean_sd, double *trace_out)
+{
+   return guarded([&] {
+      HIP_CHECK(hipSetDevice(ctx->device));
+      ensure_stats(ctx);
+      if (mean_sd && ctx->P_g) {
+         HIP_CHECK(hipMemcpy(mean_sd, ctx->d_mean, ctx->P_g * sizeof(double), hipMemcpyDeviceToHost));
+         HIP_CHECK(hipMemcpy(mean_sd + ctx->P_g, ctx->d_sd, ctx->P_g * sizeof(double), hipMemcpyDeviceToHost));
+      }
+      if (trace_out) *trace_out = ctx->trace_local;
+   });
+}
+
+int fpca_set_meansd(fpca_ctx *ctx, const double *mean_sd)
+{
+   return guarded([&] {
+      HIP_CHECK(hipSetDevice(ctx->device));
+      if (!mean_sd) throw Error(FPCA_EINVAL, "mean_sd is NULL");
+      HIP_CHECK(hipMemcpy(ctx->d_mean, mean_sd, ctx->P_g * sizeof(double), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(ctx->d_sd, mean_sd + ctx->P_g, ctx->P_g * sizeof(double), hipMemcpyHostToDevice));
+      kern::lut_from_meansd(ctx->d_mean, ctx->d_sd, ctx->P_g, ctx->d_lut, ctx->stream);
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      ctx->stats_done = true; // trace of the preloaded standardisation is not defined by the reference path
+      ctx->trace_local = 0;
+   });
+}
+
+// ---- operator, host pointers -------------------------------------------------------------------------
+int fpca_apply_xxt(fpca_ctx *ctx, const double *B, int64_t ldb, int b, double *Y, int64_t ldy)
+{
+   return guarded([&] {
+      if (!ctx || !B || !Y || b < 1 || ldb < (int64_t)ctx->N || ldy < (int64_t)ctx->N) throw Error(FPCA_EINVAL, "bad argument to fpca_apply_xxt");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      ensure_io(ctx);
+      for (int c0 = 0; c0 < b; c0 += MAX_BLOCKVEC) {
+         const int nc = std::min(MAX_BLOCKVEC, b - c0), bw = pad16(nc);
+         ctx->ensure(ctx->d_stage, ctx->stage_cap, (size_t)ctx->N * nc);
+         HIP_CHECK(hipMemcpy2DAsync(ctx->d_stage, ctx->N * sizeof(double), B + (size_t)c0 * ldb, (size_t)ldb * sizeof(double),
+                                    ctx->N * sizeof(double), nc, hipMemcpyHostToDevice, ctx->stream));
+         kern::colmajor_to_block(ctx->d_stage, ctx->N, ctx->N, ctx->N_pad, bw, nc, ctx->d_io_a, ctx->stream);
+         apply_xxt_dev(ctx, ctx->d_io_a, bw, ctx->d_io_b, ctx->stream, nullptr);
+         kern::block_to_colmajor(ctx->d_io_b, ctx->N, bw, nc, ctx->d_stage, ctx->N, ctx->stream);
+         HIP_CHECK(hipMemcpy2DAsync(Y + (size_t)c0 * ldy, (size_t)ldy * sizeof(double), ctx->d_stage, ctx->N * sizeof(double),
+                                    ctx->N * sizeof(double), nc, hipMemcpyDeviceToHost, ctx->stream));
+         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      }
+   });
+}
+
+int fpca_apply_xt(fpca_ctx *ctx, const double *B, int64_t ldb, int b, double *T, int64_t ldt)
+{
+   return guarded([&] {
+      if (!ctx || !B || !T || b < 1 || ldb < (int64_t)ctx->N || ldt < (int64_t)ctx->P_g) throw Error(FPCA_EINVAL, "bad argument to fpca_apply_xt");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      ensure_io(ctx);
+      for (int c0 = 0; c0 < b; c0 += MAX_BLOCKVEC) {
+         const int nc = std::min(MAX_BLOCKVEC, b - c0), bw = pad16(nc);
+         ctx->ensure(ctx->d_stage, ctx->stage_cap, (size_t)std::max(ctx->N, ctx->P_g) * nc);
+         HIP_CHECK(hipMemcpy2DAsync(ctx->d_stage, ctx->N * sizeof(double), B + (size_t)c0 * ldb, (size_t)ldb * sizeof(double),
+                                    ctx->N * sizeof(double), nc, hipMemcpyHostToDevice, ctx->stream));
+         kern::colmajor_to_block(ctx->d_stage, ctx->N, ctx->N, ctx->N_pad, bw, nc, ctx->d_io_a, ctx->stream);
+         xt_dev(ctx, ctx->d_io_a, bw, ctx->stream);
+         kern::t_to_colmajor(ctx->d_T, ctx->P_g, bw, nc, nullptr, ctx->d_stage, ctx->P_g, ctx->stream);
+         HIP_CHECK(hipMemcpy2DAsync(T + (size_t)c0 * ldt, (size_t)ldt * sizeof(double), ctx->d_stage, ctx->P_g * sizeof(double),
+                                    ctx->P_g * sizeof(double), nc, hipMemcpyDeviceToHost, ctx->stream));
+         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      }
+   });
+}
+
+int fpca_apply_x(fpca_ctx *ctx, const double *T, int64_t ldt, int b, double *Y, int64_t ldy)
+{
+   return guarded([&] {
+      if (!ctx || !T || !Y || b < 1 || ldt < (int64_t)ctx->P_g || ldy < (int64_t)ctx->N) throw Error(FPCA_EINVAL, "bad argument to fpca_apply_x");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      ensure_io(ctx);
+      for (int c0 = 0; c0 < b; c0 += MAX_BLOCKVEC) {
+         const int nc = std::min(MAX_BLOCKVEC, b - c0), bw = pad16(nc);
+         ctx->ensure(ctx->d_stage, ctx->stage_cap, (size_t)std::max(ctx->N, ctx->P_g) * nc);
+         ctx->ensure(ctx->d_T, ctx->T_cap, (size_t)ctx->P_pad * MAX_BLOCKVEC);
+         HIP_CHECK(hipMemcpy2DAsync(ctx->d_stage, ctx->P_g * sizeof(double), T + (size_t)c0 * ldt, (size_t)ldt * sizeof(double),
+                                    ctx->P_g * sizeof(double), nc, hipMemcpyHostToDevice, ctx->stream));
+         kern::colmajor_to_t(ctx->d_stage, ctx->P_g, ctx->P_g, ctx->P_pad, bw, nc, ctx->d_T, ctx->stream);
+         x_dev(ctx, bw, ctx->d_io_b, ctx->stream);
+         kern::block_to_colmajor(ctx->d_io_b, ctx->N, bw, nc, ctx->d_stage, ctx->N, ctx->stream);
+         HIP_CHECK(hipMemcpy2DAsync(Y + (size_t)c0 * ldy, (size_t)ldy * sizeof(double), ctx->d_stage, ctx->N * sizeof(double),
+                                    ctx->N * sizeof(double), nc, hipMemcpyDeviceToHost, ctx->stream));
+         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      }
+   });
+}
+
+int fpca_apply_xxt_dev(fpca_ctx *ctx, const double *dB, int b, double *dY, void *stream)
+{
+   return guarded([&] {
+      if (!ctx || !dB || !dY) throw Error(FPCA_EINVAL, "bad argument to fpca_apply_xxt_dev");
+      if (b != 16 && b != 32 && b != 48 && b != 64) throw Error(FPCA_EINVAL, "device blocks must be 16, 32, 48 or 64 wide");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      apply_xxt_dev(ctx, dB, b, dY, stream ? (hipStream_t)stream : ctx->stream, nullptr);
+   });
+}
+
+// ---- multi-GPU ---------------------------------------------------------------------------------------
+int fpca_comm_unique_id(uint8_t id[FPCA_UNIQUE_ID_BYTES])
+{
+   return guarded([&] {
+      static_assert(sizeof(ncclUniqueId) == FPCA_UNIQUE_ID_BYTES, "ncclUniqueId size");
+      ncclUniqueId u;
+      RCCL_CHECK(rccl().GetUniqueId(&u));
+      std::memcpy(id, &u, sizeof(u));
+   });
+}
+
+int fpca_comm_init_rank(fpca_ctx *ctx, int nranks, int rank, const uint8_t id[FPCA_UNIQUE_ID_BYTES])
+{
+   return guarded([&] {
+      if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) throw Error(FPCA_EINVAL, "bad argument to fpca_comm_init_rank");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      ncclUniqueId u;
+      std::memcpy(&u, id, sizeof(u));
+      RCCL_CHECK(rccl().CommInitRank(&ctx->comm, nranks, u, rank));
+      ctx->nranks = nranks;
+      ctx->rank = rank;
+      // self-test: sum of (rank+1) over ranks must be n(n+1)/2 on every rank
+      double v = rank + 1.0;
+      HIP_CHECK(hipMemcpyAsync(ctx->d_small, &v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      ctx->allreduce(ctx->d_small, 1, ctx->stream);
+      HIP_CHECK(hipMemcpyAsync(&v, ctx->d_small, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (v != nranks * (nranks + 1) / 2.0) throw Error(FPCA_ECOMM, "RCCL all-reduce self-test returned a wrong sum");
+   });
+}
+
+int fpca_set_allreduce(fpca_ctx *ctx, fpca_allreduce_fn fn, void *user)
+{
+   if (!ctx) return FPCA_EINVAL;
+   ctx->ar_fn = fn;
+   ctx->ar_user = user;
+   return FPCA_OK;
+}
+
+int fpca_set_total_snps(fpca_ctx *ctx, uint64_t P_total)
+{
+   if (!ctx || P_total < ctx->P_g) return FPCA_EINVAL;
+   ctx->P_total = P_total;
+   return FPCA_OK;
+}
+
+// ---- driver -------------------------------------------------------------------------------------------
+void fpca_pca_default_opts(fpca_pca_opts *o)
+{
+   std::memset(o, 0, sizeof(*o));
+   o->ndim = 10;      // flashpca.cpp:325
+   o->blockvec = 0;
+   o->maxiter = 500;  // flashpca.cpp:426
+   o->tol = 1e-6;     // flashpca.cpp:440
+   o->divisor = FPCA_DIVISOR_P; // flashpca.cpp:484
+   o->do_loadings = 0;
+   o->max_blocks = 0;
+   o->verbose = 0;
+   o->seed = 1;       // flashpca.cpp:276
+}
+
+int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, double *Px, double *pve, double *V,
+             double *mean_sd, fpca_pca_info *info)
+{
+   int solver_rc = FPCA_OK;
+   int rc = guarded([&] {
+      if (!ctx || !opts) throw Error(FPCA_EINVAL, "bad argument to fpca_pca");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      const int k = opts->ndim;
+      // Spectra's requirement nev < ncv = 2 nev + 1 <= n, enforced by the reference CLI (flashpca.cpp:623-633)
+      const uint64_t lim = std::min(ctx->N, ctx->P_total);
+      const uint64_t max_dim = lim >= 1 ? (lim - 1) / 2 : 0;
+      if (k < 1 || (uint64_t)k > max_dim)
+         throw Error(FPCA_EINVAL, "You asked for " + std::to_string(k) + " dimensions, but only " + std::to_string(max_dim) + " allowed");
+      const int b = choose_blockvec(k, opts->blockvec);
+      HipBackend be(ctx, b);
+      PcaOutputs out;
+      out.U = U;
+      out.d = d;
+      out.Px = Px;
+      out.pve = pve;
+      int ritz = -1;
+      double div = 1;
+      std::vector<double> dloc(k);
+      if (!out.d) out.d = dloc.data();
+      solver_rc = run_pca(be, *opts, ctx->P_total, out, info, &ritz, &div);
+      if (opts->do_loadings && V) {
+         // randompca.cpp:191-204: V[:, j] = X' u_j / sqrt(d_j) / sqrt(div); one K2 pass for all k columns
+         xt_dev(ctx, be.ptr(ritz), b, ctx->stream);
+         std::vector<double> sc(b, 0.0);
+         for (int j = 0; j < k; j++) sc[j] = (1.0 / std::sqrt(out.d[j])) / std::sqrt(div);
+         HIP_CHECK(hipMemcpyAsync(ctx->d_small, sc.data(), b * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+         ctx->ensure(ctx->d_stage, ctx->stage_cap, (size_t)std::max(ctx->N, ctx->P_g) * k);
+         kern::t_to_colmajor(ctx->d_T, ctx->P_g, b, k, ctx->d_small, ctx->d_stage, ctx->P_g, ctx->stream);
+         HIP_CHECK(hipMemcpyAsync(V, ctx->d_stage, (size_t)ctx->P_g * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      }
+      be.free_block(ritz);
+      if (mean_sd && ctx->P_g) {
+         HIP_CHECK(hipMemcpy(mean_sd, ctx->d_mean, ctx->P_g * sizeof(double), hipMemcpyDeviceToHost));
+         HIP_CHECK(hipMemcpy(mean_sd + ctx->P_g, ctx->d_sd, ctx->P_g * sizeof(double), hipMemcpyDeviceToHost));
+      }
+   });
+   if (rc != FPCA_OK) return rc;
+   if (solver_rc == FPCA_ENOTCONVERGED) set_last_error("eigen-decomposition was not successful (not converged within maxiter)");
+   return solver_rc;
+}
+
+int fpca_check(fpca_ctx *ctx, const double *evec, int64_t ldu, const double *eval, int k, int divisor, double *err,
+               double *mse, double *rmse)
+{
+   return guarded([&] {
+      if (!ctx || !evec || !eval || k < 1 || ldu < (int64_t)ctx->N) throw Error(FPCA_EINVAL, "bad argument to fpca_check");
+      const uint64_t N = ctx->N;
+      double div = 1; // randompca.cpp:676-680
+      if (divisor == FPCA_DIVISOR_N1)
+         div = (double)N - 1;
+      else if (divisor == FPCA_DIVISOR_P)
+         div = (double)ctx->P_total;
+      std::vector<double> Y((size_t)N * k);
+      int rc = fpca_apply_xxt(ctx, evec, ldu, k, Y.data(), (int64_t)N);
+      if (rc != FPCA_OK) throw Error(rc, fpca_last_error());
+      double tot = 0;
+      for (int j = 0; j < k; j++) {
+         double s = 0;
+         for (uint64_t i = 0; i < N; i++) {
+            const double e = Y[i + (size_t)j * N] / div - evec[i + (size_t)j * ldu] * eval[j];
+            s += e * e;
+         }
+         if (err) err[j] = s;
+         tot += s;
+      }
+      const double m = tot / ((double)N * k); // randompca.cpp:694
+      if (mse) *mse = m;
+      if (rmse) *rmse = std::sqrt(m);
+   });
+}
+
+// ---- measurement ---------------------------------------------------------------------------------------
+int fpca_bench_apply(fpca_ctx *ctx, int b, int steps, int warmup, fpca_bench_result *res)
+{
+   return guarded([&] {
+      if (!ctx || !res || steps < 1 || warmup < 0) throw Error(FPCA_EINVAL, "bad argument to fpca_bench_apply");
+      if (b != 16 && b != 32 && b != 48 && b != 64) throw Error(FPCA_EINVAL, "b must be 16, 32, 48 or 64");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      ensure_stats(ctx);
+      double *dB = nullptr, *dY = nullptr;
+      HIP_CHECK(hipMalloc(&dB, (size_t)ctx->N_pad * b * sizeof(double)));
+      HIP_CHECK(hipMalloc(&dY, (size_t)ctx->N_pad * b * sizeof(double)));
+      kern::fill_random(dB, ctx->N, ctx->N_pad, b, 12345, ctx->stream);
+      std::vector<hipEvent_t> ev((size_t)steps * 4);
+      for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));
+      for (int i = 0; i < warmup; i++) apply_xxt_dev(ctx, dB, b, dY, ctx->stream, nullptr);
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      for (int i = 0; i < steps; i++) apply_xxt_dev(ctx, dB, b, dY, ctx->stream, &ev[(size_t)i * 4]);
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      double t2 = 0, t3 = 0, ta = 0;
+      float ms = 0;
+      for (int i = 0; i < steps; i++) {
+         HIP_CHECK(hipEventElapsedTime(&ms, ev[i * 4 + 0], ev[i * 4 + 1]));
+         t2 += ms;
+         HIP_CHECK(hipEventElapsedTime(&ms, ev[i * 4 + 1], ev[i * 4 + 2]));
+         t3 += ms;
+         HIP_CHECK(hipEventElapsedTime(&ms, ev[i * 4 + 2], ev[i * 4 + 3]));
+         ta += ms;
+      }
+      HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[(size_t)steps * 4 - 1]));
+      res->ms_total = ms;
+      res->ms_xt = t2 / steps;
+      res->ms_x = t3 / steps;
+      res->ms_allreduce = ta / steps;
+      res->flops_per_step = 4.0 * (double)ctx->N * (double)ctx->P_g * b;
+      res->packed_bytes_per_step = 2.0 * (double)ctx->np * (double)ctx->P_g;
+      for (auto &e : ev) (void)hipEventDestroy(e);
+      (void)hipFree(dB);
+      (void)hipFree(dY);
+   });
+}
+
+int fpca_bench_stats(fpca_ctx *ctx, int reps, double *ms_per_launch, double *bytes_per_launch)
+{
+   return guarded([&] {
+      if (!ctx || reps < 1) throw Error(FPCA_EINVAL, "bad argument to fpca_bench_stats");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      hipEvent_t e0, e1;
+      HIP_CHECK(hipEventCreate(&e0));
+      HIP_CHECK(hipEventCreate(&e1));
+      kern::bed_stats(ctx->d_packed, ctx->pitch, ctx->N, ctx->P_g, ctx->stand, ctx->d_lut, ctx->d_mean, ctx->d_sd, ctx->d_sumsq, ctx->stream);
+      HIP_CHECK(hipEventRecord(e0, ctx->stream));
+      for (int i = 0; i < reps; i++)
+         kern::bed_stats(ctx->d_packed, ctx->pitch, ctx->N, ctx->P_g, ctx->stand, ctx->d_lut, ctx->d_mean, ctx->d_sd, ctx->d_sumsq, ctx->stream);
+      HIP_CHECK(hipEventRecord(e1, ctx->stream));
+      HIP_CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      if (ms_per_launch) *ms_per_launch = ms / reps;
+      if (bytes_per_launch) *bytes_per_launch = (double)ctx->np * (double)ctx->P_g;
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+   });
+}
+
+// diagnostic used by tests/test_gpu_kernels.py: D = A(16x4) B(4x16) through the MFMA operand mapping of kernels.hip
+int fpca_debug_mfma_probe(const double *A, const double *B, double *D)
+{
+   return guarded([&] {
+      double *dA, *dB, *dD;
+      HIP_CHECK(hipMalloc(&dA, 64 * sizeof(double)));
+      HIP_CHECK(hipMalloc(&dB, 64 * sizeof(double)));
+      HIP_CHECK(hipMalloc(&dD, 256 * sizeof(double)));
+      HIP_CHECK(hipMemcpy(dA, A, 64 * sizeof(double), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(dB, B, 64 * sizeof(double), hipMemcpyHostToDevice));
+      kern::mfma_layout_probe(dA, dB, dD, nullptr);
+      HIP_CHECK(hipDeviceSynchronize());
+      HIP_CHECK(hipMemcpy(D, dD, 256 * sizeof(double), hipMemcpyDeviceToHost));
+      (void)hipFree(dA);
+      (void)hipFree(dB);
+      (void)hipFree(dD);
+   });
+}
+
+} // extern "C"

@@ -196,6 +196,10 @@ int fpca_bench_apply(fpca_ctx *ctx, int b, int steps, int warmup, fpca_bench_res
 /* time the one-off statistics pass (K1) the same way: milliseconds per launch, bytes read */
 int fpca_bench_stats(fpca_ctx *ctx, int reps, double *ms_per_launch, double *bytes_per_launch);
 
+/* diagnostic: D(16x16, row-major) = A(16x4) B(4x16) through v_mfma_f64_16x16x4_f64 with the lane->operand mapping the
+ * kernels assume; host pointers.  Used by tests/test_gpu_kernels.py as a guard on the hardware layout. */
+int fpca_debug_mfma_probe(const double *A, const double *B, double *D);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,176 @@
+"""GPU parity tests of the individual kernels, through the C ABI, against the CPU oracle (oracle/) and the
+committed goldens (tests/golden/).  Tolerances: integer / table work bit-exact; fp64 GEMM outputs 1e-12
+relative to the column norm (fp64 accumulation order differs between an MFMA tree and the oracle's loops).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def fp(built_lib):
+    import flashpca_amd
+
+    return flashpca_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle as O
+
+    O.build()
+    return O
+
+
+def _load(golden_dir, name, stand, fp, orc):
+    N = fp.count_fam_rows(os.path.join(golden_dir, name + ".fam"))
+    bed = os.path.join(golden_dir, name + ".bed")
+    ctx = fp.Context.from_bed(bed, N, stand=stand)
+    od = orc.OracleData(bed, N, stand)
+    g = json.load(open(os.path.join(golden_dir, "golden_%s_%s.json" % (name, stand))))
+    return ctx, od, g
+
+
+def test_device_is_gfx950(fp):
+    import ctypes as C
+
+    L = fp.lib()
+    assert L.fpca_device_count() >= 1
+    buf = C.create_string_buffer(256)
+    assert L.fpca_device_name(0, buf, 256) == 0
+    assert b"gfx950" in buf.value
+
+
+def test_mfma_operand_mapping(fp):
+    """A=asymmetric, B=asymmetric: catches a transposed or permuted C/D mapping (guide section 3)."""
+    import ctypes as C
+
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((16, 4))
+    B = rng.standard_normal((4, 16))
+    D = np.zeros((16, 16))
+    rc = fp.lib().fpca_debug_mfma_probe(A.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p), D.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    assert np.allclose(D, A @ B, rtol=0, atol=1e-14)
+
+
+@pytest.mark.parametrize("name", ["data_chr1", "hapmap3_data"])
+@pytest.mark.parametrize("stand", ["binom2", "binom"])
+def test_stats_bit_exact(golden_dir, name, stand, fp, orc):
+    """K1: mean and sd must equal the oracle bit for bit (integer counts, one division, one sqrt)."""
+    ctx, od, g = _load(golden_dir, name, stand, fp, orc)
+    ms, trace = ctx.stats()
+    od.dense()  # visits every SNP -> fills the oracle's mean/sd
+    oms = od.meansd()
+    assert ctx.N == g["N"] and ctx.P == g["P"]
+    assert np.array_equal(ms[:, 0], oms[:, 0])
+    assert np.array_equal(ms[:, 1], oms[:, 1])
+    assert np.allclose(ms[:8, 0], g["mean_first8"], rtol=0, atol=0)
+    assert abs(trace - g["trace_raw"]) <= 1e-12 * g["trace_raw"]
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,b", [("data_chr1", 1), ("data_chr1", 5), ("data_chr1", 16), ("data_chr1", 37),
+                                    ("hapmap3_data", 32), ("hapmap3_data", 64), ("hapmap3_data", 70)])
+def test_operator_parity(golden_dir, name, b, fp, orc):
+    """K2, K3 and their composition vs the oracle's dense block products, every block width class."""
+    ctx, od, g = _load(golden_dir, name, "binom2", fp, orc)
+    rng = np.random.default_rng(b)
+    X = od.dense()  # N x P standardised, from the oracle (data.cpp:215-335 restated)
+    B = rng.standard_normal((ctx.N, b))
+    T_ref = X.T @ B
+    T = ctx.apply_xt(B)
+    assert np.max(np.abs(T - T_ref)) <= REL * np.max(np.abs(T_ref)) * 10
+    Tin = rng.standard_normal((ctx.P, b))
+    Y_ref = X @ Tin
+    Y = ctx.apply_x(Tin)
+    assert np.max(np.abs(Y - Y_ref)) <= REL * np.max(np.abs(Y_ref)) * 10
+    Z_ref = X @ T_ref
+    Z = ctx.apply_xxt(B)
+    assert np.max(np.abs(Z - Z_ref)) <= REL * np.max(np.abs(Z_ref)) * 10
+    ctx.close()
+
+
+def test_operator_probe_golden(golden_dir, fp, orc):
+    """y = X X' probe against the numpy golden (independent of the C oracle)."""
+    for name in ("data_chr1", "hapmap3_data"):
+        ctx, od, g = _load(golden_dir, name, "binom2", fp, orc)
+        probe = np.cos(0.37 * np.arange(ctx.N) + 0.11) + 0.25
+        y = ctx.apply_xxt(probe.reshape(-1, 1))[:, 0]
+        assert np.allclose(y[:8], g["probe_y_first8"], rtol=1e-11, atol=0)
+        assert abs(np.linalg.norm(y) - g["probe_y_norm"]) <= 1e-12 * g["probe_y_norm"]
+        ctx.close()
+
+
+@pytest.mark.parametrize("N,P", [(1, 3), (5, 7), (64, 1), (257, 300), (1000, 513), (2051, 129)])
+def test_ragged_shapes_vs_oracle(N, P, fp, orc):
+    """Edge shapes: N not a multiple of 4 (pad bits in the last byte), tiny / single SNP, monomorphic and
+    all-missing SNPs."""
+    rng = np.random.default_rng(N * 1000 + P)
+    npk = (N + 3) // 4
+    packed = rng.integers(0, 256, size=(P, npk), dtype=np.uint8)
+    if P >= 3:
+        packed[1, :] = 0xFF  # monomorphic (all hom A2) -> zero column (data.cpp:299)
+        packed[2, :] = 0x55  # all missing -> NaN mean, zero column
+    ctx = fp.Context.from_packed(packed, N, P)
+    od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+    X = od.dense()
+    ms, _ = ctx.stats()
+    oms = od.meansd()
+    assert np.array_equal(np.isnan(ms), np.isnan(oms))
+    assert np.array_equal(ms[~np.isnan(ms)], oms[~np.isnan(oms)])
+    B = rng.standard_normal((N, 3))
+    Z_ref = X @ (X.T @ B)
+    Z = ctx.apply_xxt(B)
+    assert np.all(np.isfinite(Z))
+    assert np.max(np.abs(Z - Z_ref)) <= 1e-11 * max(1.0, np.max(np.abs(Z_ref)))
+    ctx.close()
+
+
+def test_synthetic_generator_and_roundtrip(fp, orc):
+    """The on-GPU generator is deterministic, shard-consistent, and its matrix round-trips through the oracle."""
+    N, P = 3000, 700
+    a = fp.Context.synthetic(N, P, snp_begin=0, n_pop=12)
+    b1 = fp.Context.synthetic(N, 300, snp_begin=0, n_pop=12)
+    b2 = fp.Context.synthetic(N, 400, snp_begin=300, n_pop=12)
+    pa = a.download_packed().reshape(P, -1)
+    assert np.array_equal(pa[:300], b1.download_packed().reshape(300, -1))
+    assert np.array_equal(pa[300:], b2.download_packed().reshape(400, -1))
+    codes = np.stack([(pa >> (2 * s)) & 3 for s in range(4)], axis=-1).reshape(P, -1)[:, :N]
+    miss = (codes == 1).mean()
+    assert 0.0002 < miss < 0.003  # missing_rate 0.001
+    od = orc.OracleData(packed=pa, N=N, P=P, stand="binom2")
+    X = od.dense()
+    rng = np.random.default_rng(0)
+    B = rng.standard_normal((N, 32))
+    Z = a.apply_xxt(B)
+    Z_ref = X @ (X.T @ B)
+    assert np.max(np.abs(Z - Z_ref)) <= 1e-11 * np.max(np.abs(Z_ref))
+    # sharded sum == full (the multi-GPU identity, svdwide.cpp:48-62)
+    Zs = b1.apply_xxt(B) + b2.apply_xxt(B)
+    assert np.max(np.abs(Zs - Z)) <= 1e-11 * np.max(np.abs(Z))
+    for c in (a, b1, b2):
+        c.close()
+
+
+def test_linearity_at_scale(fp):
+    """Size-independent property at a size the oracle cannot touch: X X'(a u + v) == a X X' u + X X' v."""
+    N, P = 50000, 20000
+    ctx = fp.Context.synthetic(N, P)
+    rng = np.random.default_rng(1)
+    u = rng.standard_normal((N, 16))
+    v = rng.standard_normal((N, 16))
+    lhs = ctx.apply_xxt(2.5 * u + v)
+    rhs = 2.5 * ctx.apply_xxt(u) + ctx.apply_xxt(v)
+    assert np.max(np.abs(lhs - rhs)) <= 1e-11 * np.max(np.abs(lhs))
+    # symmetry: u' (A v) == (A u)' v
+    Au, Av = ctx.apply_xxt(u), ctx.apply_xxt(v)
+    s1, s2 = np.sum(u * Av), np.sum(Au * v)
+    assert abs(s1 - s2) <= 1e-10 * abs(s1)
+    ctx.close()

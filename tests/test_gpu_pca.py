@@ -1,0 +1,138 @@
+"""GPU parity tests of the whole path (fpca_pca through the C ABI) against the goldens and the CPU oracle.
+
+Tolerances (fp64 path): eigenvalues 1e-9 relative (north_star asks 1e-6), eigenvectors compared up to sign like
+every reference test (flashpcaR/tests/testthat/test_pca.R:29-31, HapMap3/test_pca.R:154-165).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fp(built_lib):
+    import flashpca_amd
+
+    return flashpca_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle as O
+
+    O.build()
+    return O
+
+
+@pytest.mark.parametrize("name,k,stand", [("hapmap3_data", 10, "binom2"), ("data_chr1", 50, "binom2"),
+                                          ("data_chr1", 10, "binom"), ("data_chr1", 3, "binom2")])
+def test_pca_matches_golden(golden_dir, name, k, stand, fp):
+    g = json.load(open(os.path.join(golden_dir, "golden_%s_%s.json" % (name, stand))))
+    r = fp.flashpca(os.path.join(golden_dir, name), ndim=k, stand=stand, do_loadings=True, tol=1e-8)
+    ev = np.array(g["eigenvalues_div_p"])[:k]
+    assert r["info"]["converged"] == 1
+    assert np.max(np.abs(r["values"] - ev) / ev) < 1e-9
+    assert np.max(np.abs(r["pve"] - np.array(g["pve"])[:k])) < 1e-11
+    U = r["vectors"]
+    assert np.max(np.abs(U.T @ U - np.eye(k))) < 1e-10
+    U5 = np.array(g["U_first5"]).T
+    for c in range(min(5, k)):
+        assert abs(abs(U5[:, c] @ U[:, c]) - 1.0) < 1e-8
+    # projection = U sqrt(d) (randompca.cpp:207)
+    assert np.allclose(r["projection"], U * np.sqrt(r["values"]), rtol=1e-14, atol=0)
+    # loadings are unit-norm right singular vectors: V = X'U / sqrt(d P) (randompca.cpp:191-204)
+    V = r["loadings"]
+    assert np.max(np.abs(np.sum(V * V, axis=0) - 1.0)) < 1e-8
+    assert np.allclose(r["center"][:8], g["mean_first8"], rtol=0, atol=0)
+    assert np.allclose(r["scale"][:8], g["sd_first8"], rtol=0, atol=0)
+
+
+def test_pca_vs_oracle_reference_path(golden_dir, fp, orc):
+    """Same answers as the restated reference path (Spectra-style IRLM on the CPU) at the reference's defaults."""
+    name, k = "hapmap3_data", 10
+    N = fp.count_fam_rows(os.path.join(golden_dir, name + ".fam"))
+    od = orc.OracleData(os.path.join(golden_dir, name + ".bed"), N, "binom2")
+    ref = orc.pca_fast(od, k, do_loadings=True)
+    r = fp.flashpca(os.path.join(golden_dir, name), ndim=k, do_loadings=True)
+    assert np.max(np.abs(r["values"] - ref["d"]) / ref["d"]) < 1e-6  # both converged to tol 1e-6: agree far better
+    assert np.max(np.abs(r["pve"] - ref["pve"])) < 1e-8
+    for c in range(5):  # well-separated components; up to sign
+        s = np.sign(ref["U"][:, c] @ r["vectors"][:, c])
+        assert np.max(np.abs(ref["U"][:, c] * s - r["vectors"][:, c])) < 1e-5
+        assert np.max(np.abs(ref["V"][:, c] * s - r["loadings"][:, c])) < 1e-5
+    assert np.array_equal(r["center"], ref["meansd"][:, 0])
+    assert np.array_equal(r["scale"], ref["meansd"][:, 1])
+
+
+def test_check_mode(golden_dir, fp, orc):
+    """fpca_check == RandomPCA::check (randompca.cpp:663-703) == the oracle's restatement."""
+    name, k = "data_chr1", 10
+    N = fp.count_fam_rows(os.path.join(golden_dir, name + ".fam"))
+    bed = os.path.join(golden_dir, name + ".bed")
+    with fp.Context.from_bed(bed, N) as ctx:
+        r = ctx.pca(ndim=k, tol=1e-8)
+        err, mse, rmse = ctx.check(r["U"], r["d"])
+        assert mse < 1e-8  # README.md:207 "should be low (e.g., <1e-8)"
+        od = orc.OracleData(bed, N, "binom2")
+        oerr, omse, ormse = orc.check(od, r["U"], r["d"], block_size=400)
+        assert abs(mse - omse) <= 1e-6 * max(omse, 1e-30) + 1e-22
+        # a deliberately wrong eigenvalue must show up identically in both
+        bad = r["d"].copy()
+        bad[0] *= 1.01
+        e2, m2, _ = ctx.check(r["U"], bad)
+        o2, om2, _ = orc.check(od, r["U"], bad, block_size=400)
+        assert np.allclose(e2, o2, rtol=1e-9, atol=1e-20)
+
+
+def test_restart_path_and_blockvec(golden_dir, fp):
+    """Small basis cap forces thick restarts; result must not change."""
+    g = json.load(open(os.path.join(golden_dir, "golden_hapmap3_data_binom2.json")))
+    N = fp.count_fam_rows(os.path.join(golden_dir, "hapmap3_data.fam"))
+    with fp.Context.from_bed(os.path.join(golden_dir, "hapmap3_data.bed"), N) as ctx:
+        ev = np.array(g["eigenvalues_div_p"])
+        for kw in (dict(max_blocks=4), dict(blockvec=32), dict(blockvec=48, max_blocks=3), dict(blockvec=64)):
+            r = ctx.pca(ndim=10, tol=1e-8, **kw)
+            assert r["info"]["converged"] == 1
+            assert np.max(np.abs(r["d"] - ev) / ev) < 1e-9
+        r = ctx.pca(ndim=10, tol=1e-8, max_blocks=4)
+        assert r["info"]["restarts"] >= 1
+
+
+def test_ndim_limit_and_errors(golden_dir, fp):
+    N = fp.count_fam_rows(os.path.join(golden_dir, "data_chr1.fam"))
+    with fp.Context.from_bed(os.path.join(golden_dir, "data_chr1.bed"), N) as ctx:
+        with pytest.raises(fp.FpcaError):
+            ctx.pca(ndim=0)
+        with pytest.raises(fp.FpcaError):
+            ctx.pca(ndim=10, blockvec=24)
+    with pytest.raises(fp.FpcaError):
+        fp.Context.from_bed("/nonexistent/file.bed", 10)
+    # ndim > (min(N,P)-1)/2 is refused like the CLI does (flashpca.cpp:623-633)
+    rng = np.random.default_rng(0)
+    packed = rng.integers(0, 256, size=(40, 25), dtype=np.uint8)
+    with fp.Context.from_packed(packed, 100, 40) as ctx:
+        with pytest.raises(fp.FpcaError):
+            ctx.pca(ndim=20)
+
+
+def test_config2_pca_end_to_end(fp, orc):
+    """BASELINE config 2 (50,000 x 20,000, k=20) on the GPU; verified with the reference's own --check quantity
+    computed on the GPU for all pairs and by the CPU oracle for the operator on a probe."""
+    N, P, k = 50000, 20000, 20
+    with fp.Context.synthetic(N, P) as ctx:
+        r = ctx.pca(ndim=k)
+        assert r["info"]["converged"] == 1
+        err, mse, rmse = ctx.check(r["U"], r["d"])
+        assert np.all(np.sqrt(err) <= 1e-6 * r["d"] * 1.01)  # ||A u/P - d u|| <= tol * d  (Spectra's rule, tol 1e-6)
+        assert np.all(np.diff(r["d"]) < 0)
+        # oracle leg: one operator application of the top eigenvector on a 2000-SNP shard of the same matrix
+        with fp.Context.synthetic(N, 2000, snp_begin=0) as sh:
+            packed = sh.download_packed()
+            od = orc.OracleData(packed=packed, N=N, P=2000, stand="binom2")
+            op = orc.OracleOp(od, 500)
+            y_ref = op.perform_op(r["U"][:, 0])
+            y = sh.apply_xxt(r["U"][:, :1])[:, 0]
+            assert np.max(np.abs(y - y_ref)) <= 1e-11 * np.max(np.abs(y_ref))
