@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the flashpca PCA hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1 directly; N>1 under torch.distributed.run)
+
+A "step" is ONE pass of the hot path over the resident genotype matrix: the block operator
+Y = sum_g X_g X_g' B on b = 32 columns (k = 20 PCA -> b = 32), i.e. K2 (xt_b) + K3 (x_t) + the all-reduce
+of the N x b product when N > 1.  That is b single-vector applications of the reference's perform_op
+(svdwide.cpp:21-68), so   value = N_samples * P_total * b * K / time   [genotype cells / s], the metric
+BASELINE.json names ("N x P x iters" with iters = single-vector operator applications).
+
+Workload (BASELINE.json configs[1]): synthetic 50,000 samples x 20,000 SNPs per GPU, k = 20; weak scaling:
+every rank holds its own 20,000-SNP shard of a (20,000 * N)-SNP matrix, generated directly in HBM.
+`--workload cfg3` selects the 500,000 x 100,000 paper-headline matrix (configs[2]/[3], SNP-sharded = strong).
+
+The same JSON line also carries: the roofline of the dominant kernel (HIP events recorded live on the
+kernels' stream inside the timed region), a bounded CPU baseline (the oracle = restated reference path, one
+thread, like the shipped reference), and the wall-clock of one full k=20 PCA solve to convergence.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (vendor datasheet); HBM3E 8 TB/s
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (N samples, SNPs, k, block width, sharding)
+    "cfg2": dict(N=50000, P=20000, k=20, b=32, scaling="weak",
+                 desc="synthetic .bed-layout matrix, 50000 samples x 20000 SNPs per GPU, k=20 (BASELINE configs[1])"),
+    "cfg3": dict(N=500000, P=100000, k=20, b=32, scaling="strong",
+                 desc="synthetic 500000 samples x 100000 SNPs total, SNP-sharded across GPUs, k=20 (BASELINE configs[2]/[3])"),
+    "tiny": dict(N=4000, P=3000, k=20, b=32, scaling="weak", desc="smoke-size workload"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pca", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the bounded baseline sample")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import flashpca_amd as fp
+
+    w = WORKLOADS[args.workload]
+    N, k, b = w["N"], w["k"], w["b"]
+    if w["scaling"] == "weak":
+        P_rank, P_total, snp_begin = w["P"], w["P"] * world, rank * w["P"]
+    else:
+        lo, hi = w["P"] * rank // world, w["P"] * (rank + 1) // world
+        P_rank, P_total, snp_begin = hi - lo, w["P"], lo
+
+    t_gen = time.time()
+    ctx = fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=2 * k, device=local_rank)
+    ctx.set_total_snps(P_total)
+    ctx.stats()
+    t_gen = time.time() - t_gen
+
+    transport = "single"
+    if world > 1:
+        # RCCL inside the library (id broadcast over torch.distributed); falls back to torch.distributed's own
+        # all-reduce (also RCCL) through the C-ABI hook if the native communicator cannot be created
+        ids = [fp.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ok = torch.ones(1, device="cuda")
+        try:
+            ctx.comm_init_rank(world, rank, ids[0])
+            transport = "rccl-native"
+        except Exception as e:  # pragma: no cover - needs multi-GPU
+            ok.zero_()
+            if rank == 0:
+                print("native RCCL init failed (%s); using torch.distributed all-reduce" % e, file=sys.stderr)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            transport = "torch.distributed"
+
+            class _Arr:
+                def __init__(self, ptr, n):
+                    self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
+
+            def allreduce(ptr, count, stream):
+                ctx.synchronize()
+                t = torch.as_tensor(_Arr(ptr, count), device="cuda")
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
+                return 0
+
+            ctx.set_allreduce(allreduce)
+
+    rows = ctx.block_rows()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    B = torch.zeros((rows, b), dtype=torch.float64, device="cuda")
+    B[:N] = torch.rand((N, b), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    Y = torch.zeros((rows, b), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctx.apply_xxt_dev(B.data_ptr(), b, Y.data_ptr())
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ctx.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.apply_xxt_dev(B.data_ptr(), b, Y.data_ptr())
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_end(b)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cells = float(N) * float(P_total) * b * args.steps
+    value = cells / elapsed
+
+    # roofline of the dominant kernel (both GEMMs carry 2 N P_g b flops per launch; the slower one dominates)
+    dom = "xt_b" if prof["ms_xt"] >= prof["ms_x"] else "x_t"
+    ms_dom = max(prof["ms_xt"], prof["ms_x"])
+    flops_launch = 2.0 * N * P_rank * b
+    roofline = dict(bound="mfma", kernel=dom, achieved=flops_launch / (ms_dom * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TFLOPS,
+                    unit="TFLOP/s", traffic=None,
+                    ms_xt_b=prof["ms_xt"], ms_x_t=prof["ms_x"], ms_allreduce=prof["ms_allreduce"],
+                    flops_per_launch=flops_launch,
+                    packed_gbs=((N + 3) // 4) * P_rank / (ms_dom * 1e-3) / 1e9)
+    roofline["frac"] = roofline["achieved"] / roofline["peak"]
+
+    out = dict(metric="genotype cells/sec (N x P x iters) for k=20 PCA", value=value, unit="cells/s", n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
+               scaling=w["scaling"], vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload=args.workload + ": " + w["desc"], samples=N, snps_total=P_total, snps_per_gpu=P_rank,
+                           k=k, blockvec=b, parallelism="snp-shard x%d + all-reduce(N x b) [%s]" % (world, transport),
+                           iters_per_step=b, generate_s=round(t_gen, 3)),
+               roofline=roofline)
+
+    # ---- one full PCA solve to convergence (reported, not the timed region) -------------------------------
+    if not args.no_pca:
+        barrier()
+        t1 = time.perf_counter()
+        r = ctx.pca(ndim=k, allow_unconverged=True)
+        ctx.synchronize()
+        barrier()
+        wall = time.perf_counter() - t1
+        info = r["info"]
+        out["pca"] = dict(wall_s=wall, converged=bool(info["converged"]), block_applies=info["block_applies"],
+                          vector_ops=info["vector_ops"], restarts=info["restarts"],
+                          cells_per_s=float(N) * P_total * info["vector_ops"] / wall,
+                          seconds_apply=info["seconds_apply"], seconds_ortho=info["seconds_ortho"],
+                          seconds_host=info["seconds_host"], eigenvalue_1=float(r["d"][0]), eigenvalue_k=float(r["d"][-1]),
+                          max_rel_residual=info["max_residual"])
+
+    # ---- CPU baseline: the oracle (restated reference path) on a bounded sample, rank 0, N=1 only -----------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+
+        O.build()
+        P_s = min(P_rank, 1000)
+        with fp.Context.synthetic(N, P_s, snp_begin=0, n_pop=2 * k, device=local_rank) as sh:
+            packed = sh.download_packed()
+        od = O.OracleData(packed=packed, N=N, P=P_s, stand="binom2")
+        bs = O.lib().orc_default_block_size(N, P_total, k, 0, 2048) or 1  # flashpca.cpp:636-686 on the FULL problem
+        op = O.OracleOp(od, min(bs, P_s), nthreads=1)
+        import numpy as np
+
+        x = np.random.default_rng(0).standard_normal(N)
+        op.perform_op(x)  # first visit computes mean/sd (not timed, like the GPU side's stats pass)
+        nops, tc = 0, time.perf_counter()
+        while True:
+            op.perform_op(x)
+            nops += 1
+            if time.perf_counter() - tc > args.cpu_seconds or nops >= 200:
+                break
+        tc = time.perf_counter() - tc
+        out["cpu_baseline"] = dict(value=float(N) * P_s * nops / tc, unit="cells/s", cores=1, kind="port",
+                                   sample="%d single-vector operator applications (decode->LUT->dense fp64 block->2 GEMV, "
+                                          "svdwide.cpp:21-68) on the first %d SNPs x %d samples of the same synthetic matrix, "
+                                          "block size %d, 1 thread, %.1f s" % (nops, P_s, N, min(bs, P_s), tc),
+                                   host_cores=os.cpu_count())
+
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -167,6 +167,27 @@ class Context:
         check(lib().fpca_bench_apply(self.h, b, steps, warmup, C.byref(r)))
         return {f[0]: getattr(r, f[0]) for f in BenchResult._fields_}
 
+    def block_rows(self):
+        return int(lib().fpca_block_rows(self.h))
+
+    def apply_xxt_dev(self, dB_ptr, b, dY_ptr, stream=None):
+        """Device-resident operator on row-major [block_rows][b] fp64 blocks given by raw device pointers."""
+        check(lib().fpca_apply_xxt_dev(self.h, C.c_void_p(dB_ptr), b, C.c_void_p(dY_ptr), C.c_void_p(stream) if stream else None))
+
+    def synchronize(self):
+        check(lib().fpca_synchronize(self.h))
+
+    def profile_begin(self, max_steps):
+        check(lib().fpca_profile_begin(self.h, max_steps))
+
+    def profile_end(self, b):
+        r = BenchResult()
+        n = C.c_int(0)
+        check(lib().fpca_profile_end(self.h, b, C.byref(r), C.byref(n)))
+        out = {f[0]: getattr(r, f[0]) for f in BenchResult._fields_}
+        out["nsteps"] = n.value
+        return out
+
     def bench_stats(self, reps=5):
         ms, by = C.c_double(0), C.c_double(0)
         check(lib().fpca_bench_stats(self.h, reps, C.byref(ms), C.byref(by)))

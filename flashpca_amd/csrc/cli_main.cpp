@@ -1,0 +1,536 @@
+// cli_main.cpp -- `flashpca`, drop-in for the reference CLI's PCA modes (flashpca.cpp:30-895) on MI355X.
+//
+// Same flags (flashpca.cpp:41-92), same defaults (ndim 10, standx binom2, div p, tol 1e-6, maxiter 500, precision 7,
+// suffix .txt), same stdout milestones and the same output files/format (eigenvalues / eigenvectors / pcs / pve
+// [/ loadings / meansd], flashpca.cpp:755-878).  Host C++ only: all arithmetic goes through the C ABI of libfpca.so
+// (include/fpca.h); there is no CPU compute path.  Modes outside the PCA hot path (--scca, --ucca) are refused.
+// New, MI355X-specific flags: --device, --blockvec, --maxblocks.  --memory/--blocksize/--batch/--numthreads are
+// accepted for compatibility; the packed matrix is always fully resident in HBM so they have no effect.
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <iostream>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/fpca.h"
+#include "plink_io.hpp"
+
+#define FLASHPCA_VERSION "2.1-mi355x (" FPCA_VERSION ")"
+
+namespace {
+
+bool show_timestamp = true;
+
+std::string timestamp() // util.cpp:270-283
+{
+   if (!show_timestamp) return "";
+   time_t t = time(nullptr);
+   char *s = asctime(localtime(&t));
+   s[strlen(s) - 1] = '\0';
+   return std::string("[") + s + "] ";
+}
+
+struct OptSpec {
+   const char *name;
+   char shortname;
+   bool has_value;
+   const char *help;
+};
+
+const OptSpec OPTS[] = {
+   {"help", 0, false, "produce help message"},
+   {"scca", 0, false, "perform sparse canonical correlation analysis (SCCA) [not supported by this build]"},
+   {"ucca", 0, false, "perform per-SNP canonical correlation analysis [not supported by this build]"},
+   {"project", 'p', false, "project new samples onto existing principal components"},
+   {"batch", 0, false, "load all genotypes into RAM at once (no effect: the packed matrix is always resident in HBM)"},
+   {"memory", 'm', true, "size of block, in MB (no effect)"},
+   {"blocksize", 'b', true, "size of block for, in number of SNPs (no effect)"},
+   {"numthreads", 'n', true, "set number of OpenMP threads (no effect)"},
+   {"seed", 0, true, "set random seed"},
+   {"bed", 0, true, "PLINK bed file"},
+   {"bim", 0, true, "PLINK bim file"},
+   {"fam", 0, true, "PLINK fam file"},
+   {"pheno", 0, true, "PLINK phenotype file"},
+   {"bfile", 0, true, "PLINK root name"},
+   {"ndim", 'd', true, "number of PCs to output"},
+   {"standx", 's', true, "standardization method for genotypes [binom2 | binom]"},
+   {"standy", 0, true, "standardization method for phenotypes (CCA only; ignored)"},
+   {"div", 0, true, "whether to divide the eigenvalues by p, n - 1, or don't divide [p | n1 | none]"},
+   {"outpc", 0, true, "PC output file"},
+   {"outvec", 0, true, "eigenvector output file"},
+   {"outload", 0, true, "SNP loadings"},
+   {"outval", 0, true, "Eigenvalue output file"},
+   {"outpve", 0, true, "proportion of variance explained output file"},
+   {"outmeansd", 0, true, "mean+SD (used to standardize SNPs) output file"},
+   {"outproj", 0, true, "PCA projection output file"},
+   {"inload", 0, true, "SNP loadings input file"},
+   {"inmeansd", 0, true, "mean+SD (used to standardize SNPs) input file"},
+   {"inmaf", 0, true, "MAF input file"},
+   {"verbose", 'v', false, "verbose"},
+   {"tol", 0, true, "tolerance for PCA iterations"},
+   {"maxiter", 0, true, "maximum number of iterations (block applies)"},
+   {"suffix", 'f', true, "suffix for all output files"},
+   {"check", 'c', false, "check eigenvalues/eigenvectors"},
+   {"precision", 0, true, "digits of precision for output"},
+   {"notime", 0, false, "don't print timestamp in output"},
+   {"version", 0, false, "version"},
+   {"device", 0, true, "HIP device index [0]"},
+   {"blockvec", 0, true, "block width of the eigensolver: 16, 32, 48 or 64 [smallest multiple of 16 >= ndim+4]"},
+   {"maxblocks", 0, true, "basis cap (in blocks) before a thick restart [automatic]"},
+};
+
+const OptSpec *find_long(const std::string &n)
+{
+   for (const auto &o : OPTS)
+      if (n == o.name) return &o;
+   return nullptr;
+}
+const OptSpec *find_short(char c)
+{
+   for (const auto &o : OPTS)
+      if (o.shortname && o.shortname == c) return &o;
+   return nullptr;
+}
+
+typedef std::map<std::string, std::string> VarMap;
+
+// throws std::runtime_error like boost::program_options does on malformed command lines
+VarMap parse_command_line(int argc, char *argv[])
+{
+   VarMap vm;
+   for (int i = 1; i < argc; i++) {
+      std::string a = argv[i];
+      const OptSpec *o = nullptr;
+      std::string val;
+      bool have_val = false;
+      if (a.rfind("--", 0) == 0) {
+         std::string body = a.substr(2);
+         size_t eq = body.find('=');
+         if (eq != std::string::npos) {
+            val = body.substr(eq + 1);
+            have_val = true;
+            body = body.substr(0, eq);
+         }
+         o = find_long(body);
+         if (!o) throw std::runtime_error("unrecognised option '" + a + "'");
+      } else if (a.size() >= 2 && a[0] == '-') {
+         o = find_short(a[1]);
+         if (!o) throw std::runtime_error("unrecognised option '" + a + "'");
+         if (a.size() > 2) {
+            val = a.substr(2);
+            have_val = true;
+         }
+      } else
+         throw std::runtime_error("too many positional options have been specified on the command line");
+      if (o->has_value) {
+         if (!have_val) {
+            if (i + 1 >= argc) throw std::runtime_error(std::string("the required argument for option '--") + o->name + "' is missing");
+            val = argv[++i];
+         }
+         vm[o->name] = val;
+      } else {
+         if (have_val) throw std::runtime_error(std::string("option '--") + o->name + "' does not take any arguments");
+         vm[o->name] = "";
+      }
+   }
+   return vm;
+}
+
+long to_long(const VarMap &vm, const char *name)
+{
+   const std::string &s = vm.at(name);
+   char *end = nullptr;
+   errno = 0;
+   long v = std::strtol(s.c_str(), &end, 10);
+   if (*end != '\0' || errno != 0 || s.empty()) throw std::runtime_error(std::string("the argument ('") + s + "') for option '--" + name + "' is invalid");
+   return v;
+}
+double to_double(const VarMap &vm, const char *name)
+{
+   const std::string &s = vm.at(name);
+   char *end = nullptr;
+   errno = 0;
+   double v = std::strtod(s.c_str(), &end);
+   if (*end != '\0' || errno != 0 || s.empty()) throw std::runtime_error(std::string("the argument ('") + s + "') for option '--" + name + "' is invalid");
+   return v;
+}
+
+void print_help()
+{
+   std::cerr << "Options:" << std::endl;
+   for (const auto &o : OPTS) {
+      std::string left = "  ";
+      if (o.shortname) left += std::string("-") + o.shortname + " [ --" + o.name + " ]";
+      else left += std::string("--") + o.name;
+      if (o.has_value) left += " arg";
+      while (left.size() < 30) left += ' ';
+      std::cerr << left << " " << o.help << std::endl;
+   }
+   std::cerr << std::endl;
+}
+
+void fpca_ok(int rc)
+{
+   if (rc != FPCA_OK) throw std::runtime_error(fpca_last_error());
+}
+
+} // namespace
+
+int main(int argc, char *argv[])
+{
+   VarMap vm;
+   try {
+      vm = parse_command_line(argc, argv);
+   } catch (std::exception &e) {
+      // flashpca.cpp:100-106 (exit status is EXIT_SUCCESS there too)
+      std::cerr << e.what() << std::endl << "Use --help to get more help" << std::endl;
+      return EXIT_SUCCESS;
+   }
+   auto has = [&](const char *n) { return vm.count(n) > 0; };
+
+   show_timestamp = !has("notime");
+   const bool verbose = has("verbose");
+
+   std::cout << timestamp() << "arguments: flashpca ";
+   for (int i = 0; i < argc; i++) std::cout << argv[i] << " ";
+   std::cout << std::endl;
+
+   if (has("version")) {
+      std::cerr << "flashpca " << FLASHPCA_VERSION << std::endl;
+      std::cerr << "MI355X-native implementation of the flashpca 2.1 PCA path (command line after Gad Abraham's flashpca)." << std::endl << std::endl;
+      return EXIT_SUCCESS;
+   }
+   if (has("help")) {
+      std::cerr << "flashpca " << FLASHPCA_VERSION << std::endl;
+      print_help();
+      return EXIT_SUCCESS;
+   }
+
+   // ---- mode selection (flashpca.cpp:136-228) ------------------------------------------------------------
+   enum { MODE_PCA, MODE_CHECK, MODE_PROJECT } mode = MODE_PCA;
+   const char *modes[] = {"ucca", "scca", "check", "project"};
+   for (const char *m1 : modes)
+      for (const char *m2 : modes)
+         if (std::string(m1) < m2 && has(m1) && has(m2)) {
+            std::cerr << "Error: conflicting modes requested: --" << m1 << ", --" << m2 << std::endl << "Use --help to get more help" << std::endl;
+            return EXIT_FAILURE;
+         }
+   if (has("scca") || has("ucca")) {
+      std::cerr << "Error: --scca / --ucca are outside the PCA path this build implements" << std::endl;
+      return EXIT_FAILURE;
+   }
+   if (has("check")) mode = MODE_CHECK;
+   else if (has("project")) {
+      mode = MODE_PROJECT;
+      if (!has("inload")) {
+         std::cerr << "Error: SNP-loadings must be specified using --inload" << std::endl;
+         return EXIT_FAILURE;
+      }
+      if (!has("inmaf") && !has("inmeansd")) {
+         std::cerr << "Error: one of MAF or mean/stdev must be specified using  --inmaf or --inmeansd, respectively" << std::endl;
+         return EXIT_FAILURE;
+      }
+   }
+
+   try {
+      if (has("memory") && to_long(vm, "memory") < 1) {
+         std::cerr << "Error: memory (MB) must be >=1" << std::endl;
+         return EXIT_FAILURE;
+      }
+      if (has("blocksize")) {
+         if (has("memory")) {
+            std::cerr << "Error: cannot specify both --memory and --blocksize at the same time" << std::endl;
+            return EXIT_FAILURE;
+         }
+         if (to_long(vm, "blocksize") < 1) {
+            std::cerr << "Error: blocksize must be >=1" << std::endl;
+            return EXIT_FAILURE;
+         }
+      }
+      if (has("numthreads")) (void)to_long(vm, "numthreads");
+      long seed = has("seed") ? to_long(vm, "seed") : 1L;
+
+      std::string fam_file, geno_file, bim_file;
+      if (has("bfile")) {
+         geno_file = vm["bfile"] + ".bed";
+         bim_file = vm["bfile"] + ".bim";
+         fam_file = vm["bfile"] + ".fam";
+      } else if (has("bed") && has("bim") && has("fam")) {
+         geno_file = vm["bed"];
+         bim_file = vm["bim"];
+         fam_file = vm["fam"];
+      } else {
+         std::cerr << "Error: you must specify either --bfile or --bed / --fam / --bim" << std::endl << "Use --help to get more help" << std::endl;
+         return EXIT_FAILURE;
+      }
+
+      int n_dim = 10;
+      if (has("ndim")) {
+         n_dim = (int)to_long(vm, "ndim");
+         if (n_dim < 1) {
+            std::cerr << "Error: --ndim can't be less than 1" << std::endl;
+            return EXIT_FAILURE;
+         }
+      }
+      int stand_method_x = FPCA_STANDARDISE_BINOM2;
+      if (has("standx")) {
+         const std::string m = vm["standx"];
+         if (m == "binom") stand_method_x = FPCA_STANDARDISE_BINOM;
+         else if (m == "binom2") stand_method_x = FPCA_STANDARDISE_BINOM2;
+         else {
+            std::cerr << "Error: unknown standardization method (--standx): " << m << std::endl;
+            return EXIT_FAILURE;
+         }
+      }
+      std::string suffix = has("suffix") ? vm["suffix"] : ".txt";
+      std::string pcfile = has("outpc") ? vm["outpc"] : "pcs" + suffix;
+      std::string eigvecfile = has("outvec") ? vm["outvec"] : "eigenvectors" + suffix;
+      std::string eigvalfile = has("outval") ? vm["outval"] : "eigenvalues" + suffix;
+      std::string eigpvefile = has("outpve") ? vm["outpve"] : "pve" + suffix;
+      std::string meansdfile = has("outmeansd") ? vm["outmeansd"] : "meansd" + suffix;
+      const bool save_meansd = has("outmeansd");
+      std::string projfile = has("outproj") ? vm["outproj"] : "projection" + suffix;
+
+      int maxiter = 500;
+      if (has("maxiter")) {
+         maxiter = (int)to_long(vm, "maxiter");
+         if (maxiter <= 0) {
+            std::cerr << "Error: --maxiter can't be less than 1" << std::endl;
+            return EXIT_FAILURE;
+         }
+      }
+      double tol = 1e-6;
+      if (has("tol")) {
+         tol = to_double(vm, "tol");
+         if (tol <= 0) {
+            std::cerr << "Error: --tol can't be zero or negative" << std::endl;
+            return EXIT_FAILURE;
+         }
+      }
+      const bool do_loadings = has("outload");
+      const std::string loadingsfile = do_loadings ? vm["outload"] : "";
+      int divisor = FPCA_DIVISOR_P;
+      if (has("div")) {
+         const std::string m = vm["div"];
+         if (m == "none") divisor = FPCA_DIVISOR_NONE;
+         else if (m == "n1") divisor = FPCA_DIVISOR_N1;
+         else if (m == "p") divisor = FPCA_DIVISOR_P;
+         else {
+            std::cerr << "Error: unknown divisor (--div): " << m << std::endl;
+            return EXIT_FAILURE;
+         }
+      }
+      std::string in_meansd_file, in_maf_file, in_load_file;
+      if (has("inmeansd")) {
+         if (has("inmaf")) {
+            std::cerr << "Error: conflicting options requested --inmeansd, --inmaf" << std::endl;
+            return EXIT_FAILURE;
+         }
+         in_meansd_file = vm["inmeansd"];
+         if (in_meansd_file.empty()) {
+            std::cerr << "Error: no file specified for --inmeansd" << std::endl;
+            return EXIT_FAILURE;
+         }
+      } else if (has("inmaf")) {
+         in_maf_file = vm["inmaf"];
+         if (in_maf_file.empty()) {
+            std::cerr << "Error: no file specified for --inmaf" << std::endl;
+            return EXIT_FAILURE;
+         }
+      }
+      if (has("inload")) {
+         in_load_file = vm["inload"];
+         if (in_load_file.empty()) {
+            std::cerr << "Error: no file specified for --inload" << std::endl;
+            return EXIT_FAILURE;
+         }
+      }
+      int precision = 7;
+      if (has("precision")) {
+         precision = (int)to_long(vm, "precision");
+         if (precision <= 1) {
+            std::cerr << "Error: output --precision too low" << std::endl;
+            return EXIT_FAILURE;
+         }
+      }
+      const int device = has("device") ? (int)to_long(vm, "device") : 0;
+      const int blockvec = has("blockvec") ? (int)to_long(vm, "blockvec") : 0;
+      const int maxblocks = has("maxblocks") ? (int)to_long(vm, "maxblocks") : 0;
+
+      // ---- end of command line parsing -------------------------------------------------------------------
+      std::cout << timestamp() << "Start flashpca (version " << FLASHPCA_VERSION << ")" << std::endl;
+      verbose && std::cout << timestamp() << "seed: " << seed << std::endl;
+
+      // N = number of rows of the .fam whose 6th column parses as a number (flashpca.cpp:589 -> data.cpp:408-413)
+      fpca::TextMatrix pheno = fpca::read_text(fam_file, 6);
+      const uint64_t N = pheno.rows;
+      std::vector<std::string> snp_ids, ref_alleles, alt_alleles, fam_ids, indiv_ids;
+      fpca::read_plink_bim(bim_file, snp_ids, ref_alleles, alt_alleles);
+      fpca::read_plink_fam(fam_file, fam_ids, indiv_ids);
+      if (N == 0) throw std::runtime_error("no samples found in " + fam_file);
+
+      fpca_ctx *ctx = nullptr;
+      uint64_t nsnps = 0;
+      fpca_ok(fpca_create_from_bed(&ctx, geno_file.c_str(), N, 0, 0, stand_method_x, device, FPCA_ACCUM_FP64, &nsnps));
+      verbose && std::cout << timestamp() << "Detected BED file: " << geno_file << " with " << N << " samples, " << nsnps << " SNPs." << std::endl;
+      if (verbose) {
+         char name[256];
+         if (fpca_device_name(device, name, sizeof(name)) == FPCA_OK) std::cout << timestamp() << "Device " << device << ": " << name << std::endl;
+      }
+
+      // flashpca.cpp:623-633
+      const unsigned max_dim = (unsigned)((std::fmin((double)N, (double)nsnps) - 1) / 2.0);
+      if ((unsigned)n_dim > max_dim) {
+         std::cerr << "Error: You asked for " << n_dim << " dimensions, but only " << max_dim << "allowed" << std::endl;
+         fpca_destroy(ctx);
+         return EXIT_FAILURE;
+      }
+      // the reference prints its dense block geometry here (flashpca.cpp:688-690); the whole packed matrix is one resident block
+      std::cout << timestamp() << "blocksize: " << nsnps << " (" << (long long)((N + 3) / 4) * (long long)nsnps << " bytes per block)" << std::endl;
+
+      std::vector<double> U, d, Px, pve, V, meansd;
+      int k_out = n_dim;
+      if (mode == MODE_PCA) {
+         std::cout << timestamp() << "PCA begin" << std::endl;
+         fpca_pca_opts o;
+         fpca_pca_default_opts(&o);
+         o.ndim = n_dim;
+         o.blockvec = blockvec;
+         o.maxiter = maxiter;
+         o.tol = tol;
+         o.divisor = divisor;
+         o.do_loadings = do_loadings ? 1 : 0;
+         o.max_blocks = maxblocks;
+         o.verbose = verbose ? 1 : 0;
+         o.seed = (uint64_t)seed;
+         U.resize((size_t)N * n_dim);
+         Px.resize((size_t)N * n_dim);
+         d.resize(n_dim);
+         pve.resize(n_dim);
+         if (do_loadings) V.resize((size_t)nsnps * n_dim);
+         meansd.resize((size_t)nsnps * 2);
+         fpca_pca_info info;
+         int rc = fpca_pca(ctx, &o, U.data(), d.data(), Px.data(), pve.data(), do_loadings ? V.data() : nullptr, meansd.data(), &info);
+         if (rc == FPCA_ENOTCONVERGED) // randompca.cpp:210-217
+            throw std::runtime_error("Spectra eigen-decomposition was not successful, status: not converging");
+         fpca_ok(rc);
+         verbose && std::cout << timestamp() << "GRM trace: " << info.trace << std::endl;
+         verbose && std::cout << timestamp() << info.block_applies << " block applies of width " << info.blockvec << " (" << info.vector_ops
+                              << " vector operations), " << info.restarts << " restarts, device " << info.seconds_apply + info.seconds_ortho
+                              << " s, host " << info.seconds_host << " s" << std::endl;
+         std::cout << timestamp() << "PCA done" << std::endl;
+      } else if (mode == MODE_CHECK) {
+         // RandomPCA::check(Data&, block_size, evec_file, eval_file) (randompca.cpp:627-661)
+         fpca::TextMatrix ev = fpca::read_text(eigvalfile, 1, -1, 0);
+         if (ev.rows == 0) throw std::runtime_error("No eigenvalues found in file");
+         fpca::TextMatrix evec = fpca::read_text(eigvecfile, 3, -1, 1);
+         if (evec.rows != N)
+            throw std::runtime_error("Eigenvector dimension doesn't match data dimension (evec.rows = " + std::to_string(evec.rows) +
+                                     "; dat.N = " + std::to_string(N) + ")");
+         if (ev.rows != evec.cols) throw std::runtime_error("Eigenvector dimension doesn't match the number of eigenvalues");
+         const int K = (int)evec.cols;
+         std::vector<double> err(K);
+         double mse = 0, rmse = 0;
+         fpca_ok(fpca_check(ctx, evec.v.data(), (int64_t)N, ev.v.data(), K, divisor, err.data(), &mse, &rmse));
+         std::cout << timestamp() << "Checking mean square error between (X X' U) / div and (U D^2) for " << K << " dimensions" << std::endl;
+         for (int j = 0; j < K; j++)
+            std::cout << timestamp() << "eval(" << (j + 1) << "): " << ev.v[j] << ", sum squared error: " << err[j] << std::endl;
+         std::cout << timestamp() << "Mean squared error: " << mse << ", Root mean squared error: " << rmse << " (n=" << N << ")" << std::endl;
+      } else { // MODE_PROJECT: RandomPCA::project (randompca.cpp:745-820)
+         fpca::TextMatrix L = fpca::read_text(in_load_file, 3, -1, 1);
+         if (L.rows != nsnps) throw std::runtime_error("number of SNPs in the loadings file doesn't match the data");
+         std::vector<double> ms((size_t)nsnps * 2);
+         if (!in_maf_file.empty()) {
+            std::vector<double> maf = fpca::read_maf(in_maf_file, snp_ids);
+            if (maf.size() != nsnps) throw std::runtime_error("number of SNPs in the MAF file doesn't match the data");
+            for (uint64_t j = 0; j < nsnps; j++) { // maf2meansd (randompca.cpp:737-743), including its missing sqrt
+               ms[j] = maf[j] * 2.0;
+               ms[nsnps + j] = maf[j] * 2.0 * (1.0 - maf[j]);
+            }
+         } else {
+            fpca::TextMatrix M2 = fpca::read_text(in_meansd_file, 3, -1, 1);
+            if (M2.rows != nsnps || M2.cols < 2) throw std::runtime_error("mean/sd file doesn't match the data");
+            for (uint64_t j = 0; j < nsnps; j++) {
+               ms[j] = M2.at(j, 0);
+               ms[nsnps + j] = M2.at(j, 1);
+            }
+         }
+         fpca_ok(fpca_set_meansd(ctx, ms.data()));
+         k_out = (int)L.cols;
+         Px.resize((size_t)N * k_out);
+         fpca_ok(fpca_apply_x(ctx, L.v.data(), (int64_t)nsnps, k_out, Px.data(), (int64_t)N));
+         double div = 1;
+         if (divisor == FPCA_DIVISOR_N1) div = (double)N - 1;
+         else if (divisor == FPCA_DIVISOR_P) div = (double)L.rows;
+         const double s = std::sqrt(div);
+         for (auto &x : Px) x /= s; // randompca.cpp:818
+      }
+
+      // ---- write out results (flashpca.cpp:755-878) --------------------------------------------------------
+      const std::vector<std::string> none;
+      if (mode == MODE_PCA) {
+         std::cout << timestamp() << "Writing " << n_dim << " eigenvalues to file " << eigvalfile << std::endl;
+         fpca::save_text(d.data(), n_dim, 1, none, none, eigvalfile, precision);
+
+         std::cout << timestamp() << "Writing " << n_dim << " eigenvectors to file " << eigvecfile << std::endl;
+         std::vector<std::string> rownames(N);
+         for (uint64_t i = 0; i < N; i++) rownames[i] = fam_ids[i] + "\t" + indiv_ids[i];
+         std::vector<std::string> colnames(n_dim + 1);
+         colnames[0] = "FID\tIID";
+         for (int i = 0; i < n_dim; i++) colnames[i + 1] = "U" + std::to_string(i + 1);
+         fpca::save_text(U.data(), N, n_dim, colnames, rownames, eigvecfile, precision);
+
+         std::cout << timestamp() << "Writing " << n_dim << " PCs to file " << pcfile << std::endl;
+         for (int i = 0; i < n_dim; i++) colnames[i + 1] = "PC" + std::to_string(i + 1);
+         fpca::save_text(Px.data(), N, n_dim, colnames, rownames, pcfile, precision);
+
+         std::cout << timestamp() << "Writing " << n_dim << " proportion variance explained to file " << eigpvefile << std::endl;
+         fpca::save_text(pve.data(), n_dim, 1, none, none, eigpvefile, precision);
+
+         if (do_loadings) {
+            std::cout << timestamp() << "Writing SNP loadings to file " << loadingsfile << std::endl;
+            std::vector<std::string> cn = {"SNP\tRefAllele"};
+            for (int i = 0; i < n_dim; i++) cn.push_back("V" + std::to_string(i + 1));
+            std::vector<std::string> rn(snp_ids.size());
+            for (size_t i = 0; i < rn.size(); i++) rn[i] = snp_ids[i] + "\t" + ref_alleles[i];
+            if (rn.size() != nsnps) throw std::runtime_error("the .bim file has a different number of SNPs than the .bed");
+            fpca::save_text(V.data(), nsnps, n_dim, cn, rn, loadingsfile, precision);
+         }
+      } else if (mode == MODE_PROJECT) {
+         std::vector<std::string> rownames(N);
+         for (uint64_t i = 0; i < N; i++) rownames[i] = fam_ids[i] + "\t" + indiv_ids[i];
+         std::vector<std::string> colnames(k_out + 1);
+         colnames[0] = "FID\tIID";
+         for (int i = 0; i < k_out; i++) colnames[i + 1] = "PC" + std::to_string(i + 1);
+         fpca::save_text(Px.data(), N, k_out, colnames, rownames, projfile, precision);
+      }
+      if (save_meansd) {
+         if (meansd.empty()) {
+            meansd.resize((size_t)nsnps * 2);
+            fpca_ok(fpca_stats(ctx, meansd.data(), nullptr));
+         }
+         std::cout << timestamp() << "Writing mean + sd file " << meansdfile << std::endl;
+         std::vector<std::string> cn = {"SNP\tRefAllele", "Mean", "SD"};
+         std::vector<std::string> rn(snp_ids.size());
+         for (size_t i = 0; i < rn.size(); i++) rn[i] = snp_ids[i] + "\t" + ref_alleles[i];
+         if (rn.size() != nsnps) throw std::runtime_error("the .bim file has a different number of SNPs than the .bed");
+         fpca::save_text(meansd.data(), nsnps, 2, cn, rn, meansdfile, precision);
+      }
+      fpca_destroy(ctx);
+      std::cout << timestamp() << "Goodbye!" << std::endl;
+   } catch (std::exception &e) {
+      std::cerr << timestamp() << "Exception: " << e.what() << std::endl;
+      std::cerr << timestamp() << "Terminating" << std::endl;
+      return EXIT_FAILURE;
+   } catch (...) {
+      std::cerr << timestamp() << "Caught unknown exception, terminating " << std::endl;
+      return EXIT_FAILURE;
+   }
+   return EXIT_SUCCESS;
+}

@@ -104,6 +104,10 @@ struct fpca_ctx {
    int nranks = 1, rank = 0;
    fpca_allreduce_fn ar_fn = nullptr;
    void *ar_user = nullptr;
+   // live profiling (fpca_profile_begin/end)
+   std::vector<hipEvent_t> prof_ev;
+   int prof_used = 0;
+   bool prof_on = false;
 
    void ensure(double *&p, size_t &cap, size_t need)
    {
@@ -186,6 +190,7 @@ void ctx_free(fpca_ctx *c)
                    c->d_part,   c->d_stage, c->d_io_a, c->d_io_b, c->d_small};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
+   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
    if (c->stream) (void)hipStreamDestroy(c->stream);
    delete c;
 }
@@ -676,7 +681,9 @@ int fpca_apply_xxt_dev(fpca_ctx *ctx, const double *dB, int b, double *dY, void 
       if (!ctx || !dB || !dY) throw Error(FPCA_EINVAL, "bad argument to fpca_apply_xxt_dev");
       if (b != 16 && b != 32 && b != 48 && b != 64) throw Error(FPCA_EINVAL, "device blocks must be 16, 32, 48 or 64 wide");
       HIP_CHECK(hipSetDevice(ctx->device));
-      apply_xxt_dev(ctx, dB, b, dY, stream ? (hipStream_t)stream : ctx->stream, nullptr);
+      hipEvent_t *ev = nullptr;
+      if (ctx->prof_on && (size_t)(ctx->prof_used + 1) * 4 <= ctx->prof_ev.size()) ev = &ctx->prof_ev[(size_t)ctx->prof_used++ * 4];
+      apply_xxt_dev(ctx, dB, b, dY, stream ? (hipStream_t)stream : ctx->stream, ev);
    });
 }
 
@@ -856,6 +863,55 @@ int fpca_bench_apply(fpca_ctx *ctx, int b, int steps, int warmup, fpca_bench_res
       for (auto &e : ev) (void)hipEventDestroy(e);
       (void)hipFree(dB);
       (void)hipFree(dY);
+   });
+}
+
+int fpca_profile_begin(fpca_ctx *ctx, int max_steps)
+{
+   return guarded([&] {
+      if (!ctx || max_steps < 1) throw Error(FPCA_EINVAL, "bad argument to fpca_profile_begin");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      while (ctx->prof_ev.size() < (size_t)max_steps * 4) {
+         hipEvent_t e;
+         HIP_CHECK(hipEventCreate(&e));
+         ctx->prof_ev.push_back(e);
+      }
+      ctx->prof_used = 0;
+      ctx->prof_on = true;
+   });
+}
+
+int fpca_profile_end(fpca_ctx *ctx, int b, fpca_bench_result *res, int *nsteps)
+{
+   return guarded([&] {
+      if (!ctx || !res) throw Error(FPCA_EINVAL, "bad argument to fpca_profile_end");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      ctx->prof_on = false;
+      HIP_CHECK(hipDeviceSynchronize());
+      const int n = ctx->prof_used;
+      double t2 = 0, t3 = 0, ta = 0, tt = 0;
+      float ms = 0;
+      for (int i = 0; i < n; i++) {
+         hipEvent_t *e = &ctx->prof_ev[(size_t)i * 4];
+         HIP_CHECK(hipEventElapsedTime(&ms, e[0], e[1]));
+         t2 += ms;
+         HIP_CHECK(hipEventElapsedTime(&ms, e[1], e[2]));
+         t3 += ms;
+         HIP_CHECK(hipEventElapsedTime(&ms, e[2], e[3]));
+         ta += ms;
+         HIP_CHECK(hipEventElapsedTime(&ms, e[0], e[3]));
+         tt += ms;
+      }
+      std::memset(res, 0, sizeof(*res));
+      if (n > 0) {
+         res->ms_total = tt;
+         res->ms_xt = t2 / n;
+         res->ms_x = t3 / n;
+         res->ms_allreduce = ta / n;
+      }
+      res->flops_per_step = 4.0 * (double)ctx->N * (double)ctx->P_g * b;
+      res->packed_bytes_per_step = 2.0 * (double)ctx->np * (double)ctx->P_g;
+      if (nsteps) *nsteps = n;
    });
 }
 

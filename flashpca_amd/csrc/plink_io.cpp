@@ -1,0 +1,166 @@
+// plink_io.cpp -- see plink_io.hpp.  Behaviour (line handling, error texts, number format) follows the reference's
+// data.cpp:419-672 and util.h:69-108 so that files round-trip between the two programs.
+#include "plink_io.hpp"
+
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+
+namespace fpca {
+
+namespace {
+
+// every '\n'-terminated line (the reference's `if(!in.eof())` after getline drops an unterminated tail)
+std::vector<std::string> terminated_lines(std::ifstream &in)
+{
+   std::vector<std::string> lines;
+   std::string line;
+   while (std::getline(in, line)) {
+      if (in.eof()) break; // last chunk had no trailing newline
+      lines.push_back(line);
+   }
+   return lines;
+}
+
+std::vector<std::string> split_ws(const std::string &s)
+{
+   std::vector<std::string> tok;
+   std::stringstream ss(s);
+   std::string t;
+   while (ss >> t) tok.push_back(t);
+   return tok;
+}
+
+} // namespace
+
+TextMatrix read_text(const std::string &filename, unsigned firstcol, long nrows, unsigned skip)
+{
+   std::ifstream in(filename, std::ios::in);
+   if (!in) throw std::runtime_error("Error reading file '" + filename + "': " + strerror(errno));
+   std::vector<std::string> all = terminated_lines(in), lines;
+   unsigned line_num = 0;
+   for (auto &l : all) {
+      if (nrows == -1 || (long)line_num < nrows) {
+         if (line_num >= skip) lines.push_back(l);
+         line_num++;
+      }
+   }
+   TextMatrix M;
+   uint64_t numfields_1st = 0;
+   for (size_t i = 0; i < lines.size(); i++) {
+      std::vector<std::string> tokens = split_ws(lines[i]);
+      if (tokens.size() + 1 < firstcol + 1u && tokens.size() < firstcol)
+         throw std::runtime_error("Error reading file '" + filename + "': inconsistent number of columns");
+      const uint64_t numfields = tokens.size() - firstcol + 1;
+      if (i == 0) {
+         M.rows = lines.size();
+         M.cols = numfields;
+         M.v.assign(M.rows * M.cols, 0.0);
+         numfields_1st = numfields;
+      } else if (numfields != numfields_1st)
+         throw std::runtime_error("Error reading file '" + filename + "': inconsistent number of columns");
+      for (uint64_t j = 0; j < numfields; j++) {
+         const std::string &t = tokens[j + firstcol - 1];
+         char *end = nullptr;
+         errno = 0;
+         const double m = std::strtod(t.c_str(), &end);
+         if (*end != '\0' || errno != 0)
+            throw std::runtime_error("Error reading file '" + filename + "', line " + std::to_string(i + 1) + ": '" + t +
+                                     "' cannot be parsed as a number");
+         M.at(i, j) = m;
+      }
+   }
+   return M;
+}
+
+void read_plink_fam(const std::string &filename, std::vector<std::string> &fam_ids, std::vector<std::string> &indiv_ids)
+{
+   std::ifstream in(filename, std::ios::in);
+   if (!in) throw std::runtime_error("[Data::read_plink_fam] Error reading file " + filename);
+   for (auto &l : terminated_lines(in)) {
+      std::vector<std::string> tokens = split_ws(l);
+      if (tokens.size() < 2) throw std::runtime_error("[Data::read_plink_fam] malformed line in " + filename);
+      fam_ids.push_back(tokens[0]);
+      indiv_ids.push_back(tokens[1]);
+   }
+}
+
+void read_plink_bim(const std::string &filename, std::vector<std::string> &snp_ids, std::vector<std::string> &ref_alleles,
+                    std::vector<std::string> &alt_alleles)
+{
+   std::ifstream in(filename, std::ios::in);
+   if (!in) throw std::runtime_error("Error reading file " + filename);
+   std::vector<std::string> lines = terminated_lines(in);
+   for (size_t i = 0; i < lines.size(); i++) {
+      std::vector<std::string> tokens = split_ws(lines[i]);
+      if (tokens.size() < 6) throw std::runtime_error("Error reading file '" + filename + "', line " + std::to_string(i + 1) + ": too few columns");
+      snp_ids.push_back(tokens[1]);
+      ref_alleles.push_back(tokens[4]);
+      alt_alleles.push_back(tokens[5]);
+      char *end = nullptr;
+      errno = 0;
+      (void)std::strtol(tokens[3].c_str(), &end, 10);
+      if (*end != '\0' || errno != 0)
+         throw std::runtime_error("Error reading file '" + filename + "', line " + std::to_string(i + 1) + ": '" + tokens[3] +
+                                  "' cannot be parsed as a number");
+   }
+}
+
+std::vector<double> read_maf(const std::string &filename, const std::vector<std::string> &snp_ids)
+{
+   std::ifstream in(filename, std::ios::in);
+   if (!in) throw std::runtime_error("Error reading file '" + filename + "': " + strerror(errno));
+   std::vector<std::string> lines = terminated_lines(in);
+   if (!lines.empty()) lines.erase(lines.begin()); // header of the .frq
+   if (lines.size() != snp_ids.size())
+      throw std::runtime_error("Error number of SNPs in '" + filename + "': different number of SNPs than in the bim file'");
+   std::vector<double> maf(lines.size());
+   for (size_t i = 0; i < lines.size(); i++) {
+      std::vector<std::string> tokens = split_ws(lines[i]);
+      if (tokens.size() != 6) throw std::runtime_error("Error reading file '" + filename + "': inconsistent number of columns");
+      if (tokens[1] != snp_ids[i])
+         throw std::runtime_error("Error reading file '" + filename + "': inconsistent SNP id at row':" + std::to_string(i));
+      char *end = nullptr;
+      errno = 0;
+      maf[i] = std::strtod(tokens[4].c_str(), &end);
+      if (*end != '\0' || errno != 0)
+         throw std::runtime_error("Error reading file '" + filename + "', line " + std::to_string(i + 1) + ": '" + tokens[4] +
+                                  "' cannot be parsed as a number");
+   }
+   return maf;
+}
+
+bool save_text(const double *M, uint64_t rows, uint64_t cols, const std::vector<std::string> &colnames,
+               const std::vector<std::string> &rownames, const std::string &filename, unsigned precision)
+{
+   std::ofstream out(filename, std::ofstream::out);
+   out << std::setprecision(precision);
+   if (!out) {
+      std::cerr << "Error while saving to file " << filename << ":" << strerror(errno) << std::endl;
+      return false;
+   }
+   for (size_t i = 0; i < colnames.size(); i++) {
+      out << colnames[i];
+      if (i == colnames.size() - 1)
+         out << "\n";
+      else
+         out << "\t";
+   }
+   for (uint64_t j = 0; j < rows; j++) {
+      if (!rownames.empty()) out << rownames[j] << "\t";
+      for (uint64_t c = 0; c < cols; c++) {
+         if (c) out << "\t";
+         out << M[j + c * rows];
+      }
+      out << "\n";
+   }
+   out.close();
+   return true;
+}
+
+} // namespace fpca

@@ -193,6 +193,12 @@ typedef struct fpca_bench_result {
    double packed_bytes_per_step;    /* 2 ceil(N/4) P_g */
 } fpca_bench_result;
 int fpca_bench_apply(fpca_ctx *ctx, int b, int steps, int warmup, fpca_bench_result *res);
+/* Live profiling of caller-driven applies: between fpca_profile_begin and fpca_profile_end every
+ * fpca_apply_xxt_dev call (up to max_steps of them) records HIP events on its stream around K2, K3 and the
+ * all-reduce; fpca_profile_end synchronises and returns the per-step averages over the recorded calls
+ * (ms_total = sum of all recorded steps; *nsteps = number recorded). */
+int fpca_profile_begin(fpca_ctx *ctx, int max_steps);
+int fpca_profile_end(fpca_ctx *ctx, int b, fpca_bench_result *res, int *nsteps);
 /* time the one-off statistics pass (K1) the same way: milliseconds per launch, bytes read */
 int fpca_bench_stats(fpca_ctx *ctx, int reps, double *ms_per_launch, double *bytes_per_launch);
 
