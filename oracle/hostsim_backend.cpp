@@ -14,6 +14,7 @@
 #include "../flashpca_amd/csrc/backend.hpp"
 #include "../flashpca_amd/csrc/common.hpp"
 #include "../flashpca_amd/csrc/pca_driver.hpp"
+#include "../flashpca_amd/csrc/plink_io.hpp"
 #include "../flashpca_amd/csrc/solver.hpp"
 #include "../flashpca_amd/csrc/symeig.hpp"
 #include "fpca_oracle.h"
@@ -167,6 +168,73 @@ int hostsim_pca(orc_data *d, int ndim, int blockvec, int maxiter, double tol, in
    } catch (const std::exception &e) {
       std::fprintf(stderr, "hostsim_pca: %s\n", e.what());
       return -3;
+   }
+}
+
+/* the CLI's text writers / readers (plink_io.cpp) exposed for CPU unit tests */
+int hostsim_save_text(const double *M, uint64_t rows, uint64_t cols, const char *colnames_tab, const char *rownames_nl,
+                      const char *filename, unsigned precision)
+{
+   try {
+      std::vector<std::string> cn, rn;
+      auto split = [](const char *s, char sep, std::vector<std::string> &out) {
+         if (!s || !*s) return;
+         std::string cur;
+         for (const char *p = s; *p; p++) {
+            if (*p == sep) {
+               out.push_back(cur);
+               cur.clear();
+            } else
+               cur += *p;
+         }
+         out.push_back(cur);
+      };
+      split(colnames_tab, '|', cn);
+      split(rownames_nl, '|', rn);
+      return fpca::save_text(M, rows, cols, cn, rn, filename, precision) ? 0 : 1;
+   } catch (const std::exception &e) {
+      std::fprintf(stderr, "hostsim_save_text: %s\n", e.what());
+      return -1;
+   }
+}
+
+/* returns rows, writes cols; values copied column-major into out (capacity cap doubles); -1 + message on error */
+long hostsim_read_text(const char *filename, unsigned firstcol, long nrows, unsigned skip, double *out, uint64_t cap,
+                       uint64_t *cols, char *err, int errlen)
+{
+   try {
+      fpca::TextMatrix M = fpca::read_text(filename, firstcol, nrows, skip);
+      if (cols) *cols = M.cols;
+      if (M.v.size() > cap) return -2;
+      std::memcpy(out, M.v.data(), M.v.size() * sizeof(double));
+      return (long)M.rows;
+   } catch (const std::exception &e) {
+      if (err) std::snprintf(err, errlen, "%s", e.what());
+      return -1;
+   }
+}
+
+long hostsim_read_fam(const char *filename, char *err, int errlen)
+{
+   try {
+      std::vector<std::string> a, b;
+      fpca::read_plink_fam(filename, a, b);
+      return (long)a.size();
+   } catch (const std::exception &e) {
+      if (err) std::snprintf(err, errlen, "%s", e.what());
+      return -1;
+   }
+}
+
+long hostsim_read_bim(const char *filename, char *err, int errlen)
+{
+   try {
+      std::vector<std::string> a, b, c;
+      fpca::read_plink_bim(filename, a, b, c);
+      return (long)a.size();
+   } catch (const std::exception &e) {
+      if (err) std::snprintf(err, errlen, "%s", e.what());
+      return -1;
    }
 }
 

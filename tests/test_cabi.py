@@ -1,0 +1,82 @@
+"""CPU tests of the drop-in boundary: libfpca.so loads, exports every symbol include/fpca.h declares, and refuses to
+run without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "fpca.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(fpca_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(n for n in names if n not in ("fpca_allreduce_fn",)))
+
+
+def test_header_is_plain_c():
+    """The header must compile as C (extern "C", plain pointers and sizes, no C++/torch types)."""
+    out = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "fpca.h")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    import flashpca_amd
+    from flashpca_amd import _lib
+
+    names = declared_functions()
+    assert len(names) >= 25
+    L = C.CDLL(built_lib)
+    for n in names:
+        assert hasattr(L, n), "libfpca.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "flashpca_amd/_lib.py has no signature for %s" % n
+    assert flashpca_amd.lib().fpca_version().decode() == "0.1.0"
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under flashpca_amd/ (nor the CLI/lib link lines) may reference it."""
+    bad = []
+    for dp, dn, fn in os.walk(os.path.join(ROOT, "flashpca_amd")):
+        if "_build" in dp or "__pycache__" in dp:
+            continue
+        for f in fn:
+            if not f.endswith((".py", ".hpp", ".cpp", ".hip", ".h")) and f != "Makefile":
+                continue
+            txt = open(os.path.join(dp, f), errors="replace").read()
+            code = "\n".join(l for l in txt.splitlines() if not l.lstrip().startswith(("//", "#", "*", "/*")))
+            if re.search(r"fpca_oracle|orc_[a-z_]+\(|from oracle|import oracle|libfpca_hostsim|hostsim_", code):
+                bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    out = subprocess.run(["ldd", os.path.join(ROOT, "flashpca_amd", "_build", "libfpca.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "hostsim" not in out
+
+
+def test_no_cpu_fallback(built_lib):
+    """Without a usable gfx950 device every constructor fails loudly with FPCA_ENODEVICE."""
+    import flashpca_amd as fp
+
+    if fp.lib().fpca_device_count() > 0:
+        pytest.skip("a GPU is present")
+    packed = np.zeros((4, 3), dtype=np.uint8)
+    with pytest.raises(fp.FpcaError) as e:
+        fp.Context.from_packed(packed, 10, 4)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+    with pytest.raises(fp.FpcaError):
+        fp.Context.synthetic(100, 10)
+    with pytest.raises(fp.FpcaError):
+        fp.Context.from_bed(os.path.join(ROOT, "tests", "golden", "data_chr1.bed"), 957)
+
+
+def test_default_opts_match_reference_cli(built_lib):
+    import flashpca_amd as fp
+    from flashpca_amd._lib import PcaOpts
+
+    o = PcaOpts()
+    fp.lib().fpca_pca_default_opts(C.byref(o))
+    # flashpca.cpp:325 (ndim 10), :426 (maxiter 500), :440 (tol 1e-6), :484 (div p), :276 (seed 1)
+    assert (o.ndim, o.maxiter, o.tol, o.divisor, o.seed) == (10, 500, 1e-6, 2, 1)

@@ -1,0 +1,93 @@
+"""The flashpca drop-in CLI (flashpca_amd/csrc/cli_main.cpp).  CPU part: flag handling and exit codes, which mirror
+flashpca.cpp:95-560.  GPU part: end-to-end run on the bundled fileset, outputs compared with the goldens."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "flashpca_amd", "_build", "flashpca")
+DATA = os.path.join(ROOT, "tests", "golden", "data_chr1")
+
+
+def run(args, cwd=None):
+    return subprocess.run([CLI] + args, capture_output=True, text=True, cwd=cwd)
+
+
+def test_cli_flag_errors(built_lib):
+    r = run(["--version"])
+    assert r.returncode == 0 and "flashpca 2.1" in r.stderr
+    r = run(["--help"])
+    assert r.returncode == 0 and "--bfile" in r.stderr and "--ndim" in r.stderr
+    r = run(["--nosuchflag"])  # flashpca.cpp:100-106: parse errors exit with status 0
+    assert r.returncode == 0 and "Use --help to get more help" in r.stderr
+    r = run(["--notime"])
+    assert r.returncode == 1 and "you must specify either --bfile or --bed / --fam / --bim" in r.stderr
+    for extra, msg in ((["--ndim", "0"], "--ndim can't be less than 1"),
+                       (["--standx", "sd"], "unknown standardization method (--standx): sd"),
+                       (["--div", "q"], "unknown divisor (--div): q"),
+                       (["--tol", "0"], "--tol can't be zero or negative"),
+                       (["--maxiter", "0"], "--maxiter can't be less than 1"),
+                       (["--precision", "1"], "output --precision too low"),
+                       (["--memory", "10", "--blocksize", "5"], "cannot specify both --memory and --blocksize"),
+                       (["--check", "--project"], "conflicting modes requested"),
+                       (["--project"], "SNP-loadings must be specified using --inload"),
+                       (["--scca"], "outside the PCA path")):
+        r = run(["--bfile", DATA, "--notime"] + extra)
+        assert r.returncode == 1, (extra, r.stderr)
+        assert msg in r.stderr, (extra, r.stderr)
+    r = run(["--bfile", "/nonexistent/prefix", "--notime"])
+    assert r.returncode == 1 and "Exception: Error reading file" in r.stderr and "Terminating" in r.stderr
+    assert r.stdout.startswith("arguments: flashpca ")
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(tmp_path, built_lib):
+    g = json.load(open(DATA.replace("data_chr1", "golden_data_chr1_binom2.json")))
+    r = run(["--bfile", DATA, "--ndim", "10", "--outload", "loadings.txt", "--outmeansd", "meansd.txt", "--notime"], cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[1].startswith("Start flashpca (version 2.1")
+    for must in ("PCA begin", "PCA done", "Writing 10 eigenvalues to file eigenvalues.txt",
+                 "Writing 10 eigenvectors to file eigenvectors.txt", "Writing 10 PCs to file pcs.txt",
+                 "Writing 10 proportion variance explained to file pve.txt", "Goodbye!"):
+        assert must in lines, must
+    ev = np.loadtxt(tmp_path / "eigenvalues.txt")
+    assert np.allclose(ev, np.array(g["eigenvalues_div_p"])[:10], rtol=2e-6)  # 7 significant digits
+    expect = ["%.7g" % v for v in g["eigenvalues_div_p"][:10]]
+    assert open(tmp_path / "eigenvalues.txt").read().split() == expect
+    assert open(tmp_path / "pve.txt").read().split() == ["%.7g" % v for v in g["pve"][:10]]
+    vec = open(tmp_path / "eigenvectors.txt").read().splitlines()
+    assert vec[0] == "FID\tIID\t" + "\t".join("U%d" % i for i in range(1, 11))
+    assert len(vec) == 958 and vec[1].split("\t")[:2] == ["2431", "NA19916"]
+    pcs = open(tmp_path / "pcs.txt").read().splitlines()
+    assert pcs[0] == "FID\tIID\t" + "\t".join("PC%d" % i for i in range(1, 11))
+    U = np.array([l.split("\t")[2:] for l in vec[1:]], dtype=float)
+    PC = np.array([l.split("\t")[2:] for l in pcs[1:]], dtype=float)
+    assert np.allclose(PC, U * np.sqrt(ev), rtol=1e-5, atol=1e-7)
+    U5 = np.array(g["U_first5"]).T
+    for c in range(5):
+        assert abs(abs(U5[:, c] @ U[:, c]) - 1) < 1e-5
+    load = open(tmp_path / "loadings.txt").read().splitlines()
+    assert load[0] == "SNP\tRefAllele\t" + "\t".join("V%d" % i for i in range(1, 11)) and len(load) == 1130
+    assert load[1].split("\t")[:2] == ["rs4970383", "A"]
+    ms = open(tmp_path / "meansd.txt").read().splitlines()
+    assert ms[0] == "SNP\tRefAllele\tMean\tSD" and len(ms) == 1130
+    assert ms[1].split("\t")[2] == "%.7g" % g["mean_first8"][0]
+    # --check re-reads eigenvectors/eigenvalues (randompca.cpp:627-661); 7-digit files -> mse ~1e-12
+    r = run(["--bfile", DATA, "--check", "--notime"], cwd=tmp_path)
+    assert r.returncode == 0 and "Mean squared error:" in r.stdout
+    mse = float(r.stdout.split("Mean squared error: ")[1].split(",")[0])
+    assert mse < 1e-8
+    # --project with the just-written loadings and mean/sd reproduces the PCs (flashpcaR test_project.R:12-47, tol 1e-5)
+    r = run(["--bfile", DATA, "--project", "--inload", "loadings.txt", "--inmeansd", "meansd.txt", "--outproj", "proj.txt", "--notime"], cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    pr = open(tmp_path / "proj.txt").read().splitlines()
+    assert pr[0] == pcs[0]
+    PR = np.array([l.split("\t")[2:] for l in pr[1:]], dtype=float)
+    assert np.max(np.abs(PR - PC)) < 1e-4
+    # ndim limit (flashpca.cpp:623-633)
+    r = run(["--bfile", DATA, "--ndim", "500", "--notime"], cwd=tmp_path)
+    assert r.returncode == 1 and "You asked for 500 dimensions, but only 478allowed" in r.stderr

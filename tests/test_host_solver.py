@@ -1,0 +1,147 @@
+"""CPU tests of the PRODUCT's host code (flashpca_amd/csrc/solver.cpp, pca_driver.cpp, symeig.cpp, plink_io.cpp)
+compiled against the host-sim backend (oracle/hostsim_backend.cpp) -- no GPU needed.  The GPU tests run the same
+sources inside libfpca.so against the HIP backend."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+HS = None
+
+
+def hostsim():
+    global HS
+    if HS is None:
+        O.build()
+        L = C.CDLL(os.path.join(O.HERE, "_build", "libfpca_hostsim.so"))
+        L.hostsim_pca.restype = C.c_int
+        L.hostsim_pca.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_int,
+                                  C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.hostsim_symeig.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.hostsim_save_text.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint]
+        L.hostsim_read_text.restype = C.c_long
+        L.hostsim_read_text.argtypes = [C.c_char_p, C.c_uint, C.c_long, C.c_uint, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                        C.c_char_p, C.c_int]
+        L.hostsim_read_fam.restype = C.c_long
+        L.hostsim_read_fam.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.hostsim_read_bim.restype = C.c_long
+        L.hostsim_read_bim.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        HS = L
+    return HS
+
+
+def run_pca(d, k, blockvec=0, tol=1e-6, maxiter=500, div=2, max_blocks=0, seed=1, allreduce=None, P_total=0):
+    L = hostsim()
+    N = d.N
+    U = np.zeros((N, k), order="F")
+    dv = np.zeros(k)
+    Px = np.zeros((N, k), order="F")
+    pve = np.zeros(k)
+    tr = C.c_double()
+    info = (C.c_int * 4)()
+    rc = L.hostsim_pca(d.h, k, blockvec, maxiter, tol, div, max_blocks, seed, 0, P_total, allreduce, None, U.ctypes.data,
+                       dv.ctypes.data, Px.ctypes.data, pve.ctypes.data, C.byref(tr), info)
+    return rc, dict(U=U, d=dv, Px=Px, pve=pve, trace=tr.value, converged=info[0], applies=info[1], restarts=info[2], b=info[3])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 16, 33, 64, 129, 200])
+def test_symeig(n):
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n))
+    A = A + A.T
+    if n > 4:
+        A[2, :] = A[:, 2] = 0  # a decoupled row exercises the zero-Householder branch
+    w = np.zeros(n)
+    Z = np.asfortranarray(A.copy())
+    assert hostsim().hostsim_symeig(n, Z.ctypes.data, w.ctypes.data) == 0
+    wr = np.linalg.eigvalsh(A)[::-1]
+    sc = max(1.0, np.abs(wr).max())
+    assert np.max(np.abs(w - wr)) < 1e-12 * sc * n
+    assert np.max(np.abs(A @ Z - Z * w)) < 1e-12 * sc * n
+    assert np.max(np.abs(Z.T @ Z - np.eye(n))) < 1e-12 * n
+
+
+@pytest.mark.parametrize("name,k,kw", [("hapmap3_data", 10, {}), ("data_chr1", 10, {}), ("data_chr1", 50, {}),
+                                       ("data_chr1", 10, dict(max_blocks=3)), ("data_chr1", 20, dict(blockvec=48)),
+                                       ("data_chr1", 1, {}), ("data_chr1", 16, dict(blockvec=16))])
+def test_block_krylov_schur_vs_golden(golden_dir, name, k, kw):
+    g = json.load(open(os.path.join(golden_dir, "golden_%s_binom2.json" % name)))
+    N = O.count_fam_rows(os.path.join(golden_dir, name + ".fam"))
+    d = O.OracleData(os.path.join(golden_dir, name + ".bed"), N, "binom2")
+    rc, r = run_pca(d, k, **kw)
+    assert rc == 0 and r["converged"] == 1
+    ev = np.array(g["eigenvalues_div_p"])[:k]
+    assert np.max(np.abs(r["d"] - ev) / ev) < 1e-9
+    assert np.max(np.abs(r["pve"] - np.array(g["pve"])[:k])) < 1e-11
+    assert np.max(np.abs(r["U"].T @ r["U"] - np.eye(k))) < 1e-10
+    U5 = np.array(g["U_first5"]).T
+    for c in range(min(5, k)):
+        assert abs(abs(U5[:, c] @ r["U"][:, c]) - 1) < 1e-8
+    if kw.get("max_blocks"):
+        assert r["restarts"] >= 1
+    # far fewer passes over the matrix than the reference's single-vector IRLM (58 / 245 operator applications)
+    assert r["applies"] <= 40
+
+
+def test_not_converged_is_reported(golden_dir):
+    N = O.count_fam_rows(os.path.join(golden_dir, "data_chr1.fam"))
+    d = O.OracleData(os.path.join(golden_dir, "data_chr1.bed"), N, "binom2")
+    rc, r = run_pca(d, 10, maxiter=2)
+    assert rc == -5 and r["converged"] == 0 and r["applies"] == 2  # FPCA_ENOTCONVERGED (randompca.cpp:212-217)
+    rc, r = run_pca(d, 10, blockvec=24)
+    assert rc == -1  # FPCA_EINVAL
+
+
+def test_low_rank_matrix_deflation():
+    """rank(X) < block width: the Krylov space closes after one step; the solver must deflate, not blow up."""
+    rng = np.random.default_rng(3)
+    N, P = 400, 6  # 6 SNPs -> rank <= 6 < b = 16
+    packed = rng.integers(0, 256, size=(P, (N + 3) // 4), dtype=np.uint8)
+    d = O.OracleData(packed=packed, N=N, P=P, stand="binom2")
+    X = d.dense()
+    w = np.linalg.eigvalsh(X @ X.T)[::-1]
+    rc, r = run_pca(d, 2, div=0)
+    assert rc == 0
+    assert np.max(np.abs(r["d"] - w[:2]) / w[:2]) < 1e-9
+
+
+def test_text_io_roundtrip(tmp_path):
+    """save_text (util.h:69-108) format and read_text (data.cpp:504-586) semantics."""
+    L = hostsim()
+    M = np.asfortranarray(np.array([[26.467988137205, -0.0361308123], [1e-5, 123456789.0], [0.5, -2.0]]))
+    f = str(tmp_path / "m.txt")
+    assert L.hostsim_save_text(M.ctypes.data, 3, 2, b"FID\tIID|U1|U2", b"f1\ti1|f2\ti2|f3\ti3", f.encode(), 7) == 0
+    txt = open(f).read()
+    assert txt == "FID\tIID\tU1\tU2\nf1\ti1\t26.46799\t-0.03613081\nf2\ti2\t1e-05\t1.234568e+08\nf3\ti3\t0.5\t-2\n"
+    out = np.zeros(6)
+    cols = C.c_uint64()
+    err = C.create_string_buffer(256)
+    rows = L.hostsim_read_text(f.encode(), 3, -1, 1, out.ctypes.data, 6, C.byref(cols), err, 256)
+    assert rows == 3 and cols.value == 2
+    assert np.allclose(out.reshape(2, 3).T, M, rtol=1e-6)
+    # eigenvalue-style file: no header, no row names, one value per line
+    v = np.asfortranarray(np.array([[26.467988137205], [2.31179038]]))
+    assert L.hostsim_save_text(v.ctypes.data, 2, 1, b"", b"", f.encode(), 7) == 0
+    assert open(f).read() == "26.46799\n2.31179\n"
+    # an unterminated last line is dropped (data.cpp:526); a non-numeric token is an error with the reference's text
+    open(f, "w").write("1 2\n3 4\n5 6")
+    rows = L.hostsim_read_text(f.encode(), 1, -1, 0, out.ctypes.data, 6, C.byref(cols), err, 256)
+    assert rows == 2 and cols.value == 2
+    open(f, "w").write("1 2\n3 x\n")
+    assert L.hostsim_read_text(f.encode(), 1, -1, 0, out.ctypes.data, 6, C.byref(cols), err, 256) == -1
+    assert b"cannot be parsed as a number" in err.value
+    assert L.hostsim_read_text(b"/nonexistent", 1, -1, 0, out.ctypes.data, 6, C.byref(cols), err, 256) == -1
+    assert b"Error reading file" in err.value
+
+
+def test_fam_bim_readers(golden_dir):
+    L = hostsim()
+    err = C.create_string_buffer(256)
+    assert L.hostsim_read_fam(os.path.join(golden_dir, "data_chr1.fam").encode(), err, 256) == 957
+    assert L.hostsim_read_bim(os.path.join(golden_dir, "data_chr1.bim").encode(), err, 256) == 1129
+    assert L.hostsim_read_fam(b"/nonexistent.fam", err, 256) == -1

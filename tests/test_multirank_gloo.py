@@ -1,0 +1,55 @@
+"""world_size-2 (and 3) CPU test of the SNP-sharded path over torch.distributed/gloo: shards + all-reduce of the N x b
+product give the single-rank answer (svdwide.cpp:48-62 sums SNP blocks the same way)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pca_matches_golden(golden_dir, tmp_path, world):
+    name, k = "data_chr1", 10
+    g = json.load(open(os.path.join(golden_dir, "golden_%s_binom2.json" % name)))
+    port = free_port()
+    out = str(tmp_path / "res.json")
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"),
+                                       os.path.join(golden_dir, name + ".bed"), os.path.join(golden_dir, name + ".fam"),
+                                       str(k), out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    r = json.load(open(out))
+    assert r["rc"] == 0 and r["same"]
+    ev = np.array(g["eigenvalues_div_p"])[:k]
+    assert np.max(np.abs(np.array(r["d"]) - ev) / ev) < 1e-9  # divisor uses the TOTAL SNP count
+    assert abs(r["trace"] * r["P_total"] - g["trace_raw"]) <= 1e-12 * g["trace_raw"]  # scalar all-reduce of the trace
+    assert np.max(np.abs(np.array(r["pve"]) - np.array(g["pve"])[:k])) < 1e-11
+    U0 = np.array(g["U_first5"])[0]
+    assert abs(abs(U0 @ np.array(r["U0"])) - 1) < 1e-8
+    # exactly one all-reduce of N x b per block apply (+ one scalar for the trace): no other data-path collective
+    assert r["allreduce_calls"] == r["applies"] + 1
+    assert r["allreduce_elems"] == r["applies"] * g["N"] * r["b"] + 1
