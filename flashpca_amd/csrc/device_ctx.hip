@@ -957,4 +957,13 @@ int fpca_debug_mfma_probe(const double *A, const double *B, double *D)
    });
 }
 
+// diagnostic: measured issue-rate ceiling of v_mfma_f64_16x16x4_f64 (TFLOP/s) with 1..8 waves per SIMD
+int fpca_debug_mfma_peak(int waves_per_simd, int iters, double *tflops)
+{
+   return guarded([&] {
+      if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 10 || !tflops) throw Error(FPCA_EINVAL, "bad argument");
+      *tflops = kern::mfma_peak_tflops(waves_per_simd, iters, nullptr);
+   });
+}
+
 } // extern "C"

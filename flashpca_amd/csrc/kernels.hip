@@ -17,6 +17,9 @@
 // A wave is 64 lanes; a workgroup is 4 waves (one per SIMD); 2 workgroups per CU hide the staging.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 #include "synth.hpp"
@@ -189,7 +192,7 @@ template <int NT> struct XtCfg {
    static constexpr int KC = (NT <= 2) ? 128 : 64; // samples per LDS chunk: keeps the prefetch registers <= 32
 };
 
-template <int NT>
+template <int NT, bool GL /* decode through an LDS-resident table (gather) instead of register selects */>
 __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ packed, size_t pitch,
                                                   const double *__restrict__ lut, const double *__restrict__ B,
                                                   double *__restrict__ Tpart, uint64_t P_pad, int chunks_total,
@@ -202,10 +205,16 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
    constexpr int NLOAD = KC * b * 8 / (256 * 16); // 16-byte pieces of the B tile per thread
    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
    double *sB = reinterpret_cast<double *>(smem_raw); // [KC][b]
+   double *sLut = sB + KC * b;                        // [XT_TILE][4] (GL only)
 
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int li = lane & 15, kq = lane >> 4;
    const uint64_t snp0 = (uint64_t)blockIdx.x * XT_TILE + (uint64_t)wave * 64;
+   if (GL) { // one SNP's 4-entry table per thread; visible after the first barrier of the chunk loop
+      const d2 *lsrc = reinterpret_cast<const d2 *>(lut + ((uint64_t)blockIdx.x * XT_TILE + tid) * 4);
+      reinterpret_cast<d2 *>(sLut)[tid * 2] = lsrc[0];
+      reinterpret_cast<d2 *>(sLut)[tid * 2 + 1] = lsrc[1];
+   }
    const int c_begin = blockIdx.y * chunks_per_split;
    int c_end = c_begin + chunks_per_split;
    if (c_end > chunks_total) c_end = chunks_total;
@@ -215,10 +224,13 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
 #pragma unroll
    for (int m = 0; m < MT; m++) {
       const uint64_t snp = snp0 + m * 16 + li;
-      const double *lp = lut + snp * 4;
-      l0[m] = lp[0];
-      l2[m] = lp[2];
-      l3[m] = lp[3];
+      if (!GL) {
+         const double *lp = lut + snp * 4;
+         l0[m] = lp[0];
+         l2[m] = lp[2];
+         l3[m] = lp[3];
+      } else
+         l0[m] = l2[m] = l3[m] = 0.0;
       rowp[m] = packed + snp * pitch + kq * (KC / 16); // lane group kq owns samples kq*KC/4 .. +KC/4 of a chunk
    }
 
@@ -267,7 +279,8 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
             for (int nt = 0; nt < NT; nt++) bv[nt] = sB_lane[(size_t)(16 * half + t) * b + nt * 16];
 #pragma unroll
             for (int m = 0; m < MT; m++) {
-               const double a = lut_sel((pk[m][half] >> (2 * t)) & 3u, l0[m], l2[m], l3[m]);
+               const uint32_t code = (pk[m][half] >> (2 * t)) & 3u;
+               const double a = GL ? sLut[(wave * 64 + m * 16 + li) * 4 + code] : lut_sel(code, l0[m], l2[m], l3[m]);
 #pragma unroll
                for (int nt = 0; nt < NT; nt++) acc[m][nt] = FPCA_MFMA(a, bv[nt], acc[m][nt]);
             }
@@ -288,6 +301,12 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
          }
 }
 
+static int env_int(const char *name, int dflt)
+{
+   const char *e = getenv(name);
+   return e && *e ? atoi(e) : dflt;
+}
+
 static int pick_splits(uint64_t tiles, uint64_t chunks, int min_chunks, int max_splits)
 {
    const uint64_t slots = 512; // 256 CUs x 2 resident workgroups
@@ -298,7 +317,9 @@ static int pick_splits(uint64_t tiles, uint64_t chunks, int min_chunks, int max_
       if (s > 1 && cps < (uint64_t)min_chunks) break;
       uint64_t seff = (chunks + cps - 1) / cps;
       uint64_t rounds = (tiles * seff + slots - 1) / slots;
-      uint64_t t = rounds * cps * 64 + seff; // ~time in chunk units, small penalty per extra partial
+      // time in 1/64 chunk units: every workgroup pays ~2 chunks of fill/drain on top of its cps chunks, and
+      // every extra partial costs a write + a read of the output in the combine pass
+      uint64_t t = rounds * (cps + 2) * 64 + (seff > 1 ? seff * 24 : 0);
       if (t < best_t) {
          best_t = t;
          best = (int)seff;
@@ -310,26 +331,39 @@ static int pick_splits(uint64_t tiles, uint64_t chunks, int min_chunks, int max_
 int xt_b_splits(uint64_t N_pad, uint64_t P_pad, int b)
 {
    const int kc = b <= 32 ? 128 : 64;
+   static const int forced = env_int("FPCA_XT_SPLITS", 0);
+   if (forced > 0) return (int)std::min<uint64_t>(forced, N_pad / kc);
    return pick_splits(P_pad / XT_TILE, N_pad / kc, 4, 64);
+}
+
+template <int NT, bool GL>
+static void launch_xt_b2(const uint8_t *packed, size_t pitch, const double *lut, const double *B, double *Tpart,
+                         uint64_t N_pad, uint64_t P_pad, int nsplit, hipStream_t stream)
+{
+   constexpr int KC = XtCfg<NT>::KC;
+   const int chunks_total = (int)(N_pad / KC);
+   const int cps = (chunks_total + nsplit - 1) / nsplit;
+   const size_t smem = (size_t)KC * 16 * NT * sizeof(double) + (GL ? XT_TILE * 4 * sizeof(double) : 0);
+   static bool attr_set = false;
+   if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xt_b<NT, GL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+   }
+   dim3 grid((unsigned)(P_pad / XT_TILE), (unsigned)nsplit);
+   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xt_b<NT, GL>), grid, dim3(256), smem, stream, packed, pitch, lut, B, Tpart, P_pad,
+                      chunks_total, cps);
+   HIP_CHECK_LAUNCH();
 }
 
 template <int NT>
 static void launch_xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *B, double *Tpart,
                         uint64_t N_pad, uint64_t P_pad, int nsplit, hipStream_t stream)
 {
-   constexpr int KC = XtCfg<NT>::KC;
-   const int chunks_total = (int)(N_pad / KC);
-   const int cps = (chunks_total + nsplit - 1) / nsplit;
-   const size_t smem = (size_t)KC * 16 * NT * sizeof(double);
-   static bool attr_set = false;
-   if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xt_b<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      attr_set = true;
-   }
-   dim3 grid((unsigned)(P_pad / XT_TILE), (unsigned)nsplit);
-   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xt_b<NT>), grid, dim3(256), smem, stream, packed, pitch, lut, B, Tpart, P_pad,
-                      chunks_total, cps);
-   HIP_CHECK_LAUNCH();
+   static const int variant = env_int("FPCA_XT_VARIANT", 1); // 1 = LDS-table gather (default, faster), 0 = register selects
+   if (variant == 1)
+      launch_xt_b2<NT, true>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream);
+   else
+      launch_xt_b2<NT, false>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream);
 }
 
 void xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *B, double *Tpart, uint64_t N_pad,
@@ -454,6 +488,8 @@ static inline int x_t_mt(int b) { return b <= 32 ? 8 : 4; }
 
 int x_t_splits(uint64_t N_pad, uint64_t P_pad, int b)
 {
+   static const int forced = env_int("FPCA_X_SPLITS", 0);
+   if (forced > 0) return (int)std::min<uint64_t>(forced, P_pad / X_KC);
    return pick_splits(N_pad / (64 * x_t_mt(b)), P_pad / X_KC, 4, 64);
 }
 
@@ -811,6 +847,47 @@ void mfma_layout_probe(const double *A, const double *B, double *D, hipStream_t 
 {
    hipLaunchKernelGGL(k_mfma_layout_probe, dim3(1), dim3(64), 0, stream, A, B, D);
    HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// micro-benchmark: issue-rate ceiling of v_mfma_f64_16x16x4_f64 on this chip (8 independent accumulators per
+// wave, no memory traffic in the loop).  Used to quote the attainable FP64 MFMA rate next to the datasheet peak.
+__global__ __launch_bounds__(256) void k_mfma_peak(double *out, int iters)
+{
+   d4 acc[8];
+#pragma unroll
+   for (int i = 0; i < 8; i++) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+   double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+   for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc[i] = FPCA_MFMA(a, b, acc[i]);
+   }
+   double s = 0;
+#pragma unroll
+   for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+   if (s == 12345.678) out[0] = s; // keep the chain alive
+}
+
+double mfma_peak_tflops(int waves_per_simd, int iters, hipStream_t stream)
+{
+   double *d = nullptr;
+   if (hipMalloc(&d, 8) != hipSuccess) throw Error(-3, "hipMalloc failed");
+   const int blocks = 256 * waves_per_simd; // one 256-thread workgroup = one wave per SIMD of a CU
+   hipEvent_t e0, e1;
+   (void)hipEventCreate(&e0);
+   (void)hipEventCreate(&e1);
+   hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, stream, d, iters / 10);
+   (void)hipEventRecord(e0, stream);
+   hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, stream, d, iters);
+   (void)hipEventRecord(e1, stream);
+   (void)hipEventSynchronize(e1);
+   float ms = 0;
+   (void)hipEventElapsedTime(&ms, e0, e1);
+   (void)hipEventDestroy(e0);
+   (void)hipEventDestroy(e1);
+   (void)hipFree(d);
+   const double flops = (double)blocks * 4 /*waves*/ * (double)iters * 8 * 2048.0;
+   return flops / (ms * 1e-3) / 1e12;
 }
 
 } // namespace kern

@@ -60,5 +60,8 @@ void synth_generate(uint8_t *packed, size_t pitch, uint64_t N, uint64_t snp_begi
 // diagnostic: D(16x16) = A(16x4) B(4x16) through v_mfma_f64_16x16x4_f64 with this file's operand mapping
 void mfma_layout_probe(const double *A, const double *B, double *D, hipStream_t stream);
 
+// issue-rate ceiling of the FP64 MFMA (TFLOP/s) with `waves_per_simd` resident waves per SIMD
+double mfma_peak_tflops(int waves_per_simd, int iters, hipStream_t stream);
+
 } // namespace kern
 } // namespace fpca
