@@ -53,6 +53,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FPCA_BENCH_ONE_GPU"):
+        local_rank = 0
     if args.gpus != world:
         if args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
@@ -64,7 +66,13 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # FPCA_BENCH_BACKEND=gloo lets two ranks share one GPU for a plumbing dry-run (the native RCCL communicator
+        # then refuses the duplicate device and the torch.distributed fallback is exercised)
+        backend = os.environ.get("FPCA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import flashpca_amd as fp
 

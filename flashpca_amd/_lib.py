@@ -9,7 +9,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_build", "libfpca.so")
+LIB_PATH = os.environ.get("FPCA_LIB") or os.path.join(HERE, "_build", "libfpca.so")  # FPCA_LIB: A/B-test another build
 CLI_PATH = os.path.join(HERE, "_build", "flashpca")
 CSRC = os.path.join(HERE, "csrc")
 
@@ -96,7 +96,7 @@ SIGNATURES = {
     "fpca_profile_end": (_I, [_P, _I, C.POINTER(BenchResult), C.POINTER(_I)]),
     "fpca_bench_stats": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D)]),
     "fpca_debug_mfma_probe": (_I, [_P, _P, _P]),
-    "fpca_debug_mfma_peak": (_I, [_I, _I, C.POINTER(_D)]),
+    "fpca_debug_mfma_peak": (_I, [_I, _I, _I, C.POINTER(_D)]),
 }
 
 _lib = None

@@ -958,11 +958,23 @@ int fpca_debug_mfma_probe(const double *A, const double *B, double *D)
 }
 
 // diagnostic: measured issue-rate ceiling of v_mfma_f64_16x16x4_f64 (TFLOP/s) with 1..8 waves per SIMD
-int fpca_debug_mfma_peak(int waves_per_simd, int iters, double *tflops)
+int fpca_debug_census(int nwg, uint64_t lds_bytes, uint32_t *out)
 {
    return guarded([&] {
-      if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 10 || !tflops) throw Error(FPCA_EINVAL, "bad argument");
-      *tflops = kern::mfma_peak_tflops(waves_per_simd, iters, nullptr);
+      uint32_t *d = nullptr;
+      HIP_CHECK(hipMalloc(&d, (size_t)nwg * 2 * sizeof(uint32_t)));
+      kern::census(d, nwg, (size_t)lds_bytes, 2000000, nullptr);
+      HIP_CHECK(hipDeviceSynchronize());
+      HIP_CHECK(hipMemcpy(out, d, (size_t)nwg * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      (void)hipFree(d);
+   });
+}
+
+int fpca_debug_mfma_peak(int waves_per_simd, int iters, int pattern, double *tflops)
+{
+   return guarded([&] {
+      if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 10 || pattern < 0 || pattern > 3 || !tflops) throw Error(FPCA_EINVAL, "bad argument");
+      *tflops = kern::mfma_peak_tflops(waves_per_simd, iters, pattern, nullptr);
    });
 }
 

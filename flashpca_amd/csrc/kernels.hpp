@@ -61,7 +61,9 @@ void synth_generate(uint8_t *packed, size_t pitch, uint64_t N, uint64_t snp_begi
 void mfma_layout_probe(const double *A, const double *B, double *D, hipStream_t stream);
 
 // issue-rate ceiling of the FP64 MFMA (TFLOP/s) with `waves_per_simd` resident waves per SIMD
-double mfma_peak_tflops(int waves_per_simd, int iters, hipStream_t stream);
+double mfma_peak_tflops(int waves_per_simd, int iters, int pattern, hipStream_t stream);
+// diagnostic: hardware placement (HW_ID, XCC_ID per workgroup) of an nwg-workgroup grid with lds_bytes of LDS each
+void census(uint32_t *d_out, int nwg, size_t lds_bytes, long long spin, hipStream_t stream);
 
 } // namespace kern
 } // namespace fpca

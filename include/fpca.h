@@ -205,9 +205,13 @@ int fpca_bench_stats(fpca_ctx *ctx, int reps, double *ms_per_launch, double *byt
 /* diagnostic: D(16x16, row-major) = A(16x4) B(4x16) through v_mfma_f64_16x16x4_f64 with the lane->operand mapping the
  * kernels assume; host pointers.  Used by tests/test_gpu_kernels.py as a guard on the hardware layout. */
 int fpca_debug_mfma_probe(const double *A, const double *B, double *D);
-/* diagnostic: measured issue-rate ceiling (TFLOP/s) of the FP64 MFMA with `waves_per_simd` (1..8) resident waves per
- * SIMD and no memory traffic -- the attainable rate to read roofline fractions against */
-int fpca_debug_mfma_peak(int waves_per_simd, int iters, double *tflops);
+/* diagnostic: sustained rate (TFLOP/s) of a pure v_mfma_f64_16x16x4_f64 stream with `waves_per_simd` (1..8) resident
+ * waves per SIMD and no memory traffic; pattern 0..3 selects the operand-register sharing pattern (kernels.hip).  The
+ * practical ceiling to read the GEMM kernels' roofline fraction against (72-74 TFLOP/s at 2 waves/SIMD vs 78.6 datasheet) */
+int fpca_debug_mfma_peak(int waves_per_simd, int iters, int pattern, double *tflops);
+/* diagnostic: placement census of an nwg-workgroup grid (256 threads, lds_bytes dynamic LDS each): out[2i] = HW_ID,
+ * out[2i+1] = XCC_ID of workgroup i */
+int fpca_debug_census(int nwg, uint64_t lds_bytes, uint32_t *out);
 
 #ifdef __cplusplus
 }
