@@ -97,6 +97,7 @@ SIGNATURES = {
     "fpca_bench_stats": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D)]),
     "fpca_debug_mfma_probe": (_I, [_P, _P, _P]),
     "fpca_debug_mfma_peak": (_I, [_I, _I, _I, C.POINTER(_D)]),
+    "fpca_debug_census": (_I, [_I, _U64, _P]),
 }
 
 _lib = None
