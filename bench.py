@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (vendor datasheet); HBM3E 8 TB/s
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X FP32 matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
@@ -45,6 +46,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--accum", default="fp64", choices=["fp64", "fp32"], help="fp32 = v_mfma_f32 products, fp64 long accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pca", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the bounded baseline sample")
@@ -85,7 +87,7 @@ def main():
         P_rank, P_total, snp_begin = hi - lo, w["P"], lo
 
     t_gen = time.time()
-    ctx = fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=2 * k, device=local_rank)
+    ctx = fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=2 * k, device=local_rank, accum=args.accum)
     ctx.set_total_snps(P_total)
     ctx.stats()
     t_gen = time.time() - t_gen
@@ -161,7 +163,8 @@ def main():
     dom = "xt_b" if prof["ms_xt"] >= prof["ms_x"] else "x_t"
     ms_dom = max(prof["ms_xt"], prof["ms_x"])
     flops_launch = 2.0 * N * P_rank * b
-    roofline = dict(bound="mfma", kernel=dom, achieved=flops_launch / (ms_dom * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TFLOPS,
+    roofline = dict(bound="mfma", kernel=dom, achieved=flops_launch / (ms_dom * 1e-3) / 1e12,
+                    peak=FP64_MFMA_PEAK_TFLOPS if args.accum == "fp64" else FP32_MFMA_PEAK_TFLOPS,
                     unit="TFLOP/s", traffic=None,
                     ms_xt_b=prof["ms_xt"], ms_x_t=prof["ms_x"], ms_allreduce=prof["ms_allreduce"],
                     flops_per_launch=flops_launch,
@@ -170,7 +173,8 @@ def main():
 
     out = dict(metric="genotype cells/sec (N x P x iters) for k=20 PCA", value=value, unit="cells/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
-               scaling=w["scaling"], vs_baseline=None, dtype="f64", data="synthetic",
+               scaling=w["scaling"], vs_baseline=None, dtype="f64" if args.accum == "fp64" else "f32 (fp64 long accumulation)",
+               data="synthetic",
                config=dict(workload=args.workload + ": " + w["desc"], samples=N, snps_total=P_total, snps_per_gpu=P_rank,
                            k=k, blockvec=b, parallelism="snp-shard x%d + all-reduce(N x b) [%s]" % (world, transport),
                            iters_per_step=b, generate_s=round(t_gen, 3)),

@@ -13,6 +13,9 @@ from . import _lib
 from ._lib import DIVISOR, STANDARDISE, BenchResult, FpcaError, PcaInfo, PcaOpts, check, lib  # noqa: F401
 
 
+ACCUM = {"fp64": 64, "fp32": 32, 64: 64, 32: 32}
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
@@ -35,18 +38,18 @@ class Context:
 
     # ---- constructors -----------------------------------------------------------------------------
     @classmethod
-    def from_packed(cls, packed, N, P, stand="binom2", device=0):
+    def from_packed(cls, packed, N, P, stand="binom2", device=0, accum="fp64"):
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         assert packed.size >= ((N + 3) // 4) * P
         h = C.c_void_p()
-        check(lib().fpca_create(C.byref(h), _p(packed), N, P, STANDARDISE[stand], device, 64))
+        check(lib().fpca_create(C.byref(h), _p(packed), N, P, STANDARDISE[stand], device, ACCUM[accum]))
         return cls(h)
 
     @classmethod
-    def from_bed(cls, bed_path, N, snp_begin=0, P=0, stand="binom2", device=0):
+    def from_bed(cls, bed_path, N, snp_begin=0, P=0, stand="binom2", device=0, accum="fp64"):
         h = C.c_void_p()
         ptot = C.c_uint64(0)
-        check(lib().fpca_create_from_bed(C.byref(h), bed_path.encode(), N, snp_begin, P, STANDARDISE[stand], device, 64,
+        check(lib().fpca_create_from_bed(C.byref(h), bed_path.encode(), N, snp_begin, P, STANDARDISE[stand], device, ACCUM[accum],
                                          C.byref(ptot)))
         c = cls(h)
         c.P_total = int(ptot.value)
@@ -54,10 +57,11 @@ class Context:
         return c
 
     @classmethod
-    def synthetic(cls, N, P, snp_begin=0, seed=20260928, n_pop=40, fst=0.05, missing_rate=0.001, stand="binom2", device=0):
+    def synthetic(cls, N, P, snp_begin=0, seed=20260928, n_pop=40, fst=0.05, missing_rate=0.001, stand="binom2", device=0,
+                  accum="fp64"):
         h = C.c_void_p()
         check(lib().fpca_create_synthetic(C.byref(h), N, snp_begin, P, seed, n_pop, fst, missing_rate, STANDARDISE[stand],
-                                          device, 64))
+                                          device, ACCUM[accum]))
         return cls(h)
 
     def close(self):
@@ -195,7 +199,7 @@ class Context:
 
 
 def flashpca(X, ndim=10, stand="binom2", divisor="p", maxiter=500, tol=1e-6, do_loadings=False, return_scale=True,
-             device=0, verbose=False, **solver_kw):
+             device=0, verbose=False, accum="fp64", **solver_kw):
     """PCA of a PLINK fileset; mirrors flashpca() of the reference's R package for the PLINK-prefix input
     (flashpcaR/R/flashpca.R:99-204 -> flashpca_plink_internal, flashpcaR/src/flashpca.cpp:96-197).
 
@@ -208,7 +212,7 @@ def flashpca(X, ndim=10, stand="binom2", divisor="p", maxiter=500, tol=1e-6, do_
     if divisor not in DIVISOR:
         raise ValueError("divisor must be one of %s" % sorted(DIVISOR))
     N = count_fam_rows(X + ".fam")
-    with Context.from_bed(X + ".bed", N, stand=stand, device=device) as ctx:
+    with Context.from_bed(X + ".bed", N, stand=stand, device=device, accum=accum) as ctx:
         r = ctx.pca(ndim=ndim, tol=tol, maxiter=maxiter, div=divisor, do_loadings=do_loadings, verbose=int(verbose),
                     **solver_kw)
     res = dict(values=r["d"], vectors=r["U"], projection=r["Px"], loadings=r["V"], pve=r["pve"], info=r["info"])

@@ -136,7 +136,7 @@ void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int devi
    if (N == 0) throw Error(FPCA_EINVAL, "N must be > 0");
    if (stand != FPCA_STANDARDISE_BINOM && stand != FPCA_STANDARDISE_BINOM2)
       throw Error(FPCA_EINVAL, "unknown standardisation method: " + std::to_string(stand)); // data.cpp:283-288
-   if (accum != FPCA_ACCUM_FP64) throw Error(FPCA_EINVAL, "only FPCA_ACCUM_FP64 is implemented in this build");
+   if (accum != FPCA_ACCUM_FP64 && accum != FPCA_ACCUM_FP32) throw Error(FPCA_EINVAL, "accum must be FPCA_ACCUM_FP64 or FPCA_ACCUM_FP32");
    int ndev = 0;
    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
       throw Error(FPCA_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
@@ -220,18 +220,18 @@ void ensure_stats(fpca_ctx *c)
 void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t s, hipEvent_t *ev)
 {
    ensure_stats(c);
-   const int s2 = kern::xt_b_splits(c->N_pad, c->P_pad, b);
-   const int s3 = kern::x_t_splits(c->N_pad, c->P_pad, b);
+   const int s2 = kern::xt_b_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
+   const int s3 = kern::x_t_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
    c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
    size_t need = 0;
    if (s2 > 1) need = std::max(need, (size_t)s2 * c->P_pad * b);
    if (s3 > 1) need = std::max(need, (size_t)s3 * c->N_pad * b);
    if (need) c->ensure(c->d_part, c->part_cap, need);
    if (ev) HIP_CHECK(hipEventRecord(ev[0], s));
-   kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, s);
+   kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, c->accum == FPCA_ACCUM_FP32, s);
    if (s2 > 1) kern::reduce_sum(c->d_part, c->d_T, (uint64_t)c->P_pad * b, s2, s);
    if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
-   kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, s);
+   kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, c->accum == FPCA_ACCUM_FP32, s);
    if (s3 > 1) kern::reduce_sum(c->d_part, dY, (uint64_t)c->N_pad * b, s3, s);
    if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
    if (c->multi()) c->allreduce(dY, (uint64_t)c->N_pad * b, s);
@@ -241,19 +241,19 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
 void xt_dev(fpca_ctx *c, const double *dB, int b, hipStream_t s)
 {
    ensure_stats(c);
-   const int s2 = kern::xt_b_splits(c->N_pad, c->P_pad, b);
+   const int s2 = kern::xt_b_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
    c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
    if (s2 > 1) c->ensure(c->d_part, c->part_cap, (size_t)s2 * c->P_pad * b);
-   kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, s);
+   kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, c->accum == FPCA_ACCUM_FP32, s);
    if (s2 > 1) kern::reduce_sum(c->d_part, c->d_T, (uint64_t)c->P_pad * b, s2, s);
 }
 
 void x_dev(fpca_ctx *c, int b, double *dY, hipStream_t s)
 {
    ensure_stats(c);
-   const int s3 = kern::x_t_splits(c->N_pad, c->P_pad, b);
+   const int s3 = kern::x_t_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
    if (s3 > 1) c->ensure(c->d_part, c->part_cap, (size_t)s3 * c->N_pad * b);
-   kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, s);
+   kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, c->accum == FPCA_ACCUM_FP32, s);
    if (s3 > 1) kern::reduce_sum(c->d_part, dY, (uint64_t)c->N_pad * b, s3, s);
 }
 

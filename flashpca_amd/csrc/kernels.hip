@@ -172,73 +172,98 @@ void lut_from_meansd(const double *mean, const double *sd, uint64_t P_g, double 
 }
 
 // ------------------------------------------------------------------------------------------------
-// standardised value of a raw PLINK code from a per-lane register table (code 01 -> 0)
-__device__ __forceinline__ double lut_sel(uint32_t code, double l0, double l2, double l3)
+// The two GEMM kernels exist in two arithmetic flavours, selected by the context's `accum` setting:
+//   RT = double : v_mfma_f64_16x16x4_f64, everything in fp64 (default; FPCA_ACCUM_FP64)
+//   RT = float  : v_mfma_f32_16x16x4_f32 (twice the MFMA rate): the table of standardised values and the B / T tile
+//                 are rounded to fp32 in LDS, products and the accumulation WITHIN one LDS chunk (128 samples / 64 SNPs)
+//                 run in fp32, and every chunk's partial sums are added into fp64 accumulators, so the rounding error
+//                 does not grow with N or P (BASELINE config 5, "fp32 accumulate (tolerance study)"; FPCA_ACCUM_FP32)
+// Both MFMAs take A[i = lane&15][k = lane>>4] and B[k = lane>>4][j = lane&15], one value per lane; they differ in the
+// C/D map: fp64 register r holds row (lane>>4) + 4r, fp32 register r holds row 4 (lane>>4) + r.
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <typename RT> struct Mma;
+template <> struct Mma<double> {
+   typedef d4 acc_t;
+   static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+   static __device__ __forceinline__ int row(int kq, int r) { return kq + 4 * r; }
+};
+template <> struct Mma<float> {
+   typedef f4 acc_t;
+   static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+   static __device__ __forceinline__ int row(int kq, int r) { return 4 * kq + r; }
+};
+
+// store a 16-byte piece of fp64 data (2 doubles) at logical element index 2*idx of an RT-typed LDS array
+__device__ __forceinline__ void lds_put2(double *base, int idx, d2 v) { reinterpret_cast<d2 *>(base)[idx] = v; }
+__device__ __forceinline__ void lds_put2(float *base, int idx, d2 v)
 {
-   const double hi = (code & 1u) ? l3 : l2;
-   const double lo = (code & 1u) ? 0.0 : l0;
-   return (code & 2u) ? hi : lo;
+   reinterpret_cast<f2 *>(base)[idx] = (f2){(float)v.x, (float)v.y};
+}
+
+static int env_int(const char *name, int dflt)
+{
+   const char *e = getenv(name);
+   return e && *e ? atoi(e) : dflt;
 }
 
 // ------------------------------------------------------------------------------------------------
 // K2 xt_b:  T[snp][c] = sum_s X[s][snp] B[s][c]
 //   workgroup = 256 SNPs x all b columns, wave = 64 SNPs (4 m-tiles of 16), K = samples.
 //   MFMA roles: A[i = SNP in m-tile][k] = decoded genotype, B[k][j = column] = B tile from LDS.
-//   Per 128-sample chunk each lane (i, kq) loads 8 packed bytes of ITS SNP record (samples 32kq..32kq+31
-//   of the chunk) straight into registers -- the K order inside a chunk is permuted so that no cross-lane
-//   shuffle is needed -- and the B tile (128 x b fp64, contiguous in HBM) is staged through LDS once per
-//   workgroup.  Loads of chunk c+1 are issued before the 256 MFMAs of chunk c.
+//   Per KC-sample chunk each lane (i, kq) loads KC/16 packed bytes of ITS SNP record (samples kq*KC/4 .. of the
+//   chunk) straight into registers -- the K order inside a chunk is permuted per lane group so that no cross-lane
+//   shuffle is needed -- and the B tile (KC x b, contiguous in HBM) is staged through LDS once per workgroup.  The
+//   workgroup's 256 x 4 table of standardised values also sits in LDS: decode = one LDS read indexed by the raw 2-bit
+//   code.  The loads of chunk c+1 are issued before the MFMAs of chunk c.  Split-K over samples (blockIdx.y) with a
+//   deterministic combine when there are too few SNP tiles to fill the chip.
 template <int NT> struct XtCfg {
    static constexpr int KC = (NT <= 2) ? 128 : 64; // samples per LDS chunk: keeps the prefetch registers <= 32
 };
 
-template <int NT, bool GL /* decode through an LDS-resident table (gather) instead of register selects */>
+template <typename RT, int NT, int MT /* m-tiles (16 SNPs each) per wave; workgroup tile = 64*MT SNPs */>
 __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ packed, size_t pitch,
                                                   const double *__restrict__ lut, const double *__restrict__ B,
                                                   double *__restrict__ Tpart, uint64_t P_pad, int chunks_total,
                                                   int chunks_per_split)
 {
+   typedef typename Mma<RT>::acc_t acc_t;
+   constexpr bool MIXED = sizeof(RT) == 4;
    constexpr int b = 16 * NT;
-   constexpr int MT = 4;
+   constexpr int TILE = 64 * MT;
    constexpr int KC = XtCfg<NT>::KC;
    constexpr int NW = KC / 64;                    // packed dwords per lane per m-tile per chunk (16 samples each)
-   constexpr int NLOAD = KC * b * 8 / (256 * 16); // 16-byte pieces of the B tile per thread
+   constexpr int NLOAD = KC * b * 8 / (256 * 16); // 16-byte pieces of the (fp64) B tile per thread
    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-   double *sB = reinterpret_cast<double *>(smem_raw); // [KC][b]
-   double *sLut = sB + KC * b;                        // [XT_TILE][4] (GL only)
+   RT *sB = reinterpret_cast<RT *>(smem_raw); // [KC][b]
+   RT *sLut = sB + KC * b;                    // [TILE][4]
 
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int li = lane & 15, kq = lane >> 4;
-   const uint64_t snp0 = (uint64_t)blockIdx.x * XT_TILE + (uint64_t)wave * 64;
-   if (GL) { // one SNP's 4-entry table per thread; visible after the first barrier of the chunk loop
-      const d2 *lsrc = reinterpret_cast<const d2 *>(lut + ((uint64_t)blockIdx.x * XT_TILE + tid) * 4);
-      reinterpret_cast<d2 *>(sLut)[tid * 2] = lsrc[0];
-      reinterpret_cast<d2 *>(sLut)[tid * 2 + 1] = lsrc[1];
-   }
+   const uint64_t snp0 = (uint64_t)blockIdx.x * TILE + (uint64_t)wave * (16 * MT);
    const int c_begin = blockIdx.y * chunks_per_split;
    int c_end = c_begin + chunks_per_split;
    if (c_end > chunks_total) c_end = chunks_total;
-
-   double l0[MT], l2[MT], l3[MT];
+   if (tid < TILE) { // one SNP's 4-entry table per thread; visible after the first barrier of the chunk loop
+      const d2 *lsrc = reinterpret_cast<const d2 *>(lut + ((uint64_t)blockIdx.x * TILE + tid) * 4);
+      lds_put2(sLut, tid * 2, lsrc[0]);
+      lds_put2(sLut, tid * 2 + 1, lsrc[1]);
+   }
    const uint8_t *rowp[MT];
 #pragma unroll
-   for (int m = 0; m < MT; m++) {
-      const uint64_t snp = snp0 + m * 16 + li;
-      if (!GL) {
-         const double *lp = lut + snp * 4;
-         l0[m] = lp[0];
-         l2[m] = lp[2];
-         l3[m] = lp[3];
-      } else
-         l0[m] = l2[m] = l3[m] = 0.0;
-      rowp[m] = packed + snp * pitch + kq * (KC / 16); // lane group kq owns samples kq*KC/4 .. +KC/4 of a chunk
-   }
+   for (int m = 0; m < MT; m++)
+      rowp[m] = packed + (snp0 + m * 16 + li) * pitch + kq * (KC / 16); // lane group kq owns samples kq*KC/4 .. +KC/4
 
-   d4 acc[MT][NT];
+   acc_t acc[MT][NT];
+   d4 acc64[MIXED ? MT : 1][MIXED ? NT : 1];
 #pragma unroll
    for (int m = 0; m < MT; m++)
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) acc[m][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int nt = 0; nt < NT; nt++) {
+         acc[m][nt] = (acc_t){0, 0, 0, 0};
+         if (MIXED) acc64[m][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+      }
 
    uint32_t pk_next[MT][NW];
    d2 breg[NLOAD];
@@ -254,15 +279,13 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
    }
    if (c_begin < c_end) FPCA_XTB_ISSUE(c_begin);
 
-   const double *sB_lane = sB + (size_t)((KC / 4) * kq) * b + li;
+   const RT *sB_lane = sB + (size_t)((KC / 4) * kq) * b + li;
+   const RT *sLut_lane = sLut + (size_t)(wave * (16 * MT) + li) * 4;
 
    for (int c = c_begin; c < c_end; c++) {
       __syncthreads(); // every wave has finished reading the previous B tile
-      {
-         d2 *dst = reinterpret_cast<d2 *>(sB);
 #pragma unroll
-         for (int r = 0; r < NLOAD; r++) dst[tid + 256 * r] = breg[r];
-      }
+      for (int r = 0; r < NLOAD; r++) lds_put2(sB, tid + 256 * r, breg[r]);
       uint32_t pk[MT][NW];
 #pragma unroll
       for (int m = 0; m < MT; m++)
@@ -274,17 +297,26 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
       for (int half = 0; half < NW; half++) {
 #pragma unroll
          for (int t = 0; t < 16; t++) {
-            double bv[NT];
+            RT bv[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) bv[nt] = sB_lane[(size_t)(16 * half + t) * b + nt * 16];
 #pragma unroll
             for (int m = 0; m < MT; m++) {
-               const uint32_t code = (pk[m][half] >> (2 * t)) & 3u;
-               const double a = GL ? sLut[(wave * 64 + m * 16 + li) * 4 + code] : lut_sel(code, l0[m], l2[m], l3[m]);
+               const RT a = sLut_lane[m * 64 + ((pk[m][half] >> (2 * t)) & 3u)];
 #pragma unroll
-               for (int nt = 0; nt < NT; nt++) acc[m][nt] = FPCA_MFMA(a, bv[nt], acc[m][nt]);
+               for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(a, bv[nt], acc[m][nt]);
             }
          }
+      }
+      if (MIXED) { // fold this chunk's fp32 partial sums into the fp64 accumulators
+#pragma unroll
+         for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+               for (int r = 0; r < 4; r++) acc64[m][nt][r] += (double)acc[m][nt][r];
+               acc[m][nt] = (acc_t){0, 0, 0, 0};
+            }
       }
    }
 #undef FPCA_XTB_ISSUE
@@ -296,15 +328,9 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
       for (int nt = 0; nt < NT; nt++)
 #pragma unroll
          for (int r = 0; r < 4; r++) {
-            const uint64_t row = snp0 + m * 16 + kq + 4 * r;
-            Tout[row * b + nt * 16 + li] = acc[m][nt][r];
+            const uint64_t row = snp0 + m * 16 + Mma<RT>::row(kq, r);
+            Tout[row * b + nt * 16 + li] = MIXED ? acc64[m][nt][r] : (double)acc[m][nt][r];
          }
-}
-
-static int env_int(const char *name, int dflt)
-{
-   const char *e = getenv(name);
-   return e && *e ? atoi(e) : dflt;
 }
 
 static int pick_splits(uint64_t tiles, uint64_t chunks, int min_chunks, int max_splits)
@@ -328,54 +354,57 @@ static int pick_splits(uint64_t tiles, uint64_t chunks, int min_chunks, int max_
    return best;
 }
 
-int xt_b_splits(uint64_t N_pad, uint64_t P_pad, int b)
+int xt_b_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32)
 {
    const int kc = b <= 32 ? 128 : 64;
+   const int tile = (fp32 && b >= 48) ? 128 : 256;
    static const int forced = env_int("FPCA_XT_SPLITS", 0);
    if (forced > 0) return (int)std::min<uint64_t>(forced, N_pad / kc);
-   return pick_splits(P_pad / XT_TILE, N_pad / kc, 4, 64);
+   return pick_splits(P_pad / tile, N_pad / kc, 4, 64);
 }
 
-template <int NT, bool GL>
-static void launch_xt_b2(const uint8_t *packed, size_t pitch, const double *lut, const double *B, double *Tpart,
-                         uint64_t N_pad, uint64_t P_pad, int nsplit, hipStream_t stream)
+template <typename RT, int NT> struct XtMt {
+   static constexpr int MT = (sizeof(RT) == 4 && NT >= 3) ? 2 : 4; // mixed mode carries fp32 + fp64 accumulators
+};
+
+template <typename RT, int NT>
+static void launch_xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *B, double *Tpart,
+                        uint64_t N_pad, uint64_t P_pad, int nsplit, hipStream_t stream)
 {
    constexpr int KC = XtCfg<NT>::KC;
    const int chunks_total = (int)(N_pad / KC);
    const int cps = (chunks_total + nsplit - 1) / nsplit;
-   const size_t smem = (size_t)KC * 16 * NT * sizeof(double) + (GL ? XT_TILE * 4 * sizeof(double) : 0);
+   constexpr int MT = XtMt<RT, NT>::MT;
+   const size_t smem = ((size_t)KC * 16 * NT + 64 * MT * 4) * sizeof(RT);
    static bool attr_set = false;
    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xt_b<NT, GL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xt_b<RT, NT, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr_set = true;
    }
-   dim3 grid((unsigned)(P_pad / XT_TILE), (unsigned)nsplit);
-   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xt_b<NT, GL>), grid, dim3(256), smem, stream, packed, pitch, lut, B, Tpart, P_pad,
+   dim3 grid((unsigned)(P_pad / (64 * MT)), (unsigned)nsplit);
+   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xt_b<RT, NT, MT>), grid, dim3(256), smem, stream, packed, pitch, lut, B, Tpart, P_pad,
                       chunks_total, cps);
    HIP_CHECK_LAUNCH();
 }
 
-template <int NT>
-static void launch_xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *B, double *Tpart,
-                        uint64_t N_pad, uint64_t P_pad, int nsplit, hipStream_t stream)
-{
-   static const int variant = env_int("FPCA_XT_VARIANT", 1); // 1 = LDS-table gather (default, faster), 0 = register selects
-   if (variant == 1)
-      launch_xt_b2<NT, true>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream);
-   else
-      launch_xt_b2<NT, false>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream);
-}
-
 void xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *B, double *Tpart, uint64_t N_pad,
-          uint64_t P_pad, int b, int nsplit, hipStream_t stream)
+          uint64_t P_pad, int b, int nsplit, bool fp32, hipStream_t stream)
 {
+#define FPCA_CASE(NT_)                                                                                          \
+   case 16 * NT_:                                                                                               \
+      if (fp32)                                                                                                 \
+         launch_xt_b<float, NT_>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream);                   \
+      else                                                                                                      \
+         launch_xt_b<double, NT_>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream);                  \
+      break;
    switch (b) {
-   case 16: launch_xt_b<1>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream); break;
-   case 32: launch_xt_b<2>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream); break;
-   case 48: launch_xt_b<3>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream); break;
-   case 64: launch_xt_b<4>(packed, pitch, lut, B, Tpart, N_pad, P_pad, nsplit, stream); break;
+      FPCA_CASE(1)
+      FPCA_CASE(2)
+      FPCA_CASE(3)
+      FPCA_CASE(4)
    default: throw Error(-1, "xt_b: block width must be 16, 32, 48 or 64");
    }
+#undef FPCA_CASE
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,22 +415,25 @@ void xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *
 //   lines for MT=8), together with the 64 x b tile of T and the 64 x 4 lookup-table tile.  Lane (i, kq) owns
 //   samples MT*i .. MT*i+MT-1 of its wave (one ushort / byte of the record), so m-tile m row i is sample
 //   MT*i + m: again a permutation chosen so that decode needs no cross-lane traffic.  The standardised
-//   value is fetched from the LDS table with the raw 2-bit code as index (ds_read_b64 gather).
-template <int MT, int NT>
+//   value is fetched from the LDS table with the raw 2-bit code as index.
+template <typename RT, int MT, int NT, int KCX /* SNPs per LDS chunk */>
 __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ packed, size_t pitch,
                                                  const double *__restrict__ lut, const double *__restrict__ T,
                                                  double *__restrict__ Ypart, uint64_t N_pad, int chunks_total,
                                                  int chunks_per_split)
 {
+   typedef typename Mma<RT>::acc_t acc_t;
+   constexpr bool MIXED = sizeof(RT) == 4;
    constexpr int b = 16 * NT;
    constexpr int ROWB = 16 * MT;                       // bytes of one record inside the workgroup tile
-   constexpr int NP = X_KC * ROWB / (256 * 16);        // packed 16-byte pieces per thread (2 for MT=8, 1 for MT=4)
-   constexpr int NTL = X_KC * b * 8 / (256 * 16);      // T-tile pieces per thread (= 2 NT)
+   constexpr int NPIECES = KCX * ROWB / 16;            // 16-byte pieces of the packed tile
+   constexpr int NP = (NPIECES + 255) / 256;           // ... per thread (2 for MT=8, 1 for MT=4)
+   constexpr int NTL = KCX * b * 8 / (256 * 16);      // (fp64) T-tile pieces per thread (= 2 NT)
    constexpr int SEG = ROWB / 16;                      // 16-byte pieces per record row
    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-   double *sT = reinterpret_cast<double *>(smem_raw);                  // [X_KC][b]
-   double *sL = sT + X_KC * b;                                         // [X_KC][4]
-   unsigned char *sP = reinterpret_cast<unsigned char *>(sL + X_KC * 4); // [X_KC][ROWB]
+   unsigned char *sP = smem_raw;                                        // [KCX][ROWB]
+   RT *sT = reinterpret_cast<RT *>(smem_raw + KCX * ROWB);             // [KCX][b]
+   RT *sL = sT + KCX * b;                                              // [KCX][4]
 
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int li = lane & 15, kq = lane >> 4;
@@ -410,63 +442,79 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
    int c_end = c_begin + chunks_per_split;
    if (c_end > chunks_total) c_end = chunks_total;
 
-   d4 acc[MT][NT];
+   acc_t acc[MT][NT];
+   d4 acc64[MIXED ? MT : 1][MIXED ? NT : 1];
 #pragma unroll
    for (int m = 0; m < MT; m++)
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) acc[m][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int nt = 0; nt < NT; nt++) {
+         acc[m][nt] = (acc_t){0, 0, 0, 0};
+         if (MIXED) acc64[m][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+      }
 
    u4 preg[NP];
    d2 treg[NTL];
    d2 lreg;
 #define FPCA_XT_ISSUE(cc)                                                                                     \
    {                                                                                                           \
-      const uint64_t snp_c0 = (uint64_t)(cc) * X_KC;                                                           \
+      const uint64_t snp_c0 = (uint64_t)(cc) * KCX;                                                           \
       _Pragma("unroll") for (int r = 0; r < NP; r++)                                                           \
       {                                                                                                        \
          const int p = tid + 256 * r;                                                                          \
          const int prow = p / SEG, pseg = p % SEG;                                                             \
-         preg[r] = *reinterpret_cast<const u4 *>(packed + (snp_c0 + prow) * pitch + wg_byte0 + pseg * 16);  \
+         if (p < NPIECES)                                                                                      \
+            preg[r] = *reinterpret_cast<const u4 *>(packed + (snp_c0 + prow) * pitch + wg_byte0 + pseg * 16);  \
       }                                                                                                        \
-      const d2 *tsrc = reinterpret_cast<const d2 *>(T + snp_c0 * b);                                 \
+      const d2 *tsrc = reinterpret_cast<const d2 *>(T + snp_c0 * b);                                           \
       _Pragma("unroll") for (int r = 0; r < NTL; r++) treg[r] = tsrc[tid + 256 * r];                           \
-      if (tid < X_KC * 2) lreg = reinterpret_cast<const d2 *>(lut + snp_c0 * 4)[tid];                     \
+      if (tid < KCX * 2) lreg = reinterpret_cast<const d2 *>(lut + snp_c0 * 4)[tid];                          \
    }
 
    if (c_begin < c_end) FPCA_XT_ISSUE(c_begin);
 
    const unsigned char *sP_lane = sP + (size_t)kq * ROWB + wave * (4 * MT) + li * (MT / 4);
-   const double *sT_lane = sT + (size_t)kq * b + li;
-   const double *sL_lane = sL + (size_t)kq * 4;
+   const RT *sT_lane = sT + (size_t)kq * b + li;
+   const RT *sL_lane = sL + (size_t)kq * 4;
 
    for (int c = c_begin; c < c_end; c++) {
       __syncthreads();
       {
 #pragma unroll
-         for (int r = 0; r < NP; r++) reinterpret_cast<u4 *>(sP)[tid + 256 * r] = preg[r];
+         for (int r = 0; r < NP; r++)
+            if (tid + 256 * r < NPIECES) reinterpret_cast<u4 *>(sP)[tid + 256 * r] = preg[r];
 #pragma unroll
-         for (int r = 0; r < NTL; r++) reinterpret_cast<d2 *>(sT)[tid + 256 * r] = treg[r];
-         if (tid < X_KC * 2) reinterpret_cast<d2 *>(sL)[tid] = lreg;
+         for (int r = 0; r < NTL; r++) lds_put2(sT, tid + 256 * r, treg[r]);
+         if (tid < KCX * 2) lds_put2(sL, tid, lreg);
       }
       __syncthreads();
       if (c + 1 < c_end) FPCA_XT_ISSUE(c + 1);
 #pragma unroll
-      for (int t = 0; t < X_KC / 4; t++) {
+      for (int t = 0; t < KCX / 4; t++) {
          uint32_t h;
          if (MT == 8)
             h = *reinterpret_cast<const unsigned short *>(sP_lane + (size_t)(4 * t) * ROWB);
          else
             h = *(sP_lane + (size_t)(4 * t) * ROWB);
-         double tv[NT];
+         RT tv[NT];
 #pragma unroll
          for (int nt = 0; nt < NT; nt++) tv[nt] = sT_lane[(size_t)(4 * t) * b + nt * 16];
-         const double *lrow = sL_lane + (size_t)(4 * t) * 4;
+         const RT *lrow = sL_lane + (size_t)(4 * t) * 4;
 #pragma unroll
          for (int m = 0; m < MT; m++) {
-            const double a = lrow[(h >> (2 * m)) & 3u];
+            const RT a = lrow[(h >> (2 * m)) & 3u];
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[m][nt] = FPCA_MFMA(a, tv[nt], acc[m][nt]);
+            for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(a, tv[nt], acc[m][nt]);
          }
+      }
+      if (MIXED) {
+#pragma unroll
+         for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+               for (int r = 0; r < 4; r++) acc64[m][nt][r] += (double)acc[m][nt][r];
+               acc[m][nt] = (acc_t){0, 0, 0, 0};
+            }
       }
    }
 #undef FPCA_XT_ISSUE
@@ -479,64 +527,100 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
       for (int nt = 0; nt < NT; nt++)
 #pragma unroll
          for (int r = 0; r < 4; r++) {
-            const uint64_t s = s_wave + (uint64_t)MT * (kq + 4 * r) + m;
-            Yout[s * b + nt * 16 + li] = acc[m][nt][r];
+            const uint64_t s = s_wave + (uint64_t)MT * Mma<RT>::row(kq, r) + m;
+            Yout[s * b + nt * 16 + li] = MIXED ? acc64[m][nt][r] : (double)acc[m][nt][r];
          }
 }
 
-static inline int x_t_mt(int b) { return b <= 32 ? 8 : 4; }
+// shape of K3 per (arithmetic, block width): fp64 -> 8 m-tiles for b <= 32 else 4, 64-SNP chunks; the mixed fp32 mode
+// carries fp32 + fp64 accumulators, so it uses 4 m-tiles and, for b >= 48, 32-SNP chunks (fewer prefetch registers)
+template <typename RT, int NT> struct XCfg {
+   static constexpr bool MIXED = sizeof(RT) == 4;
+   static constexpr int MT = MIXED ? 4 : (NT <= 2 ? 8 : 4);
+   static constexpr int KCX = (MIXED && NT >= 3) ? 32 : 64;
+};
+static inline int x_t_mt(int b, bool fp32) { return fp32 ? 4 : (b <= 32 ? 8 : 4); }
+static inline int x_t_kc(int b, bool fp32) { return (fp32 && b >= 48) ? 32 : 64; }
 
-int x_t_splits(uint64_t N_pad, uint64_t P_pad, int b)
+int x_t_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32)
 {
    static const int forced = env_int("FPCA_X_SPLITS", 0);
-   if (forced > 0) return (int)std::min<uint64_t>(forced, P_pad / X_KC);
-   return pick_splits(N_pad / (64 * x_t_mt(b)), P_pad / X_KC, 4, 64);
+   if (forced > 0) return (int)std::min<uint64_t>(forced, P_pad / x_t_kc(b, fp32));
+   return pick_splits(N_pad / (64 * x_t_mt(b, fp32)), P_pad / x_t_kc(b, fp32), 4, 64);
 }
 
-template <int MT, int NT>
+template <typename RT, int NT>
 static void launch_x_t(const uint8_t *packed, size_t pitch, const double *lut, const double *T, double *Ypart,
                        uint64_t N_pad, uint64_t P_pad, int nsplit, hipStream_t stream)
 {
-   const int chunks_total = (int)(P_pad / X_KC);
+   constexpr int MT = XCfg<RT, NT>::MT, KCX = XCfg<RT, NT>::KCX;
+   const int chunks_total = (int)(P_pad / KCX);
    const int cps = (chunks_total + nsplit - 1) / nsplit;
-   const size_t smem = (size_t)X_KC * 16 * NT * 8 + X_KC * 32 + (size_t)X_KC * 16 * MT;
+   const size_t smem = (size_t)KCX * 16 * MT + ((size_t)KCX * 16 * NT + KCX * 4) * sizeof(RT);
    static bool attr_set = false;
    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_x_t<MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)smem);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_x_t<RT, MT, NT, KCX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr_set = true;
    }
    dim3 grid((unsigned)(N_pad / (64 * MT)), (unsigned)nsplit);
-   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_x_t<MT, NT>), grid, dim3(256), smem, stream, packed, pitch, lut, T, Ypart,
+   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_x_t<RT, MT, NT, KCX>), grid, dim3(256), smem, stream, packed, pitch, lut, T, Ypart,
                       N_pad, chunks_total, cps);
    HIP_CHECK_LAUNCH();
 }
 
 void x_t(const uint8_t *packed, size_t pitch, const double *lut, const double *T, double *Ypart, uint64_t N_pad,
-         uint64_t P_pad, int b, int nsplit, hipStream_t stream)
+         uint64_t P_pad, int b, int nsplit, bool fp32, hipStream_t stream)
 {
+#define FPCA_CASE(NT_)                                                                                          \
+   case 16 * NT_:                                                                                               \
+      if (fp32)                                                                                                 \
+         launch_x_t<float, NT_>(packed, pitch, lut, T, Ypart, N_pad, P_pad, nsplit, stream);                    \
+      else                                                                                                      \
+         launch_x_t<double, NT_>(packed, pitch, lut, T, Ypart, N_pad, P_pad, nsplit, stream);                   \
+      break;
    switch (b) {
-   case 16: launch_x_t<8, 1>(packed, pitch, lut, T, Ypart, N_pad, P_pad, nsplit, stream); break;
-   case 32: launch_x_t<8, 2>(packed, pitch, lut, T, Ypart, N_pad, P_pad, nsplit, stream); break;
-   case 48: launch_x_t<4, 3>(packed, pitch, lut, T, Ypart, N_pad, P_pad, nsplit, stream); break;
-   case 64: launch_x_t<4, 4>(packed, pitch, lut, T, Ypart, N_pad, P_pad, nsplit, stream); break;
+      FPCA_CASE(1)
+      FPCA_CASE(2)
+      FPCA_CASE(3)
+      FPCA_CASE(4)
    default: throw Error(-1, "x_t: block width must be 16, 32, 48 or 64");
    }
+#undef FPCA_CASE
 }
 
 // ------------------------------------------------------------------------------------------------
 // deterministic split-K combine: out[i] = sum_s part[s][i]
-__global__ __launch_bounds__(256) void k_reduce_sum(const double2 *__restrict__ part, double2 *__restrict__ out,
-                                                     uint64_t count2, int nsplit)
+// Each thread owns 2 consecutive 16-byte elements and keeps 4 partial loads of each in flight, so the pass streams at
+// HBM rate instead of paying one dependent-load latency per partial.
+__global__ __launch_bounds__(256) void k_reduce_sum(const d2 *__restrict__ part, d2 *__restrict__ out, uint64_t count2,
+                                                     int nsplit)
 {
-   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count2; i += (uint64_t)gridDim.x * 256) {
-      double2 s = part[i];
-      for (int k = 1; k < nsplit; k++) {
-         const double2 v = part[(uint64_t)k * count2 + i];
-         s.x += v.x;
-         s.y += v.y;
+   const uint64_t stride = (uint64_t)gridDim.x * 256;
+   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count2; i += 2 * stride) {
+      const uint64_t i2 = i + stride;
+      const bool has2 = i2 < count2;
+      d2 s0 = (d2){0.0, 0.0}, s1 = (d2){0.0, 0.0};
+      int k = 0;
+      for (; k + 4 <= nsplit; k += 4) {
+         const d2 a0 = part[(uint64_t)(k + 0) * count2 + i], a1 = part[(uint64_t)(k + 1) * count2 + i];
+         const d2 a2 = part[(uint64_t)(k + 2) * count2 + i], a3 = part[(uint64_t)(k + 3) * count2 + i];
+         d2 b0 = (d2){0.0, 0.0}, b1 = b0, b2 = b0, b3 = b0;
+         if (has2) {
+            b0 = part[(uint64_t)(k + 0) * count2 + i2];
+            b1 = part[(uint64_t)(k + 1) * count2 + i2];
+            b2 = part[(uint64_t)(k + 2) * count2 + i2];
+            b3 = part[(uint64_t)(k + 3) * count2 + i2];
+         }
+         s0 += ((a0 + a1) + (a2 + a3)); // fixed association: deterministic for a given nsplit
+         s1 += ((b0 + b1) + (b2 + b3));
       }
-      out[i] = s;
+      for (; k < nsplit; k++) {
+         s0 += part[(uint64_t)k * count2 + i];
+         if (has2) s1 += part[(uint64_t)k * count2 + i2];
+      }
+      out[i] = s0;
+      if (has2) out[i2] = s1;
    }
 }
 
@@ -544,10 +628,11 @@ void reduce_sum(const double *part, double *out, uint64_t count, int nsplit, hip
 {
    if (count == 0) return;
    const uint64_t count2 = count / 2; // all our buffers have even element counts
-   uint64_t blocks = (count2 + 255) / 256;
-   if (blocks > 4096) blocks = 4096;
-   hipLaunchKernelGGL(k_reduce_sum, dim3((unsigned)blocks), dim3(256), 0, stream,
-                      reinterpret_cast<const double2 *>(part), reinterpret_cast<double2 *>(out), count2, nsplit);
+   uint64_t blocks = (count2 + 511) / 512;
+   if (blocks > 2048) blocks = 2048;
+   if (blocks == 0) blocks = 1;
+   hipLaunchKernelGGL(k_reduce_sum, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const d2 *>(part),
+                      reinterpret_cast<d2 *>(out), count2, nsplit);
    HIP_CHECK_LAUNCH();
 }
 

@@ -20,18 +20,19 @@ void bed_stats(const uint8_t *packed, size_t pitch, uint64_t N, uint64_t P_g, in
 void lut_from_meansd(const double *mean, const double *sd, uint64_t P_g, double *lut, hipStream_t stream);
 
 // K2: Tpart[split][P_pad][b] = X^T B over the split's sample chunks.   b = 16*NT, NT in 1..4
-//   B: [N_pad][b] row-major.  nsplit==1 writes the final T directly.
+//   B: [N_pad][b] row-major.  nsplit==1 writes the final T directly.  fp32: v_mfma_f32 products / per-chunk fp32
+//   accumulation folded into fp64 accumulators (FPCA_ACCUM_FP32), else everything fp64.
 void xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *B, double *Tpart, uint64_t N_pad,
-          uint64_t P_pad, int b, int nsplit, hipStream_t stream);
+          uint64_t P_pad, int b, int nsplit, bool fp32, hipStream_t stream);
 // K3: Ypart[split][N_pad][b] = X T over the split's SNP chunks.  T: [P_pad][b] row-major
 void x_t(const uint8_t *packed, size_t pitch, const double *lut, const double *T, double *Ypart, uint64_t N_pad,
-         uint64_t P_pad, int b, int nsplit, hipStream_t stream);
+         uint64_t P_pad, int b, int nsplit, bool fp32, hipStream_t stream);
 // out[i] = sum_s part[s*count + i]   (deterministic split-K combine)
 void reduce_sum(const double *part, double *out, uint64_t count, int nsplit, hipStream_t stream);
 
 // heuristics (host): number of splits for K2 / K3 given the problem and the chip (256 CUs, 2 WGs/CU)
-int xt_b_splits(uint64_t N_pad, uint64_t P_pad, int b);
-int x_t_splits(uint64_t N_pad, uint64_t P_pad, int b);
+int xt_b_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32);
+int x_t_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32);
 
 // K4 helpers on row-major [N_pad][b] blocks ------------------------------------------------------------
 // part[split][q][b][b] (row-major p,c) = A_q^T W over the split's rows; `blocks` = device array of nq pointers

@@ -174,3 +174,28 @@ def test_linearity_at_scale(fp):
     s1, s2 = np.sum(u * Av), np.sum(Au * v)
     assert abs(s1 - s2) <= 1e-10 * abs(s1)
     ctx.close()
+
+
+@pytest.mark.parametrize("name,b", [("data_chr1", 16), ("hapmap3_data", 32), ("hapmap3_data", 48), ("hapmap3_data", 64)])
+def test_fp32_mode_operator_tolerance(golden_dir, name, b, fp, orc):
+    """FPCA_ACCUM_FP32 (BASELINE config 5 "fp32 accumulate"): fp32 MFMA products, fp32 sums within a chunk, fp64 across
+    chunks.  Tolerance: 2e-6 of the output scale per entry (fp32 rounding of the table and of B is 6e-8 relative per
+    product; the observed error is ~1e-7)."""
+    N = fp.count_fam_rows(os.path.join(golden_dir, name + ".fam"))
+    bed = os.path.join(golden_dir, name + ".bed")
+    ctx = fp.Context.from_bed(bed, N, accum="fp32")
+    od = orc.OracleData(bed, N, "binom2")
+    X = od.dense()
+    rng = np.random.default_rng(b)
+    B = rng.standard_normal((N, b))
+    T_ref = X.T @ B
+    T = ctx.apply_xt(B)
+    e_t = np.max(np.abs(T - T_ref)) / np.max(np.abs(T_ref))
+    Z_ref = X @ T_ref
+    Z = ctx.apply_xxt(B)
+    e_z = np.max(np.abs(Z - Z_ref)) / np.max(np.abs(Z_ref))
+    assert 1e-12 < e_t < 2e-6 and 1e-12 < e_z < 2e-6, (e_t, e_z)  # really fp32, and within tolerance
+    ms, _ = ctx.stats()
+    od.dense()
+    assert np.array_equal(ms, od.meansd())  # statistics stay fp64 / bit-exact in both modes
+    ctx.close()

@@ -136,3 +136,18 @@ def test_config2_pca_end_to_end(fp, orc):
             y_ref = op.perform_op(r["U"][:, 0])
             y = sh.apply_xxt(r["U"][:, :1])[:, 0]
             assert np.max(np.abs(y - y_ref)) <= 1e-11 * np.max(np.abs(y_ref))
+
+
+def test_fp32_mode_tolerance_study(golden_dir, fp):
+    """Config-5 style tolerance study at fixture size: eigenvalues of the mixed fp32 path vs the dense golden.
+    north_star: eigenvalues within 1e-6 relative."""
+    for name, k in (("hapmap3_data", 10), ("data_chr1", 20)):
+        g = json.load(open(os.path.join(golden_dir, "golden_%s_binom2.json" % name)))
+        r = fp.flashpca(os.path.join(golden_dir, name), ndim=k, accum="fp32")
+        ev = np.array(g["eigenvalues_div_p"])[:k]
+        err = np.max(np.abs(r["values"] - ev) / ev)
+        assert r["info"]["converged"] == 1
+        assert err < 1e-6, err
+        U5 = np.array(g["U_first5"]).T
+        for c in range(5):
+            assert abs(abs(U5[:, c] @ r["vectors"][:, c]) - 1.0) < 1e-5
