@@ -36,6 +36,8 @@ WORKLOADS = {
                  desc="synthetic .bed-layout matrix, 50000 samples x 20000 SNPs per GPU, k=20 (BASELINE configs[1])"),
     "cfg3": dict(N=500000, P=100000, k=20, b=32, scaling="strong",
                  desc="synthetic 500000 samples x 100000 SNPs total, SNP-sharded across GPUs, k=20 (BASELINE configs[2]/[3])"),
+    "cfg5": dict(N=1000000, P=200000, k=50, b=64, scaling="strong",
+                 desc="synthetic 1000000 samples x 200000 SNPs total, SNP-sharded across GPUs, k=50 (BASELINE configs[4]; use --accum fp32)"),
     "tiny": dict(N=4000, P=3000, k=20, b=32, scaling="weak", desc="smoke-size workload"),
 }
 
@@ -170,6 +172,18 @@ def main():
                     flops_per_launch=flops_launch,
                     packed_gbs=((N + 3) // 4) * P_rank / (ms_dom * 1e-3) / 1e9)
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    if args.accum == "fp64":
+        roofline["peak_measured_pure_mfma_stream"] = 74.3  # profiles/r01_mfma_f64_microbench.txt (2 waves/SIMD)
+    # HBM traffic per launch of the dominant kernel from the committed PMC passes of this workload (bench.py cannot
+    # collect hardware counters itself; scripts/gpu_profile_round.sh does, in separate --pmc runs, as the guide asks)
+    try:
+        if world == 1 and args.accum == "fp64":
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))[args.workload][dom]
+            roofline["traffic"] = pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc)"
+            roofline["algorithmic_bytes"] = float((N + 3) // 4) * P_rank + 8.0 * b * (N + P_rank)
+    except Exception:
+        pass
 
     out = dict(metric="genotype cells/sec (N x P x iters) for k=20 PCA", value=value, unit="cells/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
@@ -215,7 +229,7 @@ def main():
         while True:
             op.perform_op(x)
             nops += 1
-            if time.perf_counter() - tc > args.cpu_seconds or nops >= 200:
+            if time.perf_counter() - tc > args.cpu_seconds or nops >= 5000:
                 break
         tc = time.perf_counter() - tc
         out["cpu_baseline"] = dict(value=float(N) * P_s * nops / tc, unit="cells/s", cores=1, kind="port",
