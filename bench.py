@@ -89,7 +89,7 @@ def main():
         P_rank, P_total, snp_begin = hi - lo, w["P"], lo
 
     t_gen = time.time()
-    ctx = fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=2 * k, device=local_rank, accum=args.accum)
+    ctx = fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=min(2 * k, 64), device=local_rank, accum=args.accum)
     ctx.set_total_snps(P_total)
     ctx.stats()
     t_gen = time.time() - t_gen
@@ -216,7 +216,7 @@ def main():
 
         O.build()
         P_s = min(P_rank, 1000)
-        with fp.Context.synthetic(N, P_s, snp_begin=0, n_pop=2 * k, device=local_rank) as sh:
+        with fp.Context.synthetic(N, P_s, snp_begin=0, n_pop=min(2 * k, 64), device=local_rank) as sh:
             packed = sh.download_packed()
         od = O.OracleData(packed=packed, N=N, P=P_s, stand="binom2")
         bs = O.lib().orc_default_block_size(N, P_total, k, 0, 2048) or 1  # flashpca.cpp:636-686 on the FULL problem
