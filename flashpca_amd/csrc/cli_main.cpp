@@ -4,7 +4,7 @@
 // suffix .txt), same stdout milestones and the same output files/format (eigenvalues / eigenvectors / pcs / pve
 // [/ loadings / meansd], flashpca.cpp:755-878).  Host C++ only: all arithmetic goes through the C ABI of libfpca.so
 // (include/fpca.h); there is no CPU compute path.  Modes outside the PCA hot path (--scca, --ucca) are refused.
-// New, MI355X-specific flags: --device, --blockvec, --maxblocks.  --memory/--blocksize/--batch/--numthreads are
+// New, MI355X-specific flags: --device, --blockvec, --maxblocks, --accum.  --memory/--blocksize/--batch/--numthreads are
 // accepted for compatibility; the packed matrix is always fully resident in HBM so they have no effect.
 #include <cerrno>
 #include <cmath>
@@ -83,6 +83,7 @@ const OptSpec OPTS[] = {
    {"device", 0, true, "HIP device index [0]"},
    {"blockvec", 0, true, "block width of the eigensolver: 16, 32, 48 or 64 [smallest multiple of 16 >= ndim+4]"},
    {"maxblocks", 0, true, "basis cap (in blocks) before a thick restart [automatic]"},
+   {"accum", 0, true, "arithmetic of the two genotype GEMMs [fp64 | fp32]: fp32 = fp32 MFMA products, fp64 long accumulation"},
 };
 
 const OptSpec *find_long(const std::string &n)
@@ -362,6 +363,16 @@ int main(int argc, char *argv[])
       const int device = has("device") ? (int)to_long(vm, "device") : 0;
       const int blockvec = has("blockvec") ? (int)to_long(vm, "blockvec") : 0;
       const int maxblocks = has("maxblocks") ? (int)to_long(vm, "maxblocks") : 0;
+      int accum = FPCA_ACCUM_FP64;
+      if (has("accum")) {
+         const std::string m = vm["accum"];
+         if (m == "fp64") accum = FPCA_ACCUM_FP64;
+         else if (m == "fp32") accum = FPCA_ACCUM_FP32;
+         else {
+            std::cerr << "Error: unknown accumulate mode (--accum): " << m << std::endl;
+            return EXIT_FAILURE;
+         }
+      }
 
       // ---- end of command line parsing -------------------------------------------------------------------
       std::cout << timestamp() << "Start flashpca (version " << FLASHPCA_VERSION << ")" << std::endl;
@@ -377,7 +388,7 @@ int main(int argc, char *argv[])
 
       fpca_ctx *ctx = nullptr;
       uint64_t nsnps = 0;
-      fpca_ok(fpca_create_from_bed(&ctx, geno_file.c_str(), N, 0, 0, stand_method_x, device, FPCA_ACCUM_FP64, &nsnps));
+      fpca_ok(fpca_create_from_bed(&ctx, geno_file.c_str(), N, 0, 0, stand_method_x, device, accum, &nsnps));
       verbose && std::cout << timestamp() << "Detected BED file: " << geno_file << " with " << N << " samples, " << nsnps << " SNPs." << std::endl;
       if (verbose) {
          char name[256];

@@ -34,6 +34,7 @@ def test_cli_flag_errors(built_lib):
                        (["--memory", "10", "--blocksize", "5"], "cannot specify both --memory and --blocksize"),
                        (["--check", "--project"], "conflicting modes requested"),
                        (["--project"], "SNP-loadings must be specified using --inload"),
+                       (["--accum", "bf16"], "unknown accumulate mode (--accum): bf16"),
                        (["--scca"], "outside the PCA path")):
         r = run(["--bfile", DATA, "--notime"] + extra)
         assert r.returncode == 1, (extra, r.stderr)
@@ -88,6 +89,11 @@ def test_cli_end_to_end(tmp_path, built_lib):
     assert pr[0] == pcs[0]
     PR = np.array([l.split("\t")[2:] for l in pr[1:]], dtype=float)
     assert np.max(np.abs(PR - PC)) < 1e-4
+    # mixed fp32 mode: same files, eigenvalues identical at the 7 printed digits
+    r = run(["--bfile", DATA, "--ndim", "10", "--accum", "fp32", "--suffix", "_fp32.txt", "--notime"], cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    ev32 = np.loadtxt(tmp_path / "eigenvalues_fp32.txt")
+    assert np.allclose(ev32, ev, rtol=1e-6)
     # ndim limit (flashpca.cpp:623-633)
     r = run(["--bfile", DATA, "--ndim", "500", "--notime"], cwd=tmp_path)
     assert r.returncode == 1 and "You asked for 500 dimensions, but only 478allowed" in r.stderr
