@@ -333,9 +333,9 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
          }
 }
 
-static int pick_splits(uint64_t tiles, uint64_t chunks, int min_chunks, int max_splits)
+// slots = workgroups the chip holds at once (256 CUs x resident workgroups per CU for this kernel's registers / LDS)
+static int pick_splits(uint64_t tiles, uint64_t chunks, int min_chunks, int max_splits, uint64_t slots)
 {
-   const uint64_t slots = 512; // 256 CUs x 2 resident workgroups
    uint64_t best_t = ~0ull;
    int best = 1;
    for (int s = 1; s <= max_splits && (uint64_t)s <= chunks; s++) {
@@ -345,7 +345,7 @@ static int pick_splits(uint64_t tiles, uint64_t chunks, int min_chunks, int max_
       uint64_t rounds = (tiles * seff + slots - 1) / slots;
       // time in 1/64 chunk units: every workgroup pays ~2 chunks of fill/drain on top of its cps chunks, and
       // every extra partial costs a write + a read of the output in the combine pass
-      uint64_t t = rounds * (cps + 2) * 64 + (seff > 1 ? seff * 24 : 0);
+      uint64_t t = rounds * (cps * 64 + 96) + (seff > 1 ? seff * 24 : 0);
       if (t < best_t) {
          best_t = t;
          best = (int)seff;
@@ -360,7 +360,9 @@ int xt_b_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32)
    const int tile = (fp32 && b >= 48) ? 128 : 256;
    static const int forced = env_int("FPCA_XT_SPLITS", 0);
    if (forced > 0) return (int)std::min<uint64_t>(forced, N_pad / kc);
-   return pick_splits(P_pad / tile, N_pad / kc, 4, 64);
+   // fp64 with b <= 32 needs 145 VGPRs and 40 KB of LDS: three workgroups per CU are resident
+   const uint64_t slots = (!fp32 && b <= 32) ? 768 : 512;
+   return pick_splits(P_pad / tile, N_pad / kc, 4, 64, slots);
 }
 
 template <typename RT, int NT> struct XtMt {
@@ -546,7 +548,7 @@ int x_t_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32)
 {
    static const int forced = env_int("FPCA_X_SPLITS", 0);
    if (forced > 0) return (int)std::min<uint64_t>(forced, P_pad / x_t_kc(b, fp32));
-   return pick_splits(N_pad / (64 * x_t_mt(b, fp32)), P_pad / x_t_kc(b, fp32), 4, 64);
+   return pick_splits(N_pad / (64 * x_t_mt(b, fp32)), P_pad / x_t_kc(b, fp32), 4, 64, 512);
 }
 
 template <typename RT, int NT>
