@@ -151,3 +151,30 @@ def test_fp32_mode_tolerance_study(golden_dir, fp):
         U5 = np.array(g["U_first5"]).T
         for c in range(5):
             assert abs(abs(U5[:, c] @ r["vectors"][:, c]) - 1.0) < 1e-5
+
+
+def test_config3_full_size_properties(fp):
+    """BASELINE config 3 (500,000 x 100,000, k=20) at full size, where no CPU oracle run is possible: size-independent
+    properties of the operator (symmetry, linearity, shard additivity) and the reference's own --check quantity
+    (randompca.cpp:663-703) for the converged pairs; plus fp64 vs mixed-fp32 agreement (tolerance study)."""
+    N, P, k = 500000, 100000, 20
+    rng = np.random.default_rng(3)
+    u = rng.standard_normal((N, 2))
+    with fp.Context.synthetic(N, P) as ctx:
+        Au = ctx.apply_xxt(u)
+        lin = ctx.apply_xxt(u @ np.array([[2.0], [-0.5]]))
+        assert np.max(np.abs(lin[:, 0] - (2.0 * Au[:, 0] - 0.5 * Au[:, 1]))) <= 1e-11 * np.max(np.abs(lin))
+        s1, s2 = u[:, 0] @ Au[:, 1], Au[:, 0] @ u[:, 1]
+        assert abs(s1 - s2) <= 1e-10 * max(abs(s1), np.linalg.norm(Au[:, 0]) * np.linalg.norm(u[:, 1]) * 1e-3)
+        r = ctx.pca(ndim=k)
+        assert r["info"]["converged"] == 1 and r["info"]["block_applies"] <= 12
+        err, mse, rmse = ctx.check(r["U"], r["d"])
+        assert np.all(np.sqrt(err) <= 1.01e-6 * r["d"])
+        d64 = r["d"]
+    # the same matrix in two SNP shards: partial products add up (svdwide.cpp:48-62), i.e. the multi-GPU identity
+    with fp.Context.synthetic(N, 60000, snp_begin=0) as a, fp.Context.synthetic(N, 40000, snp_begin=60000) as b:
+        s = a.apply_xxt(u[:, :1]) + b.apply_xxt(u[:, :1])
+        assert np.max(np.abs(s[:, 0] - Au[:, 0])) <= 1e-11 * np.max(np.abs(Au[:, 0]))
+    with fp.Context.synthetic(N, P, accum="fp32") as c32:
+        r32 = c32.pca(ndim=k)
+        assert np.max(np.abs(r32["d"] - d64) / d64) < 1e-7
