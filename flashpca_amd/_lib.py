@@ -14,6 +14,7 @@ CLI_PATH = os.path.join(HERE, "_build", "flashpca")
 CSRC = os.path.join(HERE, "csrc")
 
 STANDARDISE = {"binom": 2, "binom2": 3}
+STANDARDISE_DENSE = {"none": 0, "sd": 1, "binom": 2, "binom2": 3, "center": 4}
 DIVISOR = {"none": 0, "n1": 1, "p": 2}
 UNIQUE_ID_BYTES = 128
 
@@ -71,6 +72,7 @@ SIGNATURES = {
     "fpca_create": (_I, [C.POINTER(_P), _P, _U64, _U64, _I, _I, _I]),
     "fpca_create_from_bed": (_I, [C.POINTER(_P), C.c_char_p, _U64, _U64, _U64, _I, _I, _I, C.POINTER(_U64)]),
     "fpca_create_synthetic": (_I, [C.POINTER(_P), _U64, _U64, _U64, _U64, _I, _D, _D, _I, _I, _I]),
+    "fpca_create_dense": (_I, [C.POINTER(_P), _P, C.c_int64, _U64, _U64, _I, _I]),
     "fpca_destroy": (None, [_P]),
     "fpca_nsamples": (_U64, [_P]),
     "fpca_nsnps": (_U64, [_P]),

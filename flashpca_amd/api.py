@@ -57,6 +57,14 @@ class Context:
         return c
 
     @classmethod
+    def from_dense(cls, X, stand="binom2", device=0):
+        """In-memory N x P fp64 matrix (NaN = missing), standardised on the GPU like standardise() (util.cpp:24-192)."""
+        X = np.asfortranarray(X, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib().fpca_create_dense(C.byref(h), _p(X), X.shape[0], X.shape[0], X.shape[1], _lib.STANDARDISE_DENSE[stand], device))
+        return cls(h)
+
+    @classmethod
     def synthetic(cls, N, P, snp_begin=0, seed=20260928, n_pop=40, fst=0.05, missing_rate=0.001, stand="binom2", device=0,
                   accum="fp64"):
         h = C.c_void_p()
@@ -203,16 +211,22 @@ def flashpca(X, ndim=10, stand="binom2", divisor="p", maxiter=500, tol=1e-6, do_
     """PCA of a PLINK fileset; mirrors flashpca() of the reference's R package for the PLINK-prefix input
     (flashpcaR/R/flashpca.R:99-204 -> flashpca_plink_internal, flashpcaR/src/flashpca.cpp:96-197).
 
-    X: PLINK root name (X.bed / X.bim / X.fam).  Returns values, vectors, projection, loadings, center, scale, pve.
+    X: PLINK root name (X.bed / X.bim / X.fam), or a numeric N x P matrix (NaN = missing; the R function's matrix
+    input, flashpcaR/src/flashpca.cpp:17-93, which also accepts stand = "sd" / "center" / "none").
+    Returns values, vectors, projection, loadings, center, scale, pve.
     """
-    if not isinstance(X, str):
-        raise TypeError("X must be the root name of a PLINK fileset (dense matrix input is not part of the hot path)")
-    if stand not in STANDARDISE:
-        raise ValueError("stand must be one of %s" % sorted(STANDARDISE))  # R: match.arg
     if divisor not in DIVISOR:
         raise ValueError("divisor must be one of %s" % sorted(DIVISOR))
-    N = count_fam_rows(X + ".fam")
-    with Context.from_bed(X + ".bed", N, stand=stand, device=device, accum=accum) as ctx:
+    if isinstance(X, str):
+        if stand not in STANDARDISE:
+            raise ValueError("stand must be one of %s" % sorted(STANDARDISE))  # R: match.arg
+        N = count_fam_rows(X + ".fam")
+        ctx = Context.from_bed(X + ".bed", N, stand=stand, device=device, accum=accum)
+    else:
+        if stand not in _lib.STANDARDISE_DENSE:
+            raise ValueError("stand must be one of %s" % sorted(_lib.STANDARDISE_DENSE))
+        ctx = Context.from_dense(np.asarray(X, dtype=np.float64), stand=stand, device=device)
+    with ctx:
         r = ctx.pca(ndim=ndim, tol=tol, maxiter=maxiter, div=divisor, do_loadings=do_loadings, verbose=int(verbose),
                     **solver_kw)
     res = dict(values=r["d"], vectors=r["U"], projection=r["Px"], loadings=r["V"], pve=r["pve"], info=r["info"])

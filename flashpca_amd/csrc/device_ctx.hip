@@ -87,6 +87,8 @@ struct fpca_ctx {
    size_t pitch = 0;
    int stand = FPCA_STANDARDISE_BINOM2, accum = FPCA_ACCUM_FP64;
    uint8_t *d_packed = nullptr;
+   double *d_Xd = nullptr; // dense (in-memory matrix) mode: standardised fp64 matrix [P_pad][N_pad]; d_packed unused
+   bool dense = false;
    double *d_lut = nullptr, *d_mean = nullptr, *d_sd = nullptr, *d_sumsq = nullptr;
    bool stats_done = false;
    double trace_local = 0;
@@ -131,11 +133,13 @@ struct fpca_ctx {
 
 namespace {
 
-void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int device, int accum)
+void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int device, int accum, bool dense = false)
 {
    if (N == 0) throw Error(FPCA_EINVAL, "N must be > 0");
-   if (stand != FPCA_STANDARDISE_BINOM && stand != FPCA_STANDARDISE_BINOM2)
+   if (!dense && stand != FPCA_STANDARDISE_BINOM && stand != FPCA_STANDARDISE_BINOM2)
       throw Error(FPCA_EINVAL, "unknown standardisation method: " + std::to_string(stand)); // data.cpp:283-288
+   if (dense && (stand < FPCA_STANDARDISE_NONE || stand > FPCA_STANDARDISE_CENTER))
+      throw Error(FPCA_EINVAL, "unknown standardization method"); // util.cpp:183
    if (accum != FPCA_ACCUM_FP64 && accum != FPCA_ACCUM_FP32) throw Error(FPCA_EINVAL, "accum must be FPCA_ACCUM_FP64 or FPCA_ACCUM_FP32");
    int ndev = 0;
    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -156,9 +160,15 @@ void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int devi
    c->P_pad = round_up(std::max<uint64_t>(P_g, 1), SNP_ALIGN);
    c->stand = stand;
    c->accum = accum;
+   c->dense = dense;
    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-   HIP_CHECK(hipMalloc(&c->d_packed, c->pitch * c->P_pad));
-   HIP_CHECK(hipMemsetAsync(c->d_packed, PAD_BYTE, c->pitch * c->P_pad, c->stream));
+   if (dense) {
+      HIP_CHECK(hipMalloc(&c->d_Xd, (size_t)c->P_pad * c->N_pad * sizeof(double)));
+      HIP_CHECK(hipMemsetAsync(c->d_Xd, 0, (size_t)c->P_pad * c->N_pad * sizeof(double), c->stream));
+   } else {
+      HIP_CHECK(hipMalloc(&c->d_packed, c->pitch * c->P_pad));
+      HIP_CHECK(hipMemsetAsync(c->d_packed, PAD_BYTE, c->pitch * c->P_pad, c->stream));
+   }
    HIP_CHECK(hipMalloc(&c->d_lut, c->P_pad * 4 * sizeof(double)));
    HIP_CHECK(hipMalloc(&c->d_mean, c->P_pad * sizeof(double)));
    HIP_CHECK(hipMalloc(&c->d_sd, c->P_pad * sizeof(double)));
@@ -186,7 +196,7 @@ void ctx_free(fpca_ctx *c)
       } catch (...) {
       }
    }
-   void *ptrs[] = {c->d_packed, c->d_lut, c->d_mean, c->d_sd,   c->d_sumsq, c->d_T,
+   void *ptrs[] = {c->d_Xd, c->d_packed, c->d_lut, c->d_mean, c->d_sd,   c->d_sumsq, c->d_T,
                    c->d_part,   c->d_stage, c->d_io_a, c->d_io_b, c->d_small};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
@@ -220,18 +230,24 @@ void ensure_stats(fpca_ctx *c)
 void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t s, hipEvent_t *ev)
 {
    ensure_stats(c);
-   const int s2 = kern::xt_b_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
-   const int s3 = kern::x_t_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
+   const int s2 = c->dense ? kern::xt_b_dense_splits(c->N_pad, c->P_pad) : kern::xt_b_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
+   const int s3 = c->dense ? kern::x_t_dense_splits(c->N_pad, c->P_pad) : kern::x_t_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
    c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
    size_t need = 0;
    if (s2 > 1) need = std::max(need, (size_t)s2 * c->P_pad * b);
    if (s3 > 1) need = std::max(need, (size_t)s3 * c->N_pad * b);
    if (need) c->ensure(c->d_part, c->part_cap, need);
    if (ev) HIP_CHECK(hipEventRecord(ev[0], s));
-   kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, c->accum == FPCA_ACCUM_FP32, s);
+   if (c->dense)
+      kern::xt_b_dense(c->d_Xd, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, s);
+   else
+      kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, c->accum == FPCA_ACCUM_FP32, s);
    if (s2 > 1) kern::reduce_sum(c->d_part, c->d_T, (uint64_t)c->P_pad * b, s2, s);
    if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
-   kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, c->accum == FPCA_ACCUM_FP32, s);
+   if (c->dense)
+      kern::x_t_dense(c->d_Xd, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, s);
+   else
+      kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, c->accum == FPCA_ACCUM_FP32, s);
    if (s3 > 1) kern::reduce_sum(c->d_part, dY, (uint64_t)c->N_pad * b, s3, s);
    if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
    if (c->multi()) c->allreduce(dY, (uint64_t)c->N_pad * b, s);
@@ -241,19 +257,25 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
 void xt_dev(fpca_ctx *c, const double *dB, int b, hipStream_t s)
 {
    ensure_stats(c);
-   const int s2 = kern::xt_b_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
+   const int s2 = c->dense ? kern::xt_b_dense_splits(c->N_pad, c->P_pad) : kern::xt_b_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
    c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
    if (s2 > 1) c->ensure(c->d_part, c->part_cap, (size_t)s2 * c->P_pad * b);
-   kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, c->accum == FPCA_ACCUM_FP32, s);
+   if (c->dense)
+      kern::xt_b_dense(c->d_Xd, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, s);
+   else
+      kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, c->accum == FPCA_ACCUM_FP32, s);
    if (s2 > 1) kern::reduce_sum(c->d_part, c->d_T, (uint64_t)c->P_pad * b, s2, s);
 }
 
 void x_dev(fpca_ctx *c, int b, double *dY, hipStream_t s)
 {
    ensure_stats(c);
-   const int s3 = kern::x_t_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
+   const int s3 = c->dense ? kern::x_t_dense_splits(c->N_pad, c->P_pad) : kern::x_t_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
    if (s3 > 1) c->ensure(c->d_part, c->part_cap, (size_t)s3 * c->N_pad * b);
-   kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, c->accum == FPCA_ACCUM_FP32, s);
+   if (c->dense)
+      kern::x_t_dense(c->d_Xd, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, s);
+   else
+      kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, c->accum == FPCA_ACCUM_FP32, s);
    if (s3 > 1) kern::reduce_sum(c->d_part, dY, (uint64_t)c->N_pad * b, s3, s);
 }
 
@@ -554,6 +576,38 @@ int fpca_create_synthetic(fpca_ctx **out, uint64_t N, uint64_t snp_begin, uint64
    return FPCA_OK;
 }
 
+int fpca_create_dense(fpca_ctx **out, const double *X, int64_t ldx, uint64_t N, uint64_t P_g, int stand_method, int device)
+{
+   if (!out) return FPCA_EINVAL;
+   *out = nullptr;
+   fpca_ctx *c = new fpca_ctx();
+   int rc = guarded([&] {
+      if (!X || ldx < (int64_t)N || P_g == 0) throw Error(FPCA_EINVAL, "bad argument to fpca_create_dense");
+      ctx_alloc_common(c, N, P_g, stand_method, device, FPCA_ACCUM_FP64, true);
+      // column-major N x P on the host == row-major [P][N] : one strided copy into the padded [P_pad][N_pad] image
+      HIP_CHECK(hipMemcpy2DAsync(c->d_Xd, c->N_pad * sizeof(double), X, (size_t)ldx * sizeof(double), N * sizeof(double), P_g,
+                                 hipMemcpyHostToDevice, c->stream));
+      kern::dense_standardise(c->d_Xd, c->N_pad, N, P_g, stand_method, c->d_mean, c->d_sd, c->d_sumsq, c->stream);
+      std::vector<double> ss(P_g);
+      HIP_CHECK(hipMemcpyAsync(ss.data(), c->d_sumsq, P_g * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIP_CHECK(hipStreamSynchronize(c->stream));
+      double tot = 0;
+      for (size_t i0 = 0; i0 < ss.size(); i0 += 1024) {
+         double sblk = 0;
+         for (size_t i = i0; i < std::min(ss.size(), i0 + 1024); i++) sblk += ss[i];
+         tot += sblk;
+      }
+      c->trace_local = tot; // randompca.cpp:154: sum X^2 of the standardised matrix
+      c->stats_done = true;
+   });
+   if (rc != FPCA_OK) {
+      ctx_free(c);
+      return rc;
+   }
+   *out = c;
+   return FPCA_OK;
+}
+
 void fpca_destroy(fpca_ctx *ctx) { ctx_free(ctx); }
 
 uint64_t fpca_nsamples(const fpca_ctx *ctx) { return ctx ? ctx->N : 0; }
@@ -573,6 +627,7 @@ int fpca_download_packed(fpca_ctx *ctx, uint8_t *out)
 {
    return guarded([&] {
       HIP_CHECK(hipSetDevice(ctx->device));
+      if (ctx->dense) throw Error(FPCA_EINVAL, "this context holds a dense matrix, not a packed stream");
       if (ctx->P_g == 0) return;
       HIP_CHECK(hipMemcpy2D(out, ctx->np, ctx->d_packed, ctx->pitch, ctx->np, ctx->P_g, hipMemcpyDeviceToHost));
       // the pad bits of the last byte were rewritten to "missing" on upload; PLINK writes them as 0
@@ -601,6 +656,7 @@ int fpca_set_meansd(fpca_ctx *ctx, const double *mean_sd)
    return guarded([&] {
       HIP_CHECK(hipSetDevice(ctx->device));
       if (!mean_sd) throw Error(FPCA_EINVAL, "mean_sd is NULL");
+      if (ctx->dense) throw Error(FPCA_EINVAL, "preloaded mean/sd applies to packed genotypes only");
       HIP_CHECK(hipMemcpy(ctx->d_mean, mean_sd, ctx->P_g * sizeof(double), hipMemcpyHostToDevice));
       HIP_CHECK(hipMemcpy(ctx->d_sd, mean_sd + ctx->P_g, ctx->P_g * sizeof(double), hipMemcpyHostToDevice));
       kern::lut_from_meansd(ctx->d_mean, ctx->d_sd, ctx->P_g, ctx->d_lut, ctx->stream);

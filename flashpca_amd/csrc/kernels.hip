@@ -639,6 +639,273 @@ void reduce_sum(const double *part, double *out, uint64_t count, int nsplit, hip
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dense (in-memory matrix) path: RandomPCA::pca_fast(MatrixXd&) (randompca.cpp:121-166) + standardise()
+// (util.cpp:24-192) + SVDWide::perform_op (svdwide.cpp:4-12).  The fp64 matrix is kept in HBM as Xd[P_pad][N_pad]
+// (one row per column of the caller's N x P column-major matrix, zero padded), standardised in place once; the two
+// products are then plain tall-skinny FP64 MFMA GEMMs that read Xd once each and are HBM-bound (2 b flops per 8
+// bytes = 8 flop/B at b = 32, below the ~10 flop/B ridge).
+
+// util.cpp:24-192, one workgroup per column; method: 0 none, 1 sd, 2 binom, 3 binom2, 4 center.  NaN = missing.
+__global__ __launch_bounds__(256) void k_dense_standardise(double *__restrict__ Xd, uint64_t N_pad, uint64_t N, int method,
+                                                            double *__restrict__ mean_out, double *__restrict__ sd_out,
+                                                            double *__restrict__ sumsq_out)
+{
+   double *col = Xd + (uint64_t)blockIdx.x * N_pad;
+   __shared__ double red[3][4];
+   __shared__ double bc[2];
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   // pass 1: NaN-aware sums (sd uses the shifted-data variance with K = 1, util.cpp:84-100)
+   double s1 = 0, s2 = 0, cnt = 0;
+   for (uint64_t i = threadIdx.x; i < N; i += 256) {
+      const double x = col[i];
+      if (!isnan(x)) {
+         const double xs = (method == 1) ? x - 1.0 : x;
+         s1 += xs;
+         s2 += xs * xs;
+         cnt += 1.0;
+      }
+   }
+   for (int off = 32; off > 0; off >>= 1) {
+      s1 += __shfl_down(s1, off);
+      s2 += __shfl_down(s2, off);
+      cnt += __shfl_down(cnt, off);
+   }
+   if (lane == 0) {
+      red[0][wave] = s1;
+      red[1][wave] = s2;
+      red[2][wave] = cnt;
+   }
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      const double sum = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+      const double sum_sqr = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+      const double nj = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+      double mean = 0.0, sd = 1.0;
+      if (method == 0 || method == 4)
+         mean = sum / nj;
+      else if (method == 1) {
+         const double varj = (sum_sqr - (sum * sum) / nj) / (nj - 1.0);
+         mean = (sum + nj) / nj;
+         sd = sqrt(varj);
+      } else {
+         mean = sum / nj;
+         const double r = mean / 2.0;
+         sd = sqrt((method == 2 ? 1.0 : 2.0) * r * (1.0 - r));
+      }
+      bc[0] = mean;
+      bc[1] = sd;
+      mean_out[blockIdx.x] = mean;
+      sd_out[blockIdx.x] = sd;
+   }
+   __syncthreads();
+   const double mean = bc[0], sd = bc[1];
+   // pass 2: impute + standardise in place; accumulate sum of squares (trace, randompca.cpp:154)
+   double sq = 0;
+   for (uint64_t i = threadIdx.x; i < N; i += 256) {
+      const double x = col[i];
+      double y;
+      if (method == 0)
+         y = isnan(x) ? mean : x;
+      else if (method == 4)
+         y = isnan(x) ? 0.0 : x - mean;
+      else
+         y = isnan(x) ? 0.0 : (sd > 1e-9 ? (x - mean) / sd : mean); // util.cpp:107-113 / 141-147
+      col[i] = y;
+      sq += y * y;
+   }
+   for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
+   __syncthreads();
+   if (lane == 0) red[0][wave] = sq;
+   __syncthreads();
+   if (threadIdx.x == 0) sumsq_out[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+}
+
+void dense_standardise(double *Xd, uint64_t N_pad, uint64_t N, uint64_t P_g, int method, double *mean, double *sd,
+                       double *sumsq, hipStream_t stream)
+{
+   if (P_g == 0) return;
+   hipLaunchKernelGGL(k_dense_standardise, dim3((unsigned)P_g), dim3(256), 0, stream, Xd, N_pad, N, method, mean, sd, sumsq);
+   HIP_CHECK_LAUNCH();
+}
+
+// K2d: T[j][c] = sum_s Xd[j][s] B[s][c].  Workgroup = 128 columns-of-X (2 m-tiles per wave); lane (i, kq) streams
+// 4 consecutive doubles of ITS row per 16-sample step (16 lanes x 32 B... a wave reads 16 rows x 128 B = full lines),
+// with the K order permuted per lane group as in the packed kernel; the B tile goes through LDS.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_xt_b_dense(const double *__restrict__ Xd, uint64_t N_pad,
+                                                        const double *__restrict__ B, double *__restrict__ Tpart,
+                                                        uint64_t P_pad, int chunks_total, int chunks_per_split)
+{
+   constexpr int b = 16 * NT;
+   constexpr int MT = 2;
+   constexpr int KC = 64; // samples per chunk: lane group kq owns samples 16 kq .. 16 kq + 15
+   constexpr int NLOAD = KC * b * 8 / (256 * 16);
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+   double *sB = reinterpret_cast<double *>(smem_raw); // [KC][b]
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int li = lane & 15, kq = lane >> 4;
+   const uint64_t j0 = (uint64_t)blockIdx.x * (64 * MT) + (uint64_t)wave * (16 * MT);
+   const int c_begin = blockIdx.y * chunks_per_split;
+   int c_end = c_begin + chunks_per_split;
+   if (c_end > chunks_total) c_end = chunks_total;
+   const double *rowp[MT];
+#pragma unroll
+   for (int m = 0; m < MT; m++) rowp[m] = Xd + (j0 + m * 16 + li) * N_pad + kq * 16;
+   d4 acc[MT][NT];
+#pragma unroll
+   for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[m][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+   d2 xn[MT][8], breg[NLOAD];
+#define FPCA_XTBD_ISSUE(cc)                                                                                   \
+   {                                                                                                           \
+      _Pragma("unroll") for (int m = 0; m < MT; m++)                                                           \
+      {                                                                                                        \
+         const d2 *pp = reinterpret_cast<const d2 *>(rowp[m] + (size_t)(cc) * KC);                             \
+         _Pragma("unroll") for (int h = 0; h < 8; h++) xn[m][h] = pp[h];                                       \
+      }                                                                                                        \
+      const d2 *src = reinterpret_cast<const d2 *>(B + (size_t)(cc) * KC * b);                                 \
+      _Pragma("unroll") for (int r = 0; r < NLOAD; r++) breg[r] = src[tid + 256 * r];                          \
+   }
+   if (c_begin < c_end) FPCA_XTBD_ISSUE(c_begin);
+   const double *sB_lane = sB + (size_t)(16 * kq) * b + li;
+   for (int c = c_begin; c < c_end; c++) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < NLOAD; r++) reinterpret_cast<d2 *>(sB)[tid + 256 * r] = breg[r];
+      d2 xc[MT][8];
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+         for (int h = 0; h < 8; h++) xc[m][h] = xn[m][h];
+      __syncthreads();
+      if (c + 1 < c_end) FPCA_XTBD_ISSUE(c + 1);
+#pragma unroll
+      for (int t = 0; t < 16; t++) {
+         double bv[NT];
+#pragma unroll
+         for (int nt = 0; nt < NT; nt++) bv[nt] = sB_lane[(size_t)t * b + nt * 16];
+#pragma unroll
+         for (int m = 0; m < MT; m++) {
+            const double a = xc[m][t >> 1][t & 1];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[m][nt] = FPCA_MFMA(a, bv[nt], acc[m][nt]);
+         }
+      }
+   }
+#undef FPCA_XTBD_ISSUE
+   double *Tout = Tpart + (size_t)blockIdx.y * P_pad * b;
+#pragma unroll
+   for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+         for (int r = 0; r < 4; r++) Tout[(j0 + m * 16 + kq + 4 * r) * b + nt * 16 + li] = acc[m][nt][r];
+}
+
+// K3d: Y[s][c] = sum_j Xd[j][s] T[j][c].  Workgroup = 256 samples (wave = 64 = 4 m-tiles); lane (i, kq) owns samples
+// 4i .. 4i+3 of its wave and reads them as one 32-byte piece of row k (16 lanes = 512 contiguous bytes); the T tile
+// (64 rows x b) goes through LDS.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_x_t_dense(const double *__restrict__ Xd, uint64_t N_pad,
+                                                       const double *__restrict__ T, double *__restrict__ Ypart,
+                                                       int chunks_total, int chunks_per_split)
+{
+   constexpr int b = 16 * NT;
+   constexpr int MT = 4;
+   constexpr int KC = 64; // rows of Xd (SNPs) per chunk
+   constexpr int NTL = KC * b * 8 / (256 * 16);
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+   double *sT = reinterpret_cast<double *>(smem_raw); // [KC][b]
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int li = lane & 15, kq = lane >> 4;
+   const uint64_t s0 = (uint64_t)blockIdx.x * 256 + (uint64_t)wave * 64 + 4 * li;
+   const int c_begin = blockIdx.y * chunks_per_split;
+   int c_end = c_begin + chunks_per_split;
+   if (c_end > chunks_total) c_end = chunks_total;
+   d4 acc[MT][NT];
+#pragma unroll
+   for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[m][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+   d2 treg[NTL];
+#define FPCA_XTD_ISSUE(cc)                                                                                    \
+   {                                                                                                           \
+      const d2 *tsrc = reinterpret_cast<const d2 *>(T + (size_t)(cc) * KC * b);                                \
+      _Pragma("unroll") for (int r = 0; r < NTL; r++) treg[r] = tsrc[tid + 256 * r];                           \
+   }
+   if (c_begin < c_end) FPCA_XTD_ISSUE(c_begin);
+   const double *sT_lane = sT + (size_t)kq * b + li;
+   for (int c = c_begin; c < c_end; c++) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < NTL; r++) reinterpret_cast<d2 *>(sT)[tid + 256 * r] = treg[r];
+      __syncthreads();
+      if (c + 1 < c_end) FPCA_XTD_ISSUE(c + 1);
+      const double *xrow = Xd + ((uint64_t)c * KC + kq) * N_pad + s0;
+#pragma unroll 4
+      for (int t = 0; t < KC / 4; t++) {
+         const d2 x01 = reinterpret_cast<const d2 *>(xrow + (size_t)(4 * t) * N_pad)[0];
+         const d2 x23 = reinterpret_cast<const d2 *>(xrow + (size_t)(4 * t) * N_pad)[1];
+         const double xa[4] = {x01.x, x01.y, x23.x, x23.y};
+         double tv[NT];
+#pragma unroll
+         for (int nt = 0; nt < NT; nt++) tv[nt] = sT_lane[(size_t)(4 * t) * b + nt * 16];
+#pragma unroll
+         for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[m][nt] = FPCA_MFMA(xa[m], tv[nt], acc[m][nt]);
+      }
+   }
+#undef FPCA_XTD_ISSUE
+   double *Yout = Ypart + (size_t)blockIdx.y * N_pad * b;
+   const uint64_t s_wave = (uint64_t)blockIdx.x * 256 + (uint64_t)wave * 64;
+#pragma unroll
+   for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+         for (int r = 0; r < 4; r++) Yout[(s_wave + 4 * (kq + 4 * r) + m) * b + nt * 16 + li] = acc[m][nt][r];
+}
+
+int xt_b_dense_splits(uint64_t N_pad, uint64_t P_pad) { return pick_splits(P_pad / 128, N_pad / 64, 8, 64, 768); }
+int x_t_dense_splits(uint64_t N_pad, uint64_t P_pad) { return pick_splits(N_pad / 256, P_pad / 64, 8, 64, 768); }
+
+void xt_b_dense(const double *Xd, const double *B, double *Tpart, uint64_t N_pad, uint64_t P_pad, int b, int nsplit,
+                hipStream_t stream)
+{
+   const int chunks_total = (int)(N_pad / 64);
+   const int cps = (chunks_total + nsplit - 1) / nsplit;
+   dim3 grid((unsigned)(P_pad / 128), (unsigned)nsplit);
+   const size_t smem = (size_t)64 * b * 8;
+   switch (b) {
+   case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xt_b_dense<1>), grid, dim3(256), smem, stream, Xd, N_pad, B, Tpart, P_pad, chunks_total, cps); break;
+   case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xt_b_dense<2>), grid, dim3(256), smem, stream, Xd, N_pad, B, Tpart, P_pad, chunks_total, cps); break;
+   case 48: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xt_b_dense<3>), grid, dim3(256), smem, stream, Xd, N_pad, B, Tpart, P_pad, chunks_total, cps); break;
+   case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xt_b_dense<4>), grid, dim3(256), smem, stream, Xd, N_pad, B, Tpart, P_pad, chunks_total, cps); break;
+   default: throw Error(-1, "xt_b_dense: block width must be 16, 32, 48 or 64");
+   }
+   HIP_CHECK_LAUNCH();
+}
+
+void x_t_dense(const double *Xd, const double *T, double *Ypart, uint64_t N_pad, uint64_t P_pad, int b, int nsplit,
+               hipStream_t stream)
+{
+   const int chunks_total = (int)(P_pad / 64);
+   const int cps = (chunks_total + nsplit - 1) / nsplit;
+   dim3 grid((unsigned)(N_pad / 256), (unsigned)nsplit);
+   const size_t smem = (size_t)64 * b * 8;
+   switch (b) {
+   case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_x_t_dense<1>), grid, dim3(256), smem, stream, Xd, N_pad, T, Ypart, chunks_total, cps); break;
+   case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_x_t_dense<2>), grid, dim3(256), smem, stream, Xd, N_pad, T, Ypart, chunks_total, cps); break;
+   case 48: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_x_t_dense<3>), grid, dim3(256), smem, stream, Xd, N_pad, T, Ypart, chunks_total, cps); break;
+   case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_x_t_dense<4>), grid, dim3(256), smem, stream, Xd, N_pad, T, Ypart, chunks_total, cps); break;
+   default: throw Error(-1, "x_t_dense: block width must be 16, 32, 48 or 64");
+   }
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
 // K4 gram: part[(split*4+wave)][q][p][c] = sum_{rows of the wave} A_q[s][p] W[s][c]
 //   MFMA roles: A[i = p][k = sample] and B[k = sample][j = c] are both read straight from HBM, 16 lanes
 //   covering 128 contiguous bytes of a row; HBM-bound (each A_q read once, W once per q).

@@ -34,6 +34,17 @@ void reduce_sum(const double *part, double *out, uint64_t count, int nsplit, hip
 int xt_b_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32);
 int x_t_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32);
 
+// Dense (in-memory fp64 matrix) path: Xd [P_pad][N_pad] fp64, one row per column of the caller's N x P matrix
+// util.cpp:24-192 in place (method 0 none, 1 sd, 2 binom, 3 binom2, 4 center; NaN = missing); mean/sd/sumsq [P_pad]
+void dense_standardise(double *Xd, uint64_t N_pad, uint64_t N, uint64_t P_g, int method, double *mean, double *sd,
+                       double *sumsq, hipStream_t stream);
+int xt_b_dense_splits(uint64_t N_pad, uint64_t P_pad);
+int x_t_dense_splits(uint64_t N_pad, uint64_t P_pad);
+void xt_b_dense(const double *Xd, const double *B, double *Tpart, uint64_t N_pad, uint64_t P_pad, int b, int nsplit,
+                hipStream_t stream);
+void x_t_dense(const double *Xd, const double *T, double *Ypart, uint64_t N_pad, uint64_t P_pad, int b, int nsplit,
+               hipStream_t stream);
+
 // K4 helpers on row-major [N_pad][b] blocks ------------------------------------------------------------
 // part[split][q][b][b] (row-major p,c) = A_q^T W over the split's rows; `blocks` = device array of nq pointers
 void gram(const double *const *blocks, int nq, const double *W, double *part, uint64_t N_pad, int b, int nsplit,

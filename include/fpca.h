@@ -34,9 +34,13 @@ extern "C" {
 
 #define FPCA_VERSION "0.1.0"
 
-/* standardisation methods: same numeric values as the reference (util.h:34-38) */
+/* standardisation methods: same numeric values as the reference (util.h:34-38); the packed-genotype constructors
+ * accept BINOM / BINOM2 like the CLI (flashpca.cpp:336-349), fpca_create_dense accepts all five */
+#define FPCA_STANDARDISE_NONE 0
+#define FPCA_STANDARDISE_SD 1
 #define FPCA_STANDARDISE_BINOM 2
 #define FPCA_STANDARDISE_BINOM2 3
+#define FPCA_STANDARDISE_CENTER 4
 /* eigenvalue divisor: same numeric values as the reference (randompca.h:41-43) */
 #define FPCA_DIVISOR_NONE 0
 #define FPCA_DIVISOR_N1 1
@@ -82,6 +86,13 @@ int fpca_create_from_bed(fpca_ctx **out, const char *bed_path, uint64_t N, uint6
  * (N, seed, n_pop, fst, missing_rate) matrix can be generated independently on any rank. */
 int fpca_create_synthetic(fpca_ctx **out, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed,
                           int n_pop, double fst, double missing_rate, int stand_method, int device, int accum);
+
+/* In-memory matrix input: replaces RandomPCA::pca_fast(MatrixXd& X, ...) + standardise(X, method) (randompca.cpp:121-166,
+ * util.cpp:24-192; the R entry flashpca(X) for a numeric matrix, flashpcaR/src/flashpca.cpp:17-93).  X is N x P_g fp64
+ * column-major with leading dimension ldx, NaN = missing.  It is copied to HBM and standardised there column by column
+ * exactly as standardise() does (missing -> 0 after standardisation, or -> mean for "none"; sd <= 1e-9 -> the column
+ * becomes its mean); every operator / driver entry point then works on it like on a packed context (fp64 only). */
+int fpca_create_dense(fpca_ctx **out, const double *X, int64_t ldx, uint64_t N, uint64_t P_g, int stand_method, int device);
 
 void fpca_destroy(fpca_ctx *ctx);
 

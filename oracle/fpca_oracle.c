@@ -868,6 +868,79 @@ int orc_check(orc_data *d, uint32_t block_size, int divisor, const double *evec,
    return 0;
 }
 
+/* standardise(MatrixXd&, method) (util.cpp:24-192): column-wise, in place, NaN = missing.  X is n x p column-major;
+ * meansd (p x 2 column-major, mean | sd) may be NULL.  Methods: 0 none, 1 sd, 2 binom, 3 binom2, 4 center.
+ * Returns 0, or -1 for an unknown method (the reference throws "unknown standardization method"). */
+int orc_standardise(double *X, uint64_t n, uint64_t p, int method, double *meansd)
+{
+   if (method < 0 || method > 4) return -1;
+   for (uint64_t j = 0; j < p; j++) {
+      double *col = X + j * n;
+      double mean = 0, sd = 1;
+      if (method == 0 || method == 4) { /* util.cpp:37-71 */
+         uint64_t nj = 0;
+         for (uint64_t i = 0; i < n; i++)
+            if (!isnan(col[i])) {
+               mean += col[i];
+               nj++;
+            }
+         mean /= (double)nj;
+         if (method == 0) {
+            for (uint64_t i = 0; i < n; i++)
+               if (isnan(col[i])) col[i] = mean;
+         } else {
+            for (uint64_t i = 0; i < n; i++) col[i] = isnan(col[i]) ? 0 : col[i] - mean;
+         }
+      } else if (method == 1) { /* util.cpp:72-116: shifted-data variance, K = 1 */
+         double sum = 0, sum_sqr = 0;
+         const double K = 1;
+         uint64_t nj = 0;
+         for (uint64_t i = 0; i < n; i++)
+            if (!isnan(col[i])) {
+               sum += col[i] - K;
+               sum_sqr += (col[i] - K) * (col[i] - K);
+               nj++;
+            }
+         double varj = (sum_sqr - (sum * sum) / (double)nj) / (double)(nj - 1);
+         mean = (sum + K * (double)nj) / (double)nj;
+         sd = sqrt(varj);
+         for (uint64_t i = 0; i < n; i++) {
+            if (isnan(col[i]))
+               col[i] = 0;
+            else if (sd > VAR_TOL)
+               col[i] = (col[i] - mean) / sd;
+            else
+               col[i] = mean;
+         }
+      } else { /* util.cpp:117-150, Price 2006 eqn 3 */
+         const double mult = method == ORC_STANDARDISE_BINOM ? 1 : 2;
+         double sum = 0;
+         uint64_t nj = 0;
+         for (uint64_t i = 0; i < n; i++)
+            if (!isnan(col[i])) {
+               sum += col[i];
+               nj++;
+            }
+         mean = sum / (double)nj;
+         const double r = mean / 2.0;
+         sd = sqrt(mult * r * (1.0 - r));
+         for (uint64_t i = 0; i < n; i++) {
+            if (isnan(col[i]))
+               col[i] = 0;
+            else if (sd > VAR_TOL)
+               col[i] = (col[i] - mean) / sd;
+            else
+               col[i] = mean;
+         }
+      }
+      if (meansd) {
+         meansd[j] = mean;
+         meansd[p + j] = sd;
+      }
+   }
+   return 0;
+}
+
 /* flashpca.cpp:636-686 */
 uint32_t orc_default_block_size(uint64_t N, uint64_t nsnps, int ndim, int do_loadings, int memory_mb)
 {

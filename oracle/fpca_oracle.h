@@ -82,6 +82,9 @@ int orc_pca_fast(orc_data *d, uint32_t block_size, int ndim, int maxiter, double
 int orc_check(orc_data *d, uint32_t block_size, int divisor, const double *evec, const double *eval,
               int k, double *err, double *mse, double *rmse);
 
+/* standardise(MatrixXd&, method) (util.cpp:24-192), in place; methods 0 none, 1 sd, 2 binom, 3 binom2, 4 center */
+int orc_standardise(double *X, uint64_t n, uint64_t p, int method, double *meansd);
+
 /* block size heuristic of the CLI (flashpca.cpp:636-686); returns 0 if memory insufficient */
 uint32_t orc_default_block_size(uint64_t N, uint64_t nsnps, int ndim, int do_loadings, int memory_mb);
 

@@ -75,6 +75,8 @@ def lib():
         L.orc_default_block_size.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
         L.orc_format_number.restype = C.c_int
         L.orc_format_number.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int]
+        L.orc_standardise.restype = C.c_int
+        L.orc_standardise.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
         L.orc_decode_plink.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
         L.orc_decode_plink_simple.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
         _lib = L
@@ -231,6 +233,19 @@ def check(data, evec, evals, block_size, div="p"):
     mse, rmse = C.c_double(0), C.c_double(0)
     lib().orc_check(data.h, int(block_size), DIVISOR[div], _ptr(evec), _ptr(evals), k, _ptr(err), C.byref(mse), C.byref(rmse))
     return err, mse.value, rmse.value
+
+
+STAND_DENSE = {"none": 0, "sd": 1, "binom": 2, "binom2": 3, "center": 4}
+
+
+def standardise(X, stand):
+    """standardise(MatrixXd&, method) (util.cpp:24-192): returns (standardised copy, meansd p x 2)."""
+    Xs = np.array(X, dtype=np.float64, order="F", copy=True)
+    ms = np.zeros((Xs.shape[1], 2), order="F")
+    rc = lib().orc_standardise(_ptr(Xs), Xs.shape[0], Xs.shape[1], STAND_DENSE[stand], _ptr(ms))
+    if rc != 0:
+        raise RuntimeError("unknown standardization method")
+    return Xs, ms
 
 
 def format_number(v, precision=7):
