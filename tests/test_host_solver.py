@@ -139,6 +139,26 @@ def test_text_io_roundtrip(tmp_path):
     assert b"Error reading file" in err.value
 
 
+def test_parallel_writer_is_byte_identical_to_iostream_format(tmp_path):
+    """The chunk-parallel writer must reproduce operator<< under setprecision(p) (== "%.{p}g") for every row."""
+    L = hostsim()
+    rng = np.random.default_rng(2)
+    rows, cols = 20011, 7  # several 4096-row chunks plus a ragged tail
+    M = np.asfortranarray(rng.standard_normal((rows, cols)) * 10.0 ** rng.integers(-12, 12, size=(rows, cols)))
+    M[5, 3] = 0.0
+    M[6, 3] = -0.0
+    M[7, 3] = 123456789012.0
+    names = "|".join("f%d\ti%d" % (i, i) for i in range(rows)).encode()
+    f = str(tmp_path / "big.txt")
+    for prec in (7, 20, 3):
+        assert L.hostsim_save_text(M.ctypes.data, rows, cols, b"FID\tIID|" + b"|".join(b"U%d" % i for i in range(cols)), names, f.encode(), prec) == 0
+        lines = open(f).read().split("\n")
+        assert len(lines) == rows + 2 and lines[-1] == ""
+        for i in (0, 1, 4095, 4096, 4097, 8191, 8192, 20010, 5, 6, 7):
+            expect = "f%d\ti%d\t" % (i, i) + "\t".join("%.*g" % (prec, v) for v in M[i])
+            assert lines[i + 1] == expect, (i, prec)
+
+
 def test_fam_bim_readers(golden_dir):
     L = hostsim()
     err = C.create_string_buffer(256)
