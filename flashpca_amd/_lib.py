@@ -98,6 +98,7 @@ SIGNATURES = {
     "fpca_profile_end": (_I, [_P, _I, C.POINTER(BenchResult), C.POINTER(_I)]),
     "fpca_bench_stats": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D)]),
     "fpca_debug_mfma_probe": (_I, [_P, _P, _P]),
+    "fpca_debug_mfma_i8_probe": (_I, [_P, _P, _P]),
     "fpca_debug_mfma_peak": (_I, [_I, _I, _I, C.POINTER(_D)]),
     "fpca_debug_census": (_I, [_I, _U64, _P]),
 }

@@ -101,6 +101,16 @@ struct fpca_ctx {
    size_t stage_cap = 0;
    double *d_io_a = nullptr, *d_io_b = nullptr; // [N_pad][64] blocks for the host-pointer API
    double *d_small = nullptr;                   // small device scratch (scalars, column scales)
+   // exact-integer mode (FPCA_ACCUM_I8(S)): sample-major packed copy, K3 row scales, sliced operands, int32 partials
+   int i8_S = 0;
+   uint8_t *d_packedT = nullptr;
+   size_t pitchT = 0;
+   double *d_inv_sd = nullptr, *d_mu_inv_sd = nullptr, *d_i8w = nullptr;
+   int8_t *d_Qb = nullptr, *d_Qg = nullptr, *d_Qm = nullptr;
+   int i8_nsc = 0; // rows currently allocated (and zero-padded) in the Q buffers
+   int *d_i8ws = nullptr;
+   size_t i8ws_cap = 0;
+   bool i8_scales_done = false, i8_transposed = false;
    // communication
    ncclComm_t comm = nullptr;
    int nranks = 1, rank = 0;
@@ -140,7 +150,10 @@ void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int devi
       throw Error(FPCA_EINVAL, "unknown standardisation method: " + std::to_string(stand)); // data.cpp:283-288
    if (dense && (stand < FPCA_STANDARDISE_NONE || stand > FPCA_STANDARDISE_CENTER))
       throw Error(FPCA_EINVAL, "unknown standardization method"); // util.cpp:183
-   if (accum != FPCA_ACCUM_FP64 && accum != FPCA_ACCUM_FP32) throw Error(FPCA_EINVAL, "accum must be FPCA_ACCUM_FP64 or FPCA_ACCUM_FP32");
+   const bool i8 = accum >= FPCA_ACCUM_I8(2) && accum <= FPCA_ACCUM_I8(9);
+   if (accum != FPCA_ACCUM_FP64 && accum != FPCA_ACCUM_FP32 && !i8)
+      throw Error(FPCA_EINVAL, "accum must be FPCA_ACCUM_FP64, FPCA_ACCUM_FP32 or FPCA_ACCUM_I8(2..9)");
+   if (i8 && dense) throw Error(FPCA_EINVAL, "the int8-sliced mode needs 2-bit genotype input");
    int ndev = 0;
    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
       throw Error(FPCA_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
@@ -160,6 +173,7 @@ void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int devi
    c->P_pad = round_up(std::max<uint64_t>(P_g, 1), SNP_ALIGN);
    c->stand = stand;
    c->accum = accum;
+   c->i8_S = i8 ? accum - FPCA_ACCUM_I8(0) : 0;
    c->dense = dense;
    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
    if (dense) {
@@ -197,7 +211,8 @@ void ctx_free(fpca_ctx *c)
       }
    }
    void *ptrs[] = {c->d_Xd, c->d_packed, c->d_lut, c->d_mean, c->d_sd,   c->d_sumsq, c->d_T,
-                   c->d_part,   c->d_stage, c->d_io_a, c->d_io_b, c->d_small};
+                   c->d_part,   c->d_stage, c->d_io_a, c->d_io_b, c->d_small, c->d_packedT, c->d_inv_sd, c->d_mu_inv_sd,
+                   c->d_i8w, c->d_Qb, c->d_Qg, c->d_Qm, c->d_i8ws};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -225,11 +240,90 @@ void ensure_stats(fpca_ctx *c)
    c->stats_done = true;
 }
 
+// ---- exact-integer mode --------------------------------------------------------------------------------
+// weights / scratch layout in d_i8w (doubles): [0,512) wB, [512,1024) wg, [1024,1536) wm, [1536,1536+128) scratch
+constexpr int I8W_B = 0, I8W_G = 512, I8W_M = 1024, I8W_SCR = 1536, I8W_TOTAL = 1536 + 128;
+
+void ensure_i8(fpca_ctx *c, int b)
+{
+   hipStream_t s = c->stream;
+   if (!c->i8_transposed) {
+      c->pitchT = (size_t)c->P_pad / 4;
+      HIP_CHECK(hipMalloc(&c->d_packedT, c->pitchT * c->N_pad));
+      kern::transpose_packed(c->d_packed, c->pitch, c->N_pad, c->P_pad, c->d_packedT, c->pitchT, s);
+      HIP_CHECK(hipMalloc(&c->d_inv_sd, c->P_pad * sizeof(double)));
+      HIP_CHECK(hipMalloc(&c->d_mu_inv_sd, c->P_pad * sizeof(double)));
+      HIP_CHECK(hipMalloc(&c->d_i8w, I8W_TOTAL * sizeof(double)));
+      c->i8_transposed = true;
+   }
+   if (!c->i8_scales_done) {
+      kern::i8_rowscales(c->d_mean, c->d_sd, c->P_g, c->P_pad, c->d_inv_sd, c->d_mu_inv_sd, s);
+      c->i8_scales_done = true;
+   }
+   const int nsc = kern::gemm_i8_nsc_pad(c->i8_S, b);
+   if (nsc > c->i8_nsc) {
+      for (int8_t **q : {&c->d_Qb, &c->d_Qg, &c->d_Qm})
+         if (*q) {
+            HIP_CHECK(hipFree(*q));
+            *q = nullptr;
+         }
+      HIP_CHECK(hipMalloc(&c->d_Qb, (size_t)nsc * c->N_pad));
+      HIP_CHECK(hipMalloc(&c->d_Qg, (size_t)nsc * c->P_pad));
+      HIP_CHECK(hipMalloc(&c->d_Qm, (size_t)nsc * c->P_pad));
+      c->i8_nsc = nsc;
+   }
+   // rows >= S*b of the Q operands must be zero (they are multiplied like any other column)
+   if (nsc != c->i8_S * b) {
+      const size_t used = (size_t)c->i8_S * b;
+      HIP_CHECK(hipMemsetAsync(c->d_Qb + used * c->N_pad, 0, (nsc - used) * c->N_pad, s));
+      HIP_CHECK(hipMemsetAsync(c->d_Qg + used * c->P_pad, 0, (nsc - used) * c->P_pad, s));
+      HIP_CHECK(hipMemsetAsync(c->d_Qm + used * c->P_pad, 0, (nsc - used) * c->P_pad, s));
+   }
+   const size_t need = std::max(kern::gemm_i8_workspace_ints(c->P_pad, c->N_pad, c->i8_S, b, false),
+                                kern::gemm_i8_workspace_ints(c->N_pad, c->P_pad, c->i8_S, b, true));
+   if (need > c->i8ws_cap) {
+      if (c->d_i8ws) HIP_CHECK(hipFree(c->d_i8ws));
+      c->d_i8ws = nullptr;
+      c->i8ws_cap = 0;
+      HIP_CHECK(hipMalloc(&c->d_i8ws, need * sizeof(int)));
+      c->i8ws_cap = need;
+   }
+}
+
+// T = X' B : slices of B against the SNP-major stream, per-SNP mean / sd applied in the exact combine
+void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s)
+{
+   kern::slice_operand(dB, nullptr, c->N_pad, c->N, b, c->i8_S, c->d_Qb, c->d_i8w + I8W_B, c->d_i8w + I8W_SCR, s);
+   kern::gemm_i8(c->d_packed, c->pitch, c->d_Qb, c->d_Qb, c->d_i8w + I8W_B, c->d_i8w + I8W_B, c->d_mean, c->d_sd, c->d_T, c->d_i8ws,
+                 c->P_pad, c->N_pad, b, c->i8_S, s);
+}
+
+// Y = X T : slices of T/sd and mean T/sd against the sample-major copy
+void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s)
+{
+   kern::slice_operand(c->d_T, c->d_inv_sd, c->P_pad, c->P_g, b, c->i8_S, c->d_Qg, c->d_i8w + I8W_G, c->d_i8w + I8W_SCR, s);
+   kern::slice_operand(c->d_T, c->d_mu_inv_sd, c->P_pad, c->P_g, b, c->i8_S, c->d_Qm, c->d_i8w + I8W_M, c->d_i8w + I8W_SCR, s);
+   kern::gemm_i8(c->d_packedT, c->pitchT, c->d_Qg, c->d_Qm, c->d_i8w + I8W_G, c->d_i8w + I8W_M, nullptr, nullptr, dY, c->d_i8ws,
+                 c->N_pad, c->P_pad, b, c->i8_S, s);
+}
+
 // the operator on device-resident blocks: dY = X_g X_g' dB (+ all-reduce).  ev (optional): 4 events recorded
 // at [start, after K2(+reduce), after K3(+reduce), after all-reduce].
 void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t s, hipEvent_t *ev)
 {
    ensure_stats(c);
+   if (c->i8_S) {
+      ensure_i8(c, b);
+      c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
+      if (ev) HIP_CHECK(hipEventRecord(ev[0], s));
+      xt_i8(c, dB, b, s);
+      if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
+      x_i8(c, b, dY, s);
+      if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
+      if (c->multi()) c->allreduce(dY, (uint64_t)c->N_pad * b, s);
+      if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
+      return;
+   }
    const int s2 = c->dense ? kern::xt_b_dense_splits(c->N_pad, c->P_pad) : kern::xt_b_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
    const int s3 = c->dense ? kern::x_t_dense_splits(c->N_pad, c->P_pad) : kern::x_t_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
    c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
@@ -257,6 +351,12 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
 void xt_dev(fpca_ctx *c, const double *dB, int b, hipStream_t s)
 {
    ensure_stats(c);
+   if (c->i8_S) {
+      ensure_i8(c, b);
+      c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
+      xt_i8(c, dB, b, s);
+      return;
+   }
    const int s2 = c->dense ? kern::xt_b_dense_splits(c->N_pad, c->P_pad) : kern::xt_b_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
    c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
    if (s2 > 1) c->ensure(c->d_part, c->part_cap, (size_t)s2 * c->P_pad * b);
@@ -270,6 +370,11 @@ void xt_dev(fpca_ctx *c, const double *dB, int b, hipStream_t s)
 void x_dev(fpca_ctx *c, int b, double *dY, hipStream_t s)
 {
    ensure_stats(c);
+   if (c->i8_S) {
+      ensure_i8(c, b);
+      x_i8(c, b, dY, s);
+      return;
+   }
    const int s3 = c->dense ? kern::x_t_dense_splits(c->N_pad, c->P_pad) : kern::x_t_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
    if (s3 > 1) c->ensure(c->d_part, c->part_cap, (size_t)s3 * c->N_pad * b);
    if (c->dense)
@@ -661,6 +766,7 @@ int fpca_set_meansd(fpca_ctx *ctx, const double *mean_sd)
       HIP_CHECK(hipMemcpy(ctx->d_sd, mean_sd + ctx->P_g, ctx->P_g * sizeof(double), hipMemcpyHostToDevice));
       kern::lut_from_meansd(ctx->d_mean, ctx->d_sd, ctx->P_g, ctx->d_lut, ctx->stream);
       HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      ctx->i8_scales_done = false;
       ctx->stats_done = true; // trace of the preloaded standardisation is not defined by the reference path
       ctx->trace_local = 0;
    });
@@ -1013,7 +1119,25 @@ int fpca_debug_mfma_probe(const double *A, const double *B, double *D)
    });
 }
 
-// diagnostic: measured issue-rate ceiling of v_mfma_f64_16x16x4_f64 (TFLOP/s) with 1..8 waves per SIMD
+int fpca_debug_mfma_i8_probe(const int8_t *A, const int8_t *Bt, int32_t *D)
+{
+   return guarded([&] {
+      int8_t *dA, *dB;
+      int *dD;
+      HIP_CHECK(hipMalloc(&dA, 1024));
+      HIP_CHECK(hipMalloc(&dB, 1024));
+      HIP_CHECK(hipMalloc(&dD, 1024 * sizeof(int)));
+      HIP_CHECK(hipMemcpy(dA, A, 1024, hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(dB, Bt, 1024, hipMemcpyHostToDevice));
+      kern::mfma_i8_probe(dA, dB, dD, nullptr);
+      HIP_CHECK(hipDeviceSynchronize());
+      HIP_CHECK(hipMemcpy(D, dD, 1024 * sizeof(int), hipMemcpyDeviceToHost));
+      (void)hipFree(dA);
+      (void)hipFree(dB);
+      (void)hipFree(dD);
+   });
+}
+
 int fpca_debug_census(int nwg, uint64_t lds_bytes, uint32_t *out)
 {
    return guarded([&] {

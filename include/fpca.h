@@ -48,6 +48,10 @@ extern "C" {
 /* accumulate type of the two genotype GEMMs */
 #define FPCA_ACCUM_FP64 64
 #define FPCA_ACCUM_FP32 32
+/* exact-integer mode: the fp64 operand is cut into S signed 7-bit slices (shared power-of-two scale per column) and
+ * multiplied with the integer genotype matrices on the int8 matrix cores with exact int32 accumulation; S = 8 keeps
+ * 56 bits (fp64-equivalent), S = 4..5 roughly single precision but still without accumulation error. */
+#define FPCA_ACCUM_I8(S) (800 + (S))
 
 #define FPCA_OK 0
 #define FPCA_EINVAL -1      /* bad argument */
@@ -216,6 +220,9 @@ int fpca_bench_stats(fpca_ctx *ctx, int reps, double *ms_per_launch, double *byt
 /* diagnostic: D(16x16, row-major) = A(16x4) B(4x16) through v_mfma_f64_16x16x4_f64 with the lane->operand mapping the
  * kernels assume; host pointers.  Used by tests/test_gpu_kernels.py as a guard on the hardware layout. */
 int fpca_debug_mfma_probe(const double *A, const double *B, double *D);
+/* diagnostic: D(32x32 int32, row-major) = A(32x32 int8, row-major) * Bt(32x32 int8, row j = column j of B)' through
+ * v_mfma_i32_32x32x32_i8 with the lane->operand mapping of kernels_i8.hip; host pointers */
+int fpca_debug_mfma_i8_probe(const int8_t *A, const int8_t *Bt, int32_t *D);
 /* diagnostic: sustained rate (TFLOP/s) of a pure v_mfma_f64_16x16x4_f64 stream with `waves_per_simd` (1..8) resident
  * waves per SIMD and no memory traffic; pattern 0..3 selects the operand-register sharing pattern (kernels.hip).  The
  * practical ceiling to read the GEMM kernels' roofline fraction against (72-74 TFLOP/s at 2 waves/SIMD vs 78.6 datasheet) */

@@ -199,3 +199,62 @@ def test_fp32_mode_operator_tolerance(golden_dir, name, b, fp, orc):
     od.dense()
     assert np.array_equal(ms, od.meansd())  # statistics stay fp64 / bit-exact in both modes
     ctx.close()
+
+
+def test_mfma_i8_operand_mapping(fp):
+    """v_mfma_i32_32x32x32_i8 lane->operand map of kernels_i8.hip (asymmetric operands, full int8 range)."""
+    import ctypes as C
+
+    rng = np.random.default_rng(11)
+    A = rng.integers(-128, 128, size=(32, 32), dtype=np.int8)
+    Bt = rng.integers(-128, 128, size=(32, 32), dtype=np.int8)
+    D = np.zeros((32, 32), dtype=np.int32)
+    rc = fp.lib().fpca_debug_mfma_i8_probe(A.ctypes.data_as(C.c_void_p), Bt.ctypes.data_as(C.c_void_p), D.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    assert np.array_equal(D, A.astype(np.int32) @ Bt.astype(np.int32).T)
+
+
+@pytest.mark.parametrize("name,b,S,tol", [("data_chr1", 32, 8, 1e-12), ("hapmap3_data", 32, 8, 1e-12), ("hapmap3_data", 64, 8, 1e-12),
+                                          ("hapmap3_data", 16, 8, 1e-12), ("hapmap3_data", 48, 7, 1e-11), ("data_chr1", 5, 8, 1e-12),
+                                          ("hapmap3_data", 64, 4, 3e-6), ("hapmap3_data", 32, 6, 1e-9)])
+def test_i8_mode_operator_parity(golden_dir, name, b, S, tol, fp, orc):
+    """FPCA_ACCUM_I8(S): integer genotype matrices x 7-bit slices of the fp64 operand with exact int32 accumulation.
+    S = 8 keeps 56 bits per column scale, so the result meets the fp64 tolerance; smaller S only truncates the operand
+    (error <= 2^-7S of the column maximum per element, no accumulation error)."""
+    N = fp.count_fam_rows(os.path.join(golden_dir, name + ".fam"))
+    bed = os.path.join(golden_dir, name + ".bed")
+    ctx = fp.Context.from_bed(bed, N, accum="i8x%d" % S)
+    od = orc.OracleData(bed, N, "binom2")
+    X = od.dense()
+    rng = np.random.default_rng(b + S)
+    B = rng.standard_normal((N, b)) * np.logspace(-3, 3, b)[None, :]  # per-column scales must not matter
+    T_ref = X.T @ B
+    T = ctx.apply_xt(B)
+    assert np.max(np.abs(T - T_ref) / np.max(np.abs(T_ref), axis=0)) <= 10 * tol
+    Tin = rng.standard_normal((ctx.P, b))
+    Y_ref = X @ Tin
+    Y = ctx.apply_x(Tin)
+    assert np.max(np.abs(Y - Y_ref) / np.max(np.abs(Y_ref), axis=0)) <= 10 * tol
+    Z_ref = X @ T_ref
+    Z = ctx.apply_xxt(B)
+    assert np.max(np.abs(Z - Z_ref) / np.max(np.abs(Z_ref), axis=0)) <= 10 * tol
+    ctx.close()
+
+
+@pytest.mark.parametrize("N,P", [(1, 3), (5, 7), (257, 300), (2051, 129)])
+def test_i8_mode_ragged_shapes(N, P, fp, orc):
+    rng = np.random.default_rng(N * 1000 + P)
+    npk = (N + 3) // 4
+    packed = rng.integers(0, 256, size=(P, npk), dtype=np.uint8)
+    if P >= 3:
+        packed[1, :] = 0xFF
+        packed[2, :] = 0x55
+    ctx = fp.Context.from_packed(packed, N, P, accum="i8")
+    od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+    X = od.dense()
+    B = rng.standard_normal((N, 3))
+    Z_ref = X @ (X.T @ B)
+    Z = ctx.apply_xxt(B)
+    assert np.all(np.isfinite(Z))
+    assert np.max(np.abs(Z - Z_ref)) <= 1e-11 * max(1.0, np.max(np.abs(Z_ref)))
+    ctx.close()
