@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -127,139 +129,253 @@ void slice_operand(const double *V, const double *rowscale, uint64_t rows_pad, u
 // ------------------------------------------------------------------------------------------------
 // K2i / K3i core:  acc[row][sc] = sum_k A[row][k] * Q[sc][k]  for A in {G.M, M}
 //   `packed`: 2-bit records, one per output row (K2: the SNP-major stream, K = samples; K3: its sample-major copy,
-//   K = SNPs).  Workgroup = 8 waves = 128 rows x 256 slice-columns; wave (wr, wc) owns 64 rows x 64 columns of BOTH
-//   integer matrices (2 x 2 x 2 accumulators of 32x32), so one LDS operand read feeds 4 MFMAs (TWO = false, K2: both
-//   matrices multiply the same Q) or 2 (TWO = true, K3: Qg = slices of T/sd, Qm = slices of mean T/sd).
-//   Per KC-chunk the Q tile(s) [256 sc][KC] and the packed tile [128 rows][KC/4 B] are double-buffered in LDS (one
-//   barrier per chunk; row strides KC+16 / KC/4+16 bytes keep the ds_read_b128 of 16 lanes on distinct banks).
+//   K = SNPs).  Workgroup = 4 waves, ONE wave per SIMD with the whole 512-register budget (256 accumulator AGPRs):
+//     K2 (TWO = false): both integer matrices multiply the same operand Q; workgroup tile 128 rows x 256 columns,
+//                       wave = 64 rows x 128 columns (MT = 2, NT = 4) x 2 matrices
+//     K3 (TWO = true) : G.M multiplies Qg (slices of T/sd), M multiplies Qm (slices of mean T/sd); workgroup tile
+//                       256 rows x 128 columns of each operand, wave = 128 rows x 64 columns (MT = 4, NT = 2)
+//   so that either way a 256-k chunk costs 64 KB of operand staging for 128 MFMAs per wave and a 32-k step needs 4
+//   ds_read_b128 and 15 MT decode ops for 16 MFMAs of 8 passes.
+//   Operand tiles [columns][256 k] are double-buffered in LDS (row stride 272 B: the 16 lanes of a ds_read_b128 group
+//   hit distinct banks); the packed words go straight from global memory to the registers of the lane that decodes them.
 //   Decode: a lane's dword w holds 16 codes; (w >> 2q) & 0x03030303 leaves codes q, q+4, q+8, q+12 in the four bytes
 //   and v_perm_b32 with the code as selector looks G.M / M up in a 4-byte table -- 4 VALU ops per operand dword
 //   pair; the Q bytes were stored in the matching order by k_slice.
+//   Scheduling: with one wave per SIMD only the wave's own instruction order hides latency, and hipcc left alone
+//   sinks every LDS read to just before its MFMAs and waits at once (measured: matrix pipe 42 % busy).  The loop body is
+//   therefore a fixed pipeline of micro-steps (k-step, m-tile) = 8 MFMAs each, fenced by sched_barrier(0), with
+//   explicit (asm) loads and hand-counted s_waitcnt: operand fragments of the next k-step are read from LDS one k-step
+//   ahead, the next micro-step's genotype fragments are decoded under this one's MFMAs, and the next chunk's global
+//   loads (first half of the chunk) and LDS stores (second half) ride in the MFMA shadow instead of a burst at the
+//   chunk boundary.
 //   Output: int32 partials part[split][row][mat][NSC], combined exactly by k_i8_combine.
-constexpr int I8_ROWS = 128;
-constexpr int I8_COLS = 256;
+constexpr int I8_KC = 256;
+constexpr int I8_LDQ = I8_KC + 16;
+
+template <int OFF>
+__device__ __forceinline__ v4i lds_read16(uint32_t addr) // explicit LDS read: the caller places the s_waitcnt
+{
+   v4i r;
+   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+   return r;
+}
+template <int OFF>
+__device__ __forceinline__ u4 gload16(const void *sbase, uint32_t voff) // explicit global load, address = sbase + voff + OFF
+{
+   u4 r;
+   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF));
+   return r;
+}
+// hand-placed waits; the "+v" operands make the consumers of the loaded registers depend on the wait
+__device__ __forceinline__ void lds_wait(v4i &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+__device__ __forceinline__ void lds_wait(v4i &a, v4i &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+template <int N>
+__device__ __forceinline__ void vm_wait(u4 &a)
+{
+   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void vm_wait(u4 &a, u4 &b)
+{
+   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+   (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+   static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 template <bool TWO>
 struct I8Cfg {
-   static constexpr int KC = TWO ? 128 : 256;
-   static constexpr int LDQ = KC + 16;               // Q tile row stride (bytes)
-   static constexpr int LDP = KC / 4 + 16;           // packed tile row stride (bytes)
-   static constexpr int NQ = TWO ? 2 : 1;            // Q tiles per stage
-   static constexpr int STAGE = NQ * I8_COLS * LDQ + I8_ROWS * LDP; // bytes per LDS stage
-   static constexpr int QPIECES = NQ * I8_COLS * (KC / 16) / 512;   // 16-byte pieces per thread per chunk (8)
+   static constexpr int MT = TWO ? 4 : 2, NT = TWO ? 2 : 4, NQ = TWO ? 2 : 1;
+   static constexpr int ROWS = 64 * MT;                 // workgroup rows (2 wave rows)
+   static constexpr int COLS = 64 * NT;                 // workgroup columns of each operand (2 wave columns)
+   static constexpr int QTILE = COLS * I8_LDQ;          // bytes of one operand tile
+   static constexpr int STAGE = NQ * QTILE;             // 69632 either way
+   static constexpr int NPIECE = NQ * COLS * (I8_KC / 16) / 256; // 16-byte pieces per thread per chunk: 16
+   static constexpr int NSTEP = (I8_KC / 32) * MT;      // micro-steps per chunk: 16 / 32
 };
 
+__device__ __forceinline__ void i8_decode(uint32_t w, v4i &ag, v4i &am)
+{
+   const uint32_t tabG = 0x00010002u, tabM = 0x01010001u; // byte[code]: code 0 -> (2,1), 1 (missing) -> (0,0), 2 -> (1,1), 3 -> (0,1)
+#pragma unroll
+   for (int q = 0; q < 4; q++) {
+      const uint32_t sel = (w >> (2 * q)) & 0x03030303u;
+      ag[q] = (int)__builtin_amdgcn_perm(0u, tabG, sel);
+      am[q] = (int)__builtin_amdgcn_perm(0u, tabM, sel);
+   }
+}
+
 template <bool TWO>
-__global__ __launch_bounds__(512, 1) void k_gemm_i8(const uint8_t *__restrict__ packed, size_t pitch,
+__global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ packed, size_t pitch,
                                                      const int8_t *__restrict__ Qg, const int8_t *__restrict__ Qm,
                                                      uint64_t k_pad, int nsc_total, int *__restrict__ part, uint64_t rows_pad,
                                                      int chunks_total, int chunks_per_split)
 {
    using C = I8Cfg<TWO>;
-   constexpr int KC = C::KC, LDQ = C::LDQ, LDP = C::LDP, KS = KC / 32, NP = C::QPIECES;
-   static_assert(NP == 8, "staging assumes 8 pieces per thread");
+   constexpr int MT = C::MT, NT = C::NT, NQ = C::NQ, KS = I8_KC / 32, NP = C::NPIECE, NSTEP = C::NSTEP, LDQ = I8_LDQ;
+   constexpr int H = NSTEP / 2, LP = NP / H; // staging: LP loads per micro-step in the first half, LP stores in the second
+   static_assert(NP == 16 && LP * H == NP, "staging schedule");
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int li = lane & 31, kh = lane >> 5;
-   const int wr = wave >> 2, wc = wave & 3;
-   const uint64_t row0 = (uint64_t)blockIdx.x * I8_ROWS;
-   const int col0 = blockIdx.z * I8_COLS;
+   const int wr = wave >> 1, wc = wave & 1;
+   const uint64_t row0 = (uint64_t)blockIdx.x * C::ROWS;
+   const int col0 = blockIdx.z * C::COLS;
    const int c_begin = blockIdx.y * chunks_per_split;
    int c_end = c_begin + chunks_per_split;
    if (c_end > chunks_total) c_end = chunks_total;
+   if (c_begin >= c_end) c_end = c_begin; // (cannot happen with the host's split choice)
 
-   v16i acc[2][2][2]; // [mat][m][n]
+   v16i acc[2][MT][NT]; // [mat][m][n]
 #pragma unroll
    for (int a = 0; a < 2; a++)
 #pragma unroll
-      for (int m = 0; m < 2; m++)
+      for (int m = 0; m < MT; m++)
 #pragma unroll
-         for (int n = 0; n < 2; n++)
+         for (int n = 0; n < NT; n++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][m][n][r] = 0;
 
-   // staging assignment: Q piece p = tid + 512 r (r < 8): tile p / (256*KC/16), row, 16-byte segment
-   constexpr int SEGS = KC / 16;
-   const int8_t *qsrc[NP];
-   int qdst[NP];
+   // operand staging: piece r of this thread = row tid/16 + 16 (r % (NP/NQ)) of operand r / (NP/NQ), segment tid % 16;
+   // LDS destination = qdst + r * 16 * LDQ for both shapes (QTILE == (NP/NQ) * 16 * LDQ)
+   static_assert(C::QTILE == (NP / NQ) * 16 * LDQ, "piece stride");
+   const uint32_t qvoff = (uint32_t)((tid >> 4) * k_pad + (tid & 15) * 16);
+   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+   const int qdst = (tid >> 4) * LDQ + (tid & 15) * 16;
+   // packed words: lane (li, kh) of wave row wr decodes rows wr*32*MT + 32 m + li, k = 128 kh + 16 ks .. of the chunk
+   uint32_t pvoff[MT];
 #pragma unroll
-   for (int r = 0; r < NP; r++) {
-      const int p = tid + 512 * r;
-      const int tile = p / (I8_COLS * SEGS), pp = p % (I8_COLS * SEGS);
-      const int row = pp / SEGS, seg = pp % SEGS;
-      qsrc[r] = ((TWO && tile) ? Qm : Qg) + (uint64_t)(col0 + row) * k_pad + seg * 16;
-      qdst[r] = tile * I8_COLS * LDQ + row * LDQ + seg * 16;
-   }
-   // packed tile: 128 rows x KC/4 bytes = 128 * KC/64 pieces of 16 bytes  (KC = 256: 512 pieces, KC = 128: 256)
-   constexpr int PSEGS = KC / 64;
-   const bool p_active = tid < I8_ROWS * PSEGS;
-   const int prow = tid / PSEGS, pseg = tid % PSEGS;
-   const uint8_t *psrc = packed + (row0 + (p_active ? prow : 0)) * pitch + pseg * 16;
-   const int pdst = C::NQ * I8_COLS * LDQ + prow * LDP + pseg * 16;
+   for (int m = 0; m < MT; m++) pvoff[m] = (uint32_t)((wr * 32 * MT + 32 * m + li) * pitch + kh * 32);
+   const uint8_t *prow = packed + row0 * pitch;
+   const uint32_t aQ0 = lds_base + (uint32_t)(wc * 32 * NT + li) * LDQ + kh * 128;
 
-   u4 qreg[NP], preg;
-#define FPCA_I8_LOAD(cc)                                                                      \
-   {                                                                                           \
-      _Pragma("unroll") for (int r = 0; r < NP; r++) qreg[r] = *reinterpret_cast<const u4 *>(qsrc[r] + (uint64_t)(cc) * KC); \
-      if (p_active) preg = *reinterpret_cast<const u4 *>(psrc + (size_t)(cc) * (KC / 4));      \
-   }
-#define FPCA_I8_STORE(buf)                                                                     \
-   {                                                                                           \
-      unsigned char *st = smem + (size_t)(buf) * C::STAGE;                                     \
-      _Pragma("unroll") for (int r = 0; r < NP; r++) *reinterpret_cast<u4 *>(st + qdst[r]) = qreg[r]; \
-      if (p_active) *reinterpret_cast<u4 *>(st + pdst) = preg;                                 \
-   }
-   if (c_begin < c_end) {
-      FPCA_I8_LOAD(c_begin);
-      FPCA_I8_STORE(0);
+   u4 qreg[NP];
+   u4 pk[MT][2], pkn[MT][2]; // packed words of the current / next chunk (8 dwords = 8 k-steps per m-tile)
+
+   // prologue: chunk c_begin
+   {
+      const int c = c_begin;
+      static_for<NP>([&](auto rr) {
+         constexpr int r = decltype(rr)::value, o = r / (NP / NQ), r1 = r % (NP / NQ);
+         const int8_t *sb = ((TWO && o) ? Qm : Qg) + (uint64_t)(col0 + 16 * r1) * k_pad + (uint64_t)c * I8_KC;
+         qreg[r] = gload16<0>(sb, qvoff);
+      });
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+         pk[m][0] = gload16<0>(prow + (size_t)c * (I8_KC / 4), pvoff[m]);
+         pk[m][1] = gload16<16>(prow + (size_t)c * (I8_KC / 4), pvoff[m]);
+      }
+      static_for<NP>([&](auto rr) {
+         constexpr int r = decltype(rr)::value;
+         vm_wait<NP - 1 - r + 2 * MT>(qreg[r]);
+         *reinterpret_cast<u4 *>(smem + qdst + r * 16 * LDQ) = qreg[r];
+      });
+#pragma unroll
+      for (int m = 0; m < MT; m++) vm_wait<0>(pk[m][0], pk[m][1]);
    }
    __syncthreads();
 
-   const uint32_t tabG = 0x00010002u, tabM = 0x01010001u; // byte[code]: code 0 -> (2,1), 1 (missing) -> (0,0), 2 -> (1,1), 3 -> (0,1)
    for (int c = c_begin; c < c_end; c++) {
       const int buf = (c - c_begin) & 1;
-      if (c + 1 < c_end) FPCA_I8_LOAD(c + 1);
-      const unsigned char *st = smem + (size_t)buf * C::STAGE;
-      const unsigned char *sQ = st + (size_t)(wc * 64 + li) * LDQ + kh * (KC / 2);
-      const unsigned char *sP = st + C::NQ * I8_COLS * LDQ + (size_t)(wr * 64 + li) * LDP + kh * (KC / 8);
+      const int cn = (c + 1 < c_end) ? c + 1 : c; // the last chunk re-stages itself (branch-free pipeline)
+      const uint32_t aQ = aQ0 + (uint32_t)buf * C::STAGE;
+      unsigned char *wst = smem + (size_t)(buf ^ 1) * C::STAGE + qdst;
+      const uint8_t *pnext = prow + (size_t)cn * (I8_KC / 4);
+
+      v4i bq[2][NQ][NT]; // operand fragments, index = k-step parity
+      v4i ag[2], am[2];  // decoded genotype fragments, index = micro-step parity
+      static_for<NT>([&](auto nn) {
+         constexpr int n = decltype(nn)::value;
+         bq[0][0][n] = lds_read16<32 * n * LDQ>(aQ);
+         if (TWO) bq[0][NQ - 1][n] = lds_read16<C::QTILE + 32 * n * LDQ>(aQ);
+      });
+      i8_decode(pk[0][0][0], ag[0], am[0]);
+      static_for<NT>([&](auto nn) {
+         constexpr int n = decltype(nn)::value;
+         if (TWO)
+            lds_wait(bq[0][0][n], bq[0][NQ - 1][n]);
+         else
+            lds_wait(bq[0][0][n]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+
+      static_for<NSTEP>([&](auto ss) {
+         constexpr int s = decltype(ss)::value, ks = s / MT, m = s % MT, kp = ks & 1, sp = s & 1;
+         // --- staging of chunk cn: loads in the first half, P words at the half-way mark, LDS stores in the second half
+         if constexpr (s < H) {
+            static_for<LP>([&](auto jj) {
+               constexpr int r = s * LP + decltype(jj)::value, o = r / (NP / NQ), r1 = r % (NP / NQ);
+               const int8_t *sb = ((TWO && o) ? Qm : Qg) + (uint64_t)(col0 + 16 * r1) * k_pad + (uint64_t)cn * I8_KC;
+               qreg[r] = gload16<0>(sb, qvoff);
+            });
+         }
+         if constexpr (s == H - 1) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ks++) { // this lane half covers k = (KC/2) kh + 16 ks .. +15 of the chunk
-         v4i ag[2], am[2];
-#pragma unroll
-         for (int m = 0; m < 2; m++) {
-            const uint32_t w = *reinterpret_cast<const uint32_t *>(sP + (size_t)(32 * m) * LDP + ks * 4);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-               const uint32_t sel = (w >> (2 * q)) & 0x03030303u;
-               ag[m][q] = (int)__builtin_amdgcn_perm(0u, tabG, sel);
-               am[m][q] = (int)__builtin_amdgcn_perm(0u, tabM, sel);
+            for (int mm = 0; mm < MT; mm++) {
+               pkn[mm][0] = gload16<0>(pnext, pvoff[mm]);
+               pkn[mm][1] = gload16<16>(pnext, pvoff[mm]);
             }
          }
-#pragma unroll
-         for (int n = 0; n < 2; n++) {
-            const v4i bg = *reinterpret_cast<const v4i *>(sQ + (size_t)(32 * n) * LDQ + ks * 16);
-            v4i bm = bg;
-            if (TWO) bm = *reinterpret_cast<const v4i *>(sQ + (size_t)I8_COLS * LDQ + (size_t)(32 * n) * LDQ + ks * 16);
-#pragma unroll
-            for (int m = 0; m < 2; m++) {
-               acc[0][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ag[m], bg, acc[0][m][n], 0, 0, 0);
-               acc[1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(am[m], bm, acc[1][m][n], 0, 0, 0);
-            }
+         if constexpr (s >= H) {
+            static_for<LP>([&](auto jj) {
+               constexpr int r = (s - H) * LP + decltype(jj)::value;
+               vm_wait<NP - 1 - r + 2 * MT>(qreg[r]);
+               *reinterpret_cast<u4 *>(wst + r * 16 * LDQ) = qreg[r];
+            });
          }
+         // --- operand fragments of the next k-step
+         if constexpr (m == 0 && ks + 1 < KS) {
+            static_for<NT>([&](auto nn) {
+               constexpr int n = decltype(nn)::value;
+               bq[kp ^ 1][0][n] = lds_read16<32 * n * LDQ + (ks + 1) * 16>(aQ);
+               if (TWO) bq[kp ^ 1][NQ - 1][n] = lds_read16<C::QTILE + 32 * n * LDQ + (ks + 1) * 16>(aQ);
+            });
+         }
+         // --- 2 NT MFMAs of this micro-step, the next micro-step's decode in their shadow
+         static_for<NT>([&](auto nn) {
+            constexpr int n = decltype(nn)::value;
+            acc[0][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ag[sp], bq[kp][0][n], acc[0][m][n], 0, 0, 0);
+            acc[1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(am[sp], bq[kp][NQ - 1][n], acc[1][m][n], 0, 0, 0);
+            if constexpr (n == 0 && s + 1 < NSTEP) {
+               constexpr int s1 = s + 1, ks1 = s1 / MT, m1 = s1 % MT;
+               i8_decode(pk[m1][ks1 >> 2][ks1 & 3], ag[sp ^ 1], am[sp ^ 1]);
+            }
+         });
+         __builtin_amdgcn_sched_barrier(0);
+         if constexpr (m == MT - 1 && ks + 1 < KS) {
+            static_for<NT>([&](auto nn) {
+               constexpr int n = decltype(nn)::value;
+               if (TWO)
+                  lds_wait(bq[kp ^ 1][0][n], bq[kp ^ 1][NQ - 1][n]);
+               else
+                  lds_wait(bq[kp ^ 1][0][n]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+         }
+      });
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+         vm_wait<0>(pkn[m][0], pkn[m][1]);
+         pk[m][0] = pkn[m][0];
+         pk[m][1] = pkn[m][1];
       }
-      if (c + 1 < c_end) FPCA_I8_STORE(buf ^ 1);
       __syncthreads();
    }
-#undef FPCA_I8_LOAD
-#undef FPCA_I8_STORE
 
-   int *out = part + ((size_t)blockIdx.y * rows_pad + row0 + wr * 64) * 2 * nsc_total + col0 + wc * 64 + li;
+   int *out = part + ((size_t)blockIdx.y * rows_pad + row0 + wr * 32 * MT) * 2 * nsc_total + col0 + wc * 32 * NT + li;
 #pragma unroll
    for (int a = 0; a < 2; a++)
 #pragma unroll
-      for (int m = 0; m < 2; m++)
+      for (int m = 0; m < MT; m++)
 #pragma unroll
-         for (int n = 0; n < 2; n++)
+         for (int n = 0; n < NT; n++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -300,20 +416,31 @@ __global__ __launch_bounds__(256) void k_i8_combine(const int *__restrict__ part
    }
 }
 
+// split-K factor: one workgroup per CU, so the grid should be close to a multiple of 256 workgroups; each extra split
+// costs one more int32 partial round trip (rows * 2 * nsc * 4 bytes written and read)
 int gemm_i8_splits(uint64_t rows_pad, uint64_t k_pad, int nsc, bool two)
 {
    static const char *env = getenv("FPCA_I8_SPLITS");
-   const uint64_t tiles = rows_pad / I8_ROWS * (uint64_t)(nsc / I8_COLS), chunks = k_pad / (two ? 128 : 256);
+   const uint64_t rows_wg = two ? I8Cfg<true>::ROWS : I8Cfg<false>::ROWS, cols_wg = two ? I8Cfg<true>::COLS : I8Cfg<false>::COLS;
+   const uint64_t tiles = rows_pad / rows_wg * ((uint64_t)nsc / cols_wg), chunks = k_pad / I8_KC;
    if (env && atoi(env) > 0) return (int)std::min<uint64_t>((uint64_t)atoi(env), chunks);
-   // one workgroup per CU: aim at >= 4 rounds of 256 workgroups, at least 8 chunks per workgroup
-   uint64_t s = (1024 + tiles - 1) / tiles;
-   if (s > chunks / 8) s = chunks / 8;
-   if (s < 1) s = 1;
-   if (s > 16) s = 16;
-   return (int)s;
+   const double t_chunk = 2.2e-6;                                      // one workgroup-chunk at ~3 POP/s
+   const double t_part = (double)rows_pad * 2 * nsc * 4 * 2 / 3.0e12;  // partial write + read per split
+   double best = 1e30;
+   int best_s = 1;
+   for (uint64_t s = 1; s <= 16 && s * 4 <= std::max<uint64_t>(chunks, 4); s++) {
+      const uint64_t cps = (chunks + s - 1) / s;
+      const uint64_t rounds = (tiles * s + 255) / 256;
+      const double t = (double)rounds * (double)cps * t_chunk + (double)s * t_part;
+      if (t < best * 0.995) {
+         best = t;
+         best_s = (int)s;
+      }
+   }
+   return best_s;
 }
 
-int gemm_i8_nsc_pad(int S, int b) { return (S * b + I8_COLS - 1) / I8_COLS * I8_COLS; }
+int gemm_i8_nsc_pad(int S, int b) { return (S * b + 255) / 256 * 256; }
 
 size_t gemm_i8_workspace_ints(uint64_t rows_pad, uint64_t k_pad, int S, int b, bool two)
 {
@@ -328,25 +455,27 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
    const int nsc = gemm_i8_nsc_pad(S, b); // Q holds nsc rows; rows >= S*b are zero
    const bool two = (Qg != Qm);
    const int nsplit = gemm_i8_splits(rows_pad, k_pad, nsc, two);
-   const int KC = two ? 128 : 256;
-   const int chunks_total = (int)(k_pad / KC);
-   const int cps = (chunks_total + nsplit - 1) / nsplit;
+   const int chunks_total = (int)(k_pad / I8_KC);
+   int cps = (chunks_total + nsplit - 1) / nsplit;
+   const int nsplit_eff = (chunks_total + cps - 1) / cps; // no empty split
    static bool attr_set = false;
    if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * I8Cfg<false>::STAGE);
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * I8Cfg<true>::STAGE);
       attr_set = true;
    }
-   dim3 grid((unsigned)(rows_pad / I8_ROWS), (unsigned)nsplit, (unsigned)(nsc / I8_COLS));
-   if (two)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<true>), grid, dim3(512), 2 * I8Cfg<true>::STAGE, stream, packed, pitch, Qg, Qm, k_pad, nsc, ws,
+   if (two) {
+      dim3 grid((unsigned)(rows_pad / I8Cfg<true>::ROWS), (unsigned)nsplit_eff, (unsigned)(nsc / I8Cfg<true>::COLS));
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<true>), grid, dim3(256), 2 * I8Cfg<true>::STAGE, stream, packed, pitch, Qg, Qm, k_pad, nsc, ws,
                          rows_pad, chunks_total, cps);
-   else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<false>), grid, dim3(512), 2 * I8Cfg<false>::STAGE, stream, packed, pitch, Qg, Qm, k_pad, nsc, ws,
+   } else {
+      dim3 grid((unsigned)(rows_pad / I8Cfg<false>::ROWS), (unsigned)nsplit_eff, (unsigned)(nsc / I8Cfg<false>::COLS));
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<false>), grid, dim3(256), 2 * I8Cfg<false>::STAGE, stream, packed, pitch, Qg, Qm, k_pad, nsc, ws,
                          rows_pad, chunks_total, cps);
+   }
    HIP_CHECK_LAUNCH();
    unsigned blocks = (unsigned)std::min<uint64_t>(8192, (rows_pad * b + 255) / 256);
-   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, nsplit, rows_pad, b, S, nsc, wg, wm, mean, sd, out);
+   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, nsplit_eff, rows_pad, b, S, nsc, wg, wm, mean, sd, out);
    HIP_CHECK_LAUNCH();
 }
 
@@ -424,6 +553,201 @@ void mfma_i8_probe(const int8_t *A, const int8_t *Bt, int *D, hipStream_t stream
 {
    hipLaunchKernelGGL(k_mfma_i8_probe, dim3(1), dim3(64), 0, stream, A, Bt, D);
    HIP_CHECK_LAUNCH();
+}
+
+// issue-rate ceiling of v_mfma_i32_32x32x32_i8: 8 independent accumulators per wave, explicit registers (the compiler
+// must not reorder or shuffle them), operands = `fill` pattern (0: zeros, else pseudo-random bytes -- the rate is
+// power-limited, so the operand toggling matters)
+__global__ __launch_bounds__(256, 1) void k_mfma_i8_peak(int *out, int iters, uint32_t fill)
+{
+   const uint32_t l = threadIdx.x * 2654435761u;
+   const uint32_t f0 = fill ? (fill ^ l) * 0x9E3779B1u : 0u, f1 = fill ? (f0 >> 3) * 0x85EBCA6Bu : 0u, f2 = fill ? (f1 >> 5) * 0xC2B2AE35u : 0u,
+                  f3 = fill ? (f2 >> 7) * 0x27D4EB2Fu : 0u;
+   asm volatile(
+      "v_mov_b32 v0, 0\n\t"
+      "v_mov_b32 v1, 0\n\t"
+      "v_mov_b32 v2, 0\n\t"
+      "v_mov_b32 v3, 0\n\t"
+      "v_mov_b32 v4, 0\n\t"
+      "v_mov_b32 v5, 0\n\t"
+      "v_mov_b32 v6, 0\n\t"
+      "v_mov_b32 v7, 0\n\t"
+      "v_mov_b32 v8, 0\n\t"
+      "v_mov_b32 v9, 0\n\t"
+      "v_mov_b32 v10, 0\n\t"
+      "v_mov_b32 v11, 0\n\t"
+      "v_mov_b32 v12, 0\n\t"
+      "v_mov_b32 v13, 0\n\t"
+      "v_mov_b32 v14, 0\n\t"
+      "v_mov_b32 v15, 0\n\t"
+      "v_mov_b32 v16, 0\n\t"
+      "v_mov_b32 v17, 0\n\t"
+      "v_mov_b32 v18, 0\n\t"
+      "v_mov_b32 v19, 0\n\t"
+      "v_mov_b32 v20, 0\n\t"
+      "v_mov_b32 v21, 0\n\t"
+      "v_mov_b32 v22, 0\n\t"
+      "v_mov_b32 v23, 0\n\t"
+      "v_mov_b32 v24, 0\n\t"
+      "v_mov_b32 v25, 0\n\t"
+      "v_mov_b32 v26, 0\n\t"
+      "v_mov_b32 v27, 0\n\t"
+      "v_mov_b32 v28, 0\n\t"
+      "v_mov_b32 v29, 0\n\t"
+      "v_mov_b32 v30, 0\n\t"
+      "v_mov_b32 v31, 0\n\t"
+      "v_mov_b32 v32, 0\n\t"
+      "v_mov_b32 v33, 0\n\t"
+      "v_mov_b32 v34, 0\n\t"
+      "v_mov_b32 v35, 0\n\t"
+      "v_mov_b32 v36, 0\n\t"
+      "v_mov_b32 v37, 0\n\t"
+      "v_mov_b32 v38, 0\n\t"
+      "v_mov_b32 v39, 0\n\t"
+      "v_mov_b32 v40, 0\n\t"
+      "v_mov_b32 v41, 0\n\t"
+      "v_mov_b32 v42, 0\n\t"
+      "v_mov_b32 v43, 0\n\t"
+      "v_mov_b32 v44, 0\n\t"
+      "v_mov_b32 v45, 0\n\t"
+      "v_mov_b32 v46, 0\n\t"
+      "v_mov_b32 v47, 0\n\t"
+      "v_mov_b32 v48, 0\n\t"
+      "v_mov_b32 v49, 0\n\t"
+      "v_mov_b32 v50, 0\n\t"
+      "v_mov_b32 v51, 0\n\t"
+      "v_mov_b32 v52, 0\n\t"
+      "v_mov_b32 v53, 0\n\t"
+      "v_mov_b32 v54, 0\n\t"
+      "v_mov_b32 v55, 0\n\t"
+      "v_mov_b32 v56, 0\n\t"
+      "v_mov_b32 v57, 0\n\t"
+      "v_mov_b32 v58, 0\n\t"
+      "v_mov_b32 v59, 0\n\t"
+      "v_mov_b32 v60, 0\n\t"
+      "v_mov_b32 v61, 0\n\t"
+      "v_mov_b32 v62, 0\n\t"
+      "v_mov_b32 v63, 0\n\t"
+      "v_mov_b32 v64, 0\n\t"
+      "v_mov_b32 v65, 0\n\t"
+      "v_mov_b32 v66, 0\n\t"
+      "v_mov_b32 v67, 0\n\t"
+      "v_mov_b32 v68, 0\n\t"
+      "v_mov_b32 v69, 0\n\t"
+      "v_mov_b32 v70, 0\n\t"
+      "v_mov_b32 v71, 0\n\t"
+      "v_mov_b32 v72, 0\n\t"
+      "v_mov_b32 v73, 0\n\t"
+      "v_mov_b32 v74, 0\n\t"
+      "v_mov_b32 v75, 0\n\t"
+      "v_mov_b32 v76, 0\n\t"
+      "v_mov_b32 v77, 0\n\t"
+      "v_mov_b32 v78, 0\n\t"
+      "v_mov_b32 v79, 0\n\t"
+      "v_mov_b32 v80, 0\n\t"
+      "v_mov_b32 v81, 0\n\t"
+      "v_mov_b32 v82, 0\n\t"
+      "v_mov_b32 v83, 0\n\t"
+      "v_mov_b32 v84, 0\n\t"
+      "v_mov_b32 v85, 0\n\t"
+      "v_mov_b32 v86, 0\n\t"
+      "v_mov_b32 v87, 0\n\t"
+      "v_mov_b32 v88, 0\n\t"
+      "v_mov_b32 v89, 0\n\t"
+      "v_mov_b32 v90, 0\n\t"
+      "v_mov_b32 v91, 0\n\t"
+      "v_mov_b32 v92, 0\n\t"
+      "v_mov_b32 v93, 0\n\t"
+      "v_mov_b32 v94, 0\n\t"
+      "v_mov_b32 v95, 0\n\t"
+      "v_mov_b32 v96, 0\n\t"
+      "v_mov_b32 v97, 0\n\t"
+      "v_mov_b32 v98, 0\n\t"
+      "v_mov_b32 v99, 0\n\t"
+      "v_mov_b32 v100, 0\n\t"
+      "v_mov_b32 v101, 0\n\t"
+      "v_mov_b32 v102, 0\n\t"
+      "v_mov_b32 v103, 0\n\t"
+      "v_mov_b32 v104, 0\n\t"
+      "v_mov_b32 v105, 0\n\t"
+      "v_mov_b32 v106, 0\n\t"
+      "v_mov_b32 v107, 0\n\t"
+      "v_mov_b32 v108, 0\n\t"
+      "v_mov_b32 v109, 0\n\t"
+      "v_mov_b32 v110, 0\n\t"
+      "v_mov_b32 v111, 0\n\t"
+      "v_mov_b32 v112, 0\n\t"
+      "v_mov_b32 v113, 0\n\t"
+      "v_mov_b32 v114, 0\n\t"
+      "v_mov_b32 v115, 0\n\t"
+      "v_mov_b32 v116, 0\n\t"
+      "v_mov_b32 v117, 0\n\t"
+      "v_mov_b32 v118, 0\n\t"
+      "v_mov_b32 v119, 0\n\t"
+      "v_mov_b32 v120, 0\n\t"
+      "v_mov_b32 v121, 0\n\t"
+      "v_mov_b32 v122, 0\n\t"
+      "v_mov_b32 v123, 0\n\t"
+      "v_mov_b32 v124, 0\n\t"
+      "v_mov_b32 v125, 0\n\t"
+      "v_mov_b32 v126, 0\n\t"
+      "v_mov_b32 v127, 0\n\t"
+      ::: "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143");
+   asm volatile(
+      "v_mov_b32 v128, %0\n\t"
+      "v_mov_b32 v129, %1\n\t"
+      "v_mov_b32 v130, %2\n\t"
+      "v_mov_b32 v131, %3\n\t"
+      "v_mov_b32 v132, %0\n\t"
+      "v_mov_b32 v133, %1\n\t"
+      "v_mov_b32 v134, %2\n\t"
+      "v_mov_b32 v135, %3\n\t"
+      "v_mov_b32 v136, %0\n\t"
+      "v_mov_b32 v137, %1\n\t"
+      "v_mov_b32 v138, %2\n\t"
+      "v_mov_b32 v139, %3\n\t"
+      "v_mov_b32 v140, %0\n\t"
+      "v_mov_b32 v141, %1\n\t"
+      "v_mov_b32 v142, %2\n\t"
+      "v_mov_b32 v143, %3\n\t"
+      :: "v"(f0), "v"(f1), "v"(f2), "v"(f3) : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143");
+   for (int it = 0; it < iters; it++) {
+      asm volatile(
+         "v_mfma_i32_32x32x32_i8 v[0:15], v[128:131], v[136:139], v[0:15]\n\t"
+         "v_mfma_i32_32x32x32_i8 v[16:31], v[132:135], v[136:139], v[16:31]\n\t"
+         "v_mfma_i32_32x32x32_i8 v[32:47], v[128:131], v[140:143], v[32:47]\n\t"
+         "v_mfma_i32_32x32x32_i8 v[48:63], v[132:135], v[140:143], v[48:63]\n\t"
+         "v_mfma_i32_32x32x32_i8 v[64:79], v[128:131], v[136:139], v[64:79]\n\t"
+         "v_mfma_i32_32x32x32_i8 v[80:95], v[132:135], v[136:139], v[80:95]\n\t"
+         "v_mfma_i32_32x32x32_i8 v[96:111], v[128:131], v[140:143], v[96:111]\n\t"
+         "v_mfma_i32_32x32x32_i8 v[112:127], v[132:135], v[140:143], v[112:127]\n\t"
+         ::: "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143");
+   }
+   int r;
+   asm volatile("s_nop 7\n\ts_nop 7\n\tv_mov_b32 %0, v0" : "=v"(r)::"v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143");
+   if (r == 0x7fffffff) out[threadIdx.x] = r;
+}
+
+double mfma_i8_peak_tops(int waves_per_simd, int iters, uint32_t fill, hipStream_t stream)
+{
+   int *d = nullptr;
+   (void)hipMalloc(&d, 4096);
+   const int blocks = 256 * waves_per_simd;
+   hipEvent_t e0, e1;
+   (void)hipEventCreate(&e0);
+   (void)hipEventCreate(&e1);
+   hipLaunchKernelGGL(k_mfma_i8_peak, dim3(blocks), dim3(256), 0, stream, d, iters / 10, fill);
+   (void)hipEventRecord(e0, stream);
+   hipLaunchKernelGGL(k_mfma_i8_peak, dim3(blocks), dim3(256), 0, stream, d, iters, fill);
+   (void)hipEventRecord(e1, stream);
+   (void)hipEventSynchronize(e1);
+   float ms = 0;
+   (void)hipEventElapsedTime(&ms, e0, e1);
+   (void)hipEventDestroy(e0);
+   (void)hipEventDestroy(e1);
+   (void)hipFree(d);
+   const double ops = (double)blocks * 4 /*waves*/ * (double)iters * 8 * 65536.0;
+   return ops / (ms * 1e-3) / 1e12;
 }
 
 } // namespace kern

@@ -225,7 +225,8 @@ int fpca_debug_mfma_probe(const double *A, const double *B, double *D);
 int fpca_debug_mfma_i8_probe(const int8_t *A, const int8_t *Bt, int32_t *D);
 /* diagnostic: sustained rate (TFLOP/s) of a pure v_mfma_f64_16x16x4_f64 stream with `waves_per_simd` (1..8) resident
  * waves per SIMD and no memory traffic; pattern 0..3 selects the operand-register sharing pattern (kernels.hip).  The
- * practical ceiling to read the GEMM kernels' roofline fraction against (72-74 TFLOP/s at 2 waves/SIMD vs 78.6 datasheet) */
+ * practical ceiling to read the GEMM kernels' roofline fraction against (72-74 TFLOP/s at 2 waves/SIMD vs 78.6 datasheet).
+ * pattern 10 / 11: v_mfma_i32_32x32x32_i8 in TOP/s with zero / pseudo-random operands. */
 int fpca_debug_mfma_peak(int waves_per_simd, int iters, int pattern, double *tflops);
 /* diagnostic: placement census of an nwg-workgroup grid (256 threads, lds_bytes dynamic LDS each): out[2i] = HW_ID,
  * out[2i+1] = XCC_ID of workgroup i */
