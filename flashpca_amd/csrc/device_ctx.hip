@@ -241,8 +241,9 @@ void ensure_stats(fpca_ctx *c)
 }
 
 // ---- exact-integer mode --------------------------------------------------------------------------------
-// weights / scratch layout in d_i8w (doubles): [0,512) wB, [512,1024) wg, [1024,1536) wm, [1536,1536+128) scratch
-constexpr int I8W_B = 0, I8W_G = 512, I8W_M = 1024, I8W_SCR = 1536, I8W_TOTAL = 1536 + 128;
+// weights / scratch layout in d_i8w (8-byte words, S*b <= 9*64 = 576 each): wB, wg, wm, column sums, scratch
+constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_CS = 1920 /* int64 column sums of the M operand */, I8W_SCR = 2560,
+              I8W_TOTAL = 2560 + 128;
 
 void ensure_i8(fpca_ctx *c, int b)
 {
@@ -293,17 +294,19 @@ void ensure_i8(fpca_ctx *c, int b)
 // T = X' B : slices of B against the SNP-major stream, per-SNP mean / sd applied in the exact combine
 void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s)
 {
-   kern::slice_operand(dB, nullptr, c->N_pad, c->N, b, c->i8_S, c->d_Qb, c->d_i8w + I8W_B, c->d_i8w + I8W_SCR, s);
-   kern::gemm_i8(c->d_packed, c->pitch, c->d_Qb, c->d_Qb, c->d_i8w + I8W_B, c->d_i8w + I8W_B, c->d_mean, c->d_sd, c->d_T, c->d_i8ws,
+   long long *cs = reinterpret_cast<long long *>(c->d_i8w + I8W_CS);
+   kern::slice_operand(dB, nullptr, c->N_pad, c->N, b, c->i8_S, c->d_Qb, c->d_i8w + I8W_B, cs, c->d_i8w + I8W_SCR, s);
+   kern::gemm_i8(c->d_packed, c->pitch, c->d_Qb, c->d_Qb, c->d_i8w + I8W_B, c->d_i8w + I8W_B, cs, c->d_mean, c->d_sd, c->d_T, c->d_i8ws,
                  c->P_pad, c->N_pad, b, c->i8_S, s);
 }
 
 // Y = X T : slices of T/sd and mean T/sd against the sample-major copy
 void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s)
 {
-   kern::slice_operand(c->d_T, c->d_inv_sd, c->P_pad, c->P_g, b, c->i8_S, c->d_Qg, c->d_i8w + I8W_G, c->d_i8w + I8W_SCR, s);
-   kern::slice_operand(c->d_T, c->d_mu_inv_sd, c->P_pad, c->P_g, b, c->i8_S, c->d_Qm, c->d_i8w + I8W_M, c->d_i8w + I8W_SCR, s);
-   kern::gemm_i8(c->d_packedT, c->pitchT, c->d_Qg, c->d_Qm, c->d_i8w + I8W_G, c->d_i8w + I8W_M, nullptr, nullptr, dY, c->d_i8ws,
+   long long *cs = reinterpret_cast<long long *>(c->d_i8w + I8W_CS);
+   kern::slice_operand(c->d_T, c->d_inv_sd, c->P_pad, c->P_g, b, c->i8_S, c->d_Qg, c->d_i8w + I8W_G, nullptr, c->d_i8w + I8W_SCR, s);
+   kern::slice_operand(c->d_T, c->d_mu_inv_sd, c->P_pad, c->P_g, b, c->i8_S, c->d_Qm, c->d_i8w + I8W_M, cs, c->d_i8w + I8W_SCR, s);
+   kern::gemm_i8(c->d_packedT, c->pitchT, c->d_Qg, c->d_Qm, c->d_i8w + I8W_G, c->d_i8w + I8W_M, cs, nullptr, nullptr, dY, c->d_i8ws,
                  c->N_pad, c->P_pad, b, c->i8_S, s);
 }
 

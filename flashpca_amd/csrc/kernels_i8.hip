@@ -49,17 +49,23 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_colmax(const double *__restrict__ V, const double *__restrict__ rowscale,
                                                 uint64_t rows, int b, unsigned long long *__restrict__ colmax_bits)
 {
+   __shared__ double smax[256];
    const int c = threadIdx.x % b;
    const int r_in = threadIdx.x / b, r_step = 256 / b;
-   if (r_in >= r_step) return;
    double m = 0.0;
-   for (uint64_t r = (uint64_t)blockIdx.x * r_step + r_in; r < rows; r += (uint64_t)gridDim.x * r_step) {
-      double v = V[r * b + c];
-      if (rowscale) v *= rowscale[r];
-      v = fabs(v);
-      if (v > m) m = v; // NaN never wins: a NaN operand would poison the fp64 path as well
+   if (r_in < r_step)
+      for (uint64_t r = (uint64_t)blockIdx.x * r_step + r_in; r < rows; r += (uint64_t)gridDim.x * r_step) {
+         double v = V[r * b + c];
+         if (rowscale) v *= rowscale[r];
+         v = fabs(v);
+         if (v > m) m = v; // NaN never wins: a NaN operand would poison the fp64 path as well
+      }
+   smax[threadIdx.x] = m;
+   __syncthreads();
+   if (threadIdx.x < b) {
+      for (int k = 1; k < r_step; k++) m = fmax(m, smax[k * b + threadIdx.x]);
+      atomicMax(&colmax_bits[threadIdx.x], (unsigned long long)__double_as_longlong(m));
    }
-   atomicMax(&colmax_bits[c], (unsigned long long)__double_as_longlong(m));
 }
 
 // weights: colw[s*b + c] = 2^e_c / 64 / 128^s with 2^e_c > max|column c|  (e_c from frexp; zero column -> e = 0)
@@ -79,40 +85,61 @@ __global__ void k_slice_weights(const unsigned long long *__restrict__ colmax_bi
    }
 }
 
-// one thread = one 16-row group of one column: 16 strided fp64 in, one 16-byte store per slice out
+// one thread = one 16-row group of one column: 16 strided fp64 in, one 16-byte store per slice out; optionally the
+// exact integer column sums of every slice (for  M'Q = 1'Q - E'Q, see k_gemm_i8) -- block-reduced, one atomic per
+// slice-column per block
 __global__ __launch_bounds__(256) void k_slice(const double *__restrict__ V, const double *__restrict__ rowscale, uint64_t rows_pad,
                                                uint64_t rows, int b, int S, const double *__restrict__ colinv,
-                                               int8_t *__restrict__ Q)
+                                               int8_t *__restrict__ Q, long long *__restrict__ colsum)
 {
+   __shared__ int ssum[9][256];
    const uint64_t groups = rows_pad / 16;
-   for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < groups * b; t += (uint64_t)gridDim.x * 256) {
-      const int c = (int)(t % b);
-      const uint64_t r0 = (t / b) * 16;
-      const double sc = colinv[c] * 64.0;
+   const int c = threadIdx.x % b, gl = threadIdx.x / b, gpb = 256 / b; // column, local group, groups per block
+   const double sc = colinv[c] * 64.0;
+   for (uint64_t g0 = (uint64_t)blockIdx.x * gpb; g0 < groups; g0 += (uint64_t)gridDim.x * gpb) {
+      const uint64_t g = g0 + gl;
+      const bool act = gl < gpb && g < groups;
+      const uint64_t r0 = g * 16;
       double q[16];
 #pragma unroll
       for (int j = 0; j < 16; j++) {
          const uint64_t r = r0 + j;
-         double v = (r < rows) ? V[r * b + c] : 0.0;
-         if (rowscale && r < rows) v *= rowscale[r];
+         double v = (act && r < rows) ? V[r * b + c] : 0.0;
+         if (rowscale && act && r < rows) v *= rowscale[r];
          q[j] = v * sc; // |q| < 64; exact (power-of-two scaling)
       }
       for (int s = 0; s < S; s++) {
          u4 word = {0u, 0u, 0u, 0u};
+         int tot = 0;
 #pragma unroll
          for (int j = 0; j < 16; j++) {
             const double d = rint(q[j]);
             q[j] = (q[j] - d) * 128.0; // exact
+            tot += (int)d;
             word[j & 3] |= ((uint32_t)(int)d & 0xFFu) << (8 * (j >> 2)); // position 4 (j&3) + (j>>2)
          }
-         *reinterpret_cast<u4 *>(Q + ((uint64_t)(s * b + c)) * rows_pad + r0) = word;
+         if (act) *reinterpret_cast<u4 *>(Q + ((uint64_t)(s * b + c)) * rows_pad + r0) = word;
+         ssum[s][threadIdx.x] = tot;
+      }
+      if (colsum) {
+         __syncthreads();
+         for (int t = threadIdx.x; t < S * b; t += 256) {
+            const int s = t / b, cc = t % b;
+            long long a = 0;
+            for (int k = 0; k < gpb; k++) a += ssum[s][k * b + cc];
+            if (a) atomicAdd(reinterpret_cast<unsigned long long *>(&colsum[t]), (unsigned long long)a);
+         }
+         __syncthreads();
       }
    }
 }
 
 void slice_operand(const double *V, const double *rowscale, uint64_t rows_pad, uint64_t rows, int b, int S, int8_t *Q,
-                   double *colw /* [S*b] */, double *scratch /* >= 2*b doubles */, hipStream_t stream)
+                   double *colw /* [S*b] */, long long *colsum /* [S*b] or null */, double *scratch /* >= 2*b doubles */,
+                   hipStream_t stream)
 {
+   if (S > 9 || b > 64) throw Error(-1, "slice_operand: S <= 9 and b <= 64");
+   if (colsum) (void)hipMemsetAsync(colsum, 0, sizeof(long long) * S * b, stream);
    unsigned long long *bits = reinterpret_cast<unsigned long long *>(scratch);
    double *colinv = scratch + b;
    (void)hipMemsetAsync(bits, 0, sizeof(unsigned long long) * b, stream);
@@ -121,37 +148,30 @@ void slice_operand(const double *V, const double *rowscale, uint64_t rows_pad, u
    HIP_CHECK_LAUNCH();
    hipLaunchKernelGGL(k_slice_weights, dim3(1), dim3(64), 0, stream, bits, b, S, colw, colinv);
    HIP_CHECK_LAUNCH();
-   blocks = (unsigned)std::min<uint64_t>(16384, (rows_pad / 16 * b + 255) / 256);
-   hipLaunchKernelGGL(k_slice, dim3(blocks), dim3(256), 0, stream, V, rowscale, rows_pad, rows, b, S, colinv, Q);
+   blocks = (unsigned)std::min<uint64_t>(16384, (rows_pad / 16 + (256 / b) - 1) / (256 / b));
+   hipLaunchKernelGGL(k_slice, dim3(blocks), dim3(256), 0, stream, V, rowscale, rows_pad, rows, b, S, colinv, Q, colsum);
    HIP_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------
 // K2i / K3i core:  acc[row][sc] = sum_k A[row][k] * Q[sc][k]  for A in {G.M, M}
 //   `packed`: 2-bit records, one per output row (K2: the SNP-major stream, K = samples; K3: its sample-major copy,
-//   K = SNPs).  Workgroup = 4 waves, ONE wave per SIMD with the whole 512-register budget (256 accumulator AGPRs):
-//     K2 (TWO = false): both integer matrices multiply the same operand Q; workgroup tile 128 rows x 256 columns,
-//                       wave = 64 rows x 128 columns (MT = 2, NT = 4) x 2 matrices
-//     K3 (TWO = true) : G.M multiplies Qg (slices of T/sd), M multiplies Qm (slices of mean T/sd); workgroup tile
-//                       256 rows x 128 columns of each operand, wave = 128 rows x 64 columns (MT = 4, NT = 2)
-//   so that either way a 256-k chunk costs 64 KB of operand staging for 128 MFMAs per wave and a 32-k step needs 4
-//   ds_read_b128 and 15 MT decode ops for 16 MFMAs of 8 passes.
-//   Operand tiles [columns][256 k] are double-buffered in LDS (row stride 272 B: the 16 lanes of a ds_read_b128 group
-//   hit distinct banks); the packed words go straight from global memory to the registers of the lane that decodes them.
+//   K = SNPs).  TWO = false (K2): both integer matrices multiply the same operand Q.  TWO = true (K3): G.M multiplies
+//   Qg (slices of T/sd), M multiplies Qm (slices of mean T/sd).
+//   Workgroup = 4 waves, ONE wave per SIMD with the whole 512-register budget (up to 256 accumulator AGPRs), arranged
+//   WR x WC; a wave owns MT x NT tiles of 32x32 of both matrices (2 MT NT <= 16 accumulators).  Operand tiles
+//   [WC NT 32 columns][KC k] are double-buffered in LDS (row stride KC + 16 B: the 16 lanes of a ds_read_b128 group hit
+//   distinct banks); the packed words go straight from global memory to the registers of the lane that decodes them.
 //   Decode: a lane's dword w holds 16 codes; (w >> 2q) & 0x03030303 leaves codes q, q+4, q+8, q+12 in the four bytes
 //   and v_perm_b32 with the code as selector looks G.M / M up in a 4-byte table -- 4 VALU ops per operand dword
 //   pair; the Q bytes were stored in the matching order by k_slice.
 //   Scheduling: with one wave per SIMD only the wave's own instruction order hides latency, and hipcc left alone
 //   sinks every LDS read to just before its MFMAs and waits at once (measured: matrix pipe 42 % busy).  The loop body is
-//   therefore a fixed pipeline of micro-steps (k-step, m-tile) = 8 MFMAs each, fenced by sched_barrier(0), with
-//   explicit (asm) loads and hand-counted s_waitcnt: operand fragments of the next k-step are read from LDS one k-step
-//   ahead, the next micro-step's genotype fragments are decoded under this one's MFMAs, and the next chunk's global
-//   loads (first half of the chunk) and LDS stores (second half) ride in the MFMA shadow instead of a burst at the
-//   chunk boundary.
+//   therefore a fixed pipeline of micro-steps (k-step, m-tile, n-group) fenced by sched_barrier(0), with explicit (asm)
+//   loads and hand-counted s_waitcnt: the operand fragments of the next micro-step are read from LDS and its genotype
+//   fragments decoded under this one's MFMAs, and the next chunk's global loads (first half of the chunk) and LDS
+//   stores (second half) ride in the MFMA shadow instead of a burst at the chunk boundary.
 //   Output: int32 partials part[split][row][mat][NSC], combined exactly by k_i8_combine.
-constexpr int I8_KC = 256;
-constexpr int I8_LDQ = I8_KC + 16;
-
 template <int OFF>
 __device__ __forceinline__ v4i lds_read16(uint32_t addr) // explicit LDS read: the caller places the s_waitcnt
 {
@@ -174,11 +194,6 @@ __device__ __forceinline__ void vm_wait(u4 &a)
 {
    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N));
 }
-template <int N>
-__device__ __forceinline__ void vm_wait(u4 &a, u4 &b)
-{
-   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
-}
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
 {
@@ -190,20 +205,32 @@ __device__ __forceinline__ void static_for(F &&f)
    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <bool TWO>
+template <bool TWO_, int MT_, int NT_, int WR_, int WC_, int KC_, int G_>
 struct I8Cfg {
-   static constexpr int MT = TWO ? 4 : 2, NT = TWO ? 2 : 4, NQ = TWO ? 2 : 1;
-   static constexpr int ROWS = 64 * MT;                 // workgroup rows (2 wave rows)
-   static constexpr int COLS = 64 * NT;                 // workgroup columns of each operand (2 wave columns)
-   static constexpr int QTILE = COLS * I8_LDQ;          // bytes of one operand tile
-   static constexpr int STAGE = NQ * QTILE;             // 69632 either way
-   static constexpr int NPIECE = NQ * COLS * (I8_KC / 16) / 256; // 16-byte pieces per thread per chunk: 16
-   static constexpr int NSTEP = (I8_KC / 32) * MT;      // micro-steps per chunk: 16 / 32
+   static constexpr bool TWO = TWO_;
+   static constexpr int MT = MT_, NT = NT_, WR = WR_, WC = WC_, KC = KC_, G = G_, NQ = TWO ? 2 : 1;
+   static_assert(WR * WC == 4 && 2 * MT * NT <= 16 && (MT == 1 || G == 1) && G <= NT, "shape");
+   static constexpr int ROWS = WR * MT * 32;            // workgroup rows
+   static constexpr int COLS = WC * NT * 32;            // workgroup columns of each operand
+   static constexpr int LDQ = KC + 16;                  // operand tile row stride (bytes)
+   static constexpr int QTILE = COLS * LDQ;             // bytes of one operand tile
+   static constexpr int STAGE = NQ * QTILE;
+   static constexpr int SEGS = KC / 16, RSTEP = 256 / SEGS; // 16-byte segments per row; rows covered by 256 threads
+   static constexpr int NP1 = COLS / RSTEP;             // pieces per thread per operand tile
+   static constexpr int NP = NQ * NP1;                  // ... per chunk
+   static constexpr int KS = KC / 32;                   // 32-k steps per chunk
+   static constexpr int PW = KC / 128;                  // 16-byte packed pieces per lane per m-tile (lane half = KC/2 k)
+   static constexpr int NSTEP = KS * MT * G;            // micro-steps per chunk
+   static constexpr int H = NSTEP / 2;
+   static_assert(COLS % RSTEP == 0 && NSTEP % 2 == 0 && STAGE * 2 <= 160 * 1024, "staging");
 };
 
 __device__ __forceinline__ void i8_decode(uint32_t w, v4i &ag, v4i &am)
 {
-   const uint32_t tabG = 0x00010002u, tabM = 0x01010001u; // byte[code]: code 0 -> (2,1), 1 (missing) -> (0,0), 2 -> (1,1), 3 -> (0,1)
+   // byte[code] of the two integer matrices: G.M (dosage, 0 if missing) and E = 1 - M (missing indicator): code 0 -> (2,0),
+   // 1 (missing) -> (0,1), 2 -> (1,0), 3 -> (0,0).  E instead of M because E is almost all zeros: the products vanish and
+   // the power-limited matrix pipe clocks higher; M'Q is recovered exactly in the combine as 1'Q - E'Q.
+   const uint32_t tabG = 0x00010002u, tabM = 0x00000100u;
 #pragma unroll
    for (int q = 0; q < 4; q++) {
       const uint32_t sel = (w >> (2 * q)) & 0x03030303u;
@@ -212,26 +239,24 @@ __device__ __forceinline__ void i8_decode(uint32_t w, v4i &ag, v4i &am)
    }
 }
 
-template <bool TWO>
+template <class C>
 __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ packed, size_t pitch,
                                                      const int8_t *__restrict__ Qg, const int8_t *__restrict__ Qm,
                                                      uint64_t k_pad, int nsc_total, int *__restrict__ part, uint64_t rows_pad,
                                                      int chunks_total, int chunks_per_split)
 {
-   using C = I8Cfg<TWO>;
-   constexpr int MT = C::MT, NT = C::NT, NQ = C::NQ, KS = I8_KC / 32, NP = C::NPIECE, NSTEP = C::NSTEP, LDQ = I8_LDQ;
-   constexpr int H = NSTEP / 2, LP = NP / H; // staging: LP loads per micro-step in the first half, LP stores in the second
-   static_assert(NP == 16 && LP * H == NP, "staging schedule");
+   constexpr bool TWO = C::TWO;
+   constexpr int MT = C::MT, NT = C::NT, NQ = C::NQ, KC = C::KC, NP = C::NP, NP1 = C::NP1, NSTEP = C::NSTEP, LDQ = C::LDQ,
+                 H = C::H, G = C::G, PW = C::PW, NPK = MT * PW;
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int li = lane & 31, kh = lane >> 5;
-   const int wr = wave >> 1, wc = wave & 1;
+   const int wr = wave / C::WC, wc = wave % C::WC;
    const uint64_t row0 = (uint64_t)blockIdx.x * C::ROWS;
    const int col0 = blockIdx.z * C::COLS;
    const int c_begin = blockIdx.y * chunks_per_split;
    int c_end = c_begin + chunks_per_split;
    if (c_end > chunks_total) c_end = chunks_total;
-   if (c_begin >= c_end) c_end = c_begin; // (cannot happen with the host's split choice)
 
    v16i acc[2][MT][NT]; // [mat][m][n]
 #pragma unroll
@@ -243,129 +268,131 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][m][n][r] = 0;
 
-   // operand staging: piece r of this thread = row tid/16 + 16 (r % (NP/NQ)) of operand r / (NP/NQ), segment tid % 16;
-   // LDS destination = qdst + r * 16 * LDQ for both shapes (QTILE == (NP/NQ) * 16 * LDQ)
-   static_assert(C::QTILE == (NP / NQ) * 16 * LDQ, "piece stride");
-   const uint32_t qvoff = (uint32_t)((tid >> 4) * k_pad + (tid & 15) * 16);
+   // operand staging: piece r of this thread = operand r / NP1, row tid / SEGS + RSTEP (r % NP1), segment tid % SEGS
+   const uint32_t qvoff = (uint32_t)((tid / C::SEGS) * k_pad + (tid % C::SEGS) * 16);
    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-   const int qdst = (tid >> 4) * LDQ + (tid & 15) * 16;
-   // packed words: lane (li, kh) of wave row wr decodes rows wr*32*MT + 32 m + li, k = 128 kh + 16 ks .. of the chunk
+   const int qdst = (tid / C::SEGS) * LDQ + (tid % C::SEGS) * 16;
+   // packed words: lane (li, kh) of wave row wr decodes rows wr*32*MT + 32 m + li, k = (KC/2) kh + 16 ks .. of the chunk
    uint32_t pvoff[MT];
 #pragma unroll
-   for (int m = 0; m < MT; m++) pvoff[m] = (uint32_t)((wr * 32 * MT + 32 * m + li) * pitch + kh * 32);
+   for (int m = 0; m < MT; m++) pvoff[m] = (uint32_t)((wr * 32 * MT + 32 * m + li) * pitch + kh * (KC / 8));
    const uint8_t *prow = packed + row0 * pitch;
-   const uint32_t aQ0 = lds_base + (uint32_t)(wc * 32 * NT + li) * LDQ + kh * 128;
+   const uint32_t aQ0 = lds_base + (uint32_t)(wc * 32 * NT + li) * LDQ + kh * (KC / 2);
 
    u4 qreg[NP];
-   u4 pk[MT][2], pkn[MT][2]; // packed words of the current / next chunk (8 dwords = 8 k-steps per m-tile)
+   u4 pk[MT][PW], pkn[MT][PW]; // packed words of the current / next chunk (one dword per k-step)
 
-   // prologue: chunk c_begin
-   {
-      const int c = c_begin;
-      static_for<NP>([&](auto rr) {
-         constexpr int r = decltype(rr)::value, o = r / (NP / NQ), r1 = r % (NP / NQ);
-         const int8_t *sb = ((TWO && o) ? Qm : Qg) + (uint64_t)(col0 + 16 * r1) * k_pad + (uint64_t)c * I8_KC;
-         qreg[r] = gload16<0>(sb, qvoff);
-      });
+   auto issue_q = [&](auto rr, int cc) {
+      constexpr int r = decltype(rr)::value, o = r / NP1, r1 = r % NP1;
+      const int8_t *sb = ((TWO && o) ? Qm : Qg) + (uint64_t)(col0 + C::RSTEP * r1) * k_pad + (uint64_t)cc * KC;
+      qreg[r] = gload16<0>(sb, qvoff);
+   };
+   auto issue_p = [&](u4(&dst)[MT][PW], int cc) {
+      const uint8_t *pb = prow + (size_t)cc * (KC / 4);
 #pragma unroll
       for (int m = 0; m < MT; m++) {
-         pk[m][0] = gload16<0>(prow + (size_t)c * (I8_KC / 4), pvoff[m]);
-         pk[m][1] = gload16<16>(prow + (size_t)c * (I8_KC / 4), pvoff[m]);
+         dst[m][0] = gload16<0>(pb, pvoff[m]);
+         if constexpr (PW == 2) dst[m][1] = gload16<16>(pb, pvoff[m]);
       }
-      static_for<NP>([&](auto rr) {
-         constexpr int r = decltype(rr)::value;
-         vm_wait<NP - 1 - r + 2 * MT>(qreg[r]);
-         *reinterpret_cast<u4 *>(smem + qdst + r * 16 * LDQ) = qreg[r];
-      });
+   };
+   auto store_q = [&](auto rr, unsigned char *st) {
+      constexpr int r = decltype(rr)::value, o = r / NP1, r1 = r % NP1;
+      vm_wait<NP - 1 - r + NPK>(qreg[r]); // loads are issued in the order q[0..NP), p[..]
+      *reinterpret_cast<u4 *>(st + o * C::QTILE + r1 * C::RSTEP * LDQ) = qreg[r];
+   };
+
+   // prologue: chunk c_begin
+   static_for<NP>([&](auto rr) { issue_q(rr, c_begin); });
+   issue_p(pk, c_begin);
+   static_for<NP>([&](auto rr) { store_q(rr, smem + qdst); });
 #pragma unroll
-      for (int m = 0; m < MT; m++) vm_wait<0>(pk[m][0], pk[m][1]);
-   }
+   for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int h = 0; h < PW; h++) vm_wait<0>(pk[m][h]);
    __syncthreads();
 
    for (int c = c_begin; c < c_end; c++) {
       const int buf = (c - c_begin) & 1;
       const int cn = (c + 1 < c_end) ? c + 1 : c; // the last chunk re-stages itself (branch-free pipeline)
-      const uint32_t aQ = aQ0 + (uint32_t)buf * C::STAGE;
+      const uint32_t aQ = aQ0 + (uint32_t)buf * C::STAGE, aQ2 = aQ + C::QTILE;
       unsigned char *wst = smem + (size_t)(buf ^ 1) * C::STAGE + qdst;
-      const uint8_t *pnext = prow + (size_t)cn * (I8_KC / 4);
 
-      v4i bq[2][NQ][NT]; // operand fragments, index = k-step parity
-      v4i ag[2], am[2];  // decoded genotype fragments, index = micro-step parity
-      static_for<NT>([&](auto nn) {
-         constexpr int n = decltype(nn)::value;
-         bq[0][0][n] = lds_read16<32 * n * LDQ>(aQ);
-         if (TWO) bq[0][NQ - 1][n] = lds_read16<C::QTILE + 32 * n * LDQ>(aQ);
-      });
+      // micro-step s -> (ks, m, g); operand fragments are keyed by (ks, g), genotype fragments by (ks, m)
+      constexpr int NG = (NT + G - 1) / G; // n-tiles per group (the last group may be shorter)
+      v4i bq[2][NQ][NG];
+      v4i ag[2], am[2];
+      auto read_b = [&](auto kk, auto gg, auto par) {
+         constexpr int ks = decltype(kk)::value, g = decltype(gg)::value, p = decltype(par)::value;
+         static_for<NG>([&](auto jj) {
+            constexpr int j = decltype(jj)::value, n = g * NG + j;
+            if constexpr (n < NT) {
+               bq[p][0][j] = lds_read16<32 * n * LDQ + ks * 16>(aQ);
+               if constexpr (TWO) bq[p][NQ - 1][j] = lds_read16<32 * n * LDQ + ks * 16>(aQ2);
+            }
+         });
+      };
+      auto wait_b = [&](auto gg, auto par) {
+         constexpr int g = decltype(gg)::value, p = decltype(par)::value;
+         static_for<NG>([&](auto jj) {
+            constexpr int j = decltype(jj)::value, n = g * NG + j;
+            if constexpr (n < NT) {
+               if constexpr (TWO)
+                  lds_wait(bq[p][0][j], bq[p][NQ - 1][j]);
+               else
+                  lds_wait(bq[p][0][j]);
+            }
+         });
+      };
+      read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       i8_decode(pk[0][0][0], ag[0], am[0]);
-      static_for<NT>([&](auto nn) {
-         constexpr int n = decltype(nn)::value;
-         if (TWO)
-            lds_wait(bq[0][0][n], bq[0][NQ - 1][n]);
-         else
-            lds_wait(bq[0][0][n]);
-      });
+      wait_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       __builtin_amdgcn_sched_barrier(0);
 
       static_for<NSTEP>([&](auto ss) {
-         constexpr int s = decltype(ss)::value, ks = s / MT, m = s % MT, kp = ks & 1, sp = s & 1;
-         // --- staging of chunk cn: loads in the first half, P words at the half-way mark, LDS stores in the second half
+         constexpr int s = decltype(ss)::value;
+         constexpr int ks = s / (MT * G), m = (G == 1) ? s % MT : 0, g = (G == 1) ? 0 : s % G;
+         constexpr int bkey = ks * G + g, akey = ks * MT + m;
+         constexpr bool last = (s + 1 == NSTEP);
+         constexpr int s1 = last ? s : s + 1;
+         constexpr int ks1 = s1 / (MT * G), m1 = (G == 1) ? s1 % MT : 0, g1 = (G == 1) ? 0 : s1 % G;
+         constexpr int bkey1 = ks1 * G + g1, akey1 = ks1 * MT + m1;
+         // --- staging of chunk cn: loads in the first half, packed words at the half-way mark, LDS stores in the second
          if constexpr (s < H) {
-            static_for<LP>([&](auto jj) {
-               constexpr int r = s * LP + decltype(jj)::value, o = r / (NP / NQ), r1 = r % (NP / NQ);
-               const int8_t *sb = ((TWO && o) ? Qm : Qg) + (uint64_t)(col0 + 16 * r1) * k_pad + (uint64_t)cn * I8_KC;
-               qreg[r] = gload16<0>(sb, qvoff);
+            static_for<(s + 1) * NP / H - s * NP / H>([&](auto jj) {
+               issue_q(std::integral_constant<int, s * NP / H + decltype(jj)::value>{}, cn);
             });
          }
-         if constexpr (s == H - 1) {
-#pragma unroll
-            for (int mm = 0; mm < MT; mm++) {
-               pkn[mm][0] = gload16<0>(pnext, pvoff[mm]);
-               pkn[mm][1] = gload16<16>(pnext, pvoff[mm]);
-            }
-         }
+         if constexpr (s == H - 1) issue_p(pkn, cn);
          if constexpr (s >= H) {
-            static_for<LP>([&](auto jj) {
-               constexpr int r = (s - H) * LP + decltype(jj)::value;
-               vm_wait<NP - 1 - r + 2 * MT>(qreg[r]);
-               *reinterpret_cast<u4 *>(wst + r * 16 * LDQ) = qreg[r];
+            static_for<(s - H + 1) * NP / H - (s - H) * NP / H>([&](auto jj) {
+               store_q(std::integral_constant<int, (s - H) * NP / H + decltype(jj)::value>{}, wst);
             });
          }
-         // --- operand fragments of the next k-step
-         if constexpr (m == 0 && ks + 1 < KS) {
-            static_for<NT>([&](auto nn) {
-               constexpr int n = decltype(nn)::value;
-               bq[kp ^ 1][0][n] = lds_read16<32 * n * LDQ + (ks + 1) * 16>(aQ);
-               if (TWO) bq[kp ^ 1][NQ - 1][n] = lds_read16<C::QTILE + 32 * n * LDQ + (ks + 1) * 16>(aQ);
-            });
-         }
-         // --- 2 NT MFMAs of this micro-step, the next micro-step's decode in their shadow
-         static_for<NT>([&](auto nn) {
-            constexpr int n = decltype(nn)::value;
-            acc[0][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ag[sp], bq[kp][0][n], acc[0][m][n], 0, 0, 0);
-            acc[1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(am[sp], bq[kp][NQ - 1][n], acc[1][m][n], 0, 0, 0);
-            if constexpr (n == 0 && s + 1 < NSTEP) {
-               constexpr int s1 = s + 1, ks1 = s1 / MT, m1 = s1 % MT;
-               i8_decode(pk[m1][ks1 >> 2][ks1 & 3], ag[sp ^ 1], am[sp ^ 1]);
+         // --- operand fragments of the next micro-step
+         if constexpr (bkey1 != bkey)
+            read_b(std::integral_constant<int, ks1>{}, std::integral_constant<int, g1>{}, std::integral_constant<int, (bkey1 & 1)>{});
+         // --- this micro-step's MFMAs, the next micro-step's decode in their shadow
+         static_for<NG>([&](auto jj) {
+            constexpr int j = decltype(jj)::value, n = g * NG + j;
+            if constexpr (n < NT) {
+               acc[0][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ag[akey & 1], bq[bkey & 1][0][j], acc[0][m][n], 0, 0, 0);
+               acc[1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(am[akey & 1], bq[bkey & 1][NQ - 1][j], acc[1][m][n], 0, 0, 0);
             }
+            if constexpr (j == 0 && akey1 != akey) i8_decode(pk[m1][ks1 >> 2][ks1 & 3], ag[akey1 & 1], am[akey1 & 1]);
          });
          __builtin_amdgcn_sched_barrier(0);
-         if constexpr (m == MT - 1 && ks + 1 < KS) {
-            static_for<NT>([&](auto nn) {
-               constexpr int n = decltype(nn)::value;
-               if (TWO)
-                  lds_wait(bq[kp ^ 1][0][n], bq[kp ^ 1][NQ - 1][n]);
-               else
-                  lds_wait(bq[kp ^ 1][0][n]);
-            });
+         if constexpr (bkey1 != bkey) {
+            wait_b(std::integral_constant<int, g1>{}, std::integral_constant<int, (bkey1 & 1)>{});
             __builtin_amdgcn_sched_barrier(0);
          }
       });
 #pragma unroll
-      for (int m = 0; m < MT; m++) {
-         vm_wait<0>(pkn[m][0], pkn[m][1]);
-         pk[m][0] = pkn[m][0];
-         pk[m][1] = pkn[m][1];
-      }
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+         for (int h = 0; h < PW; h++) {
+            vm_wait<0>(pkn[m][h]);
+            pk[m][h] = pkn[m][h];
+         }
       __syncthreads();
    }
 
@@ -389,6 +416,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
 __global__ __launch_bounds__(256) void k_i8_combine(const int *__restrict__ part, int nsplit, uint64_t rows_pad, int b, int S,
                                                      int NSC /* row stride of the partials: S*b rounded up to 256 */,
                                                      const double *__restrict__ wg, const double *__restrict__ wm,
+                                                     const long long *__restrict__ colsum_m /* 1'Qm per slice-column */,
                                                      const double *__restrict__ mean, const double *__restrict__ sd,
                                                      double *__restrict__ out)
 {
@@ -404,7 +432,7 @@ __global__ __launch_bounds__(256) void k_i8_combine(const int *__restrict__ part
             m += p[NSC];
          }
          accg += wg[s * b + c] * (double)g;
-         accm += wm[s * b + c] * (double)m;
+         accm += wm[s * b + c] * (double)(colsum_m[s * b + c] - m); // M'Q = 1'Q - E'Q
       }
       double v;
       if (mean) {
@@ -416,16 +444,60 @@ __global__ __launch_bounds__(256) void k_i8_combine(const int *__restrict__ part
    }
 }
 
+// ---- shape selection ----
+// The slice-columns (S*b, rounded up to whole 32-column tiles) are cut into `zb` equal column blocks of NT tiles.
+//   shape 'B' (default): 4 x 1 waves, each 32 rows x all NT tiles (no redundant decode; KC = 256 for K2, 128 for K3)
+//   shape 'A'          : 2 x 2 waves, wave = 64 x 128 (K2) / 128 x 64 (K3), needs blocks of exactly 8 tiles
+struct I8Shape {
+   int nt, zb, rows, cols, kc;
+   bool a, c;
+};
+
+static I8Shape i8_shape(int S, int b, bool two)
+{
+   static const char *env = getenv("FPCA_I8_SHAPE");
+   const int tiles = (S * b + 31) / 32;
+   I8Shape sh;
+   sh.zb = (tiles + 7) / 8;
+   sh.nt = (tiles + sh.zb - 1) / sh.zb;
+   if (sh.nt < 4) sh.nt = 4; // smallest instantiated block
+   sh.a = (env && env[0] == 'A' && sh.nt == 8 && sh.zb * 8 == tiles);
+   sh.c = env ? (env[0] == 'C' || (env[0] == 'D' && two) || (env[0] == 'E' && !two)) : two; // default: K3 -> C, K2 -> B
+   if (sh.c) { // 4 x 1 waves, wave = 64 rows x NT (3 or 4) tiles, KC = 256: column blocks of at most 4 tiles
+      sh.zb = (tiles + 3) / 4;
+      sh.nt = (tiles + sh.zb - 1) / sh.zb;
+      if (sh.nt < 3) sh.nt = 3;
+      sh.rows = 256;
+      sh.cols = 32 * sh.nt;
+      sh.kc = 256;
+   } else if (sh.a) {
+      sh.rows = two ? 256 : 128;
+      sh.cols = two ? 128 : 256;
+      sh.kc = 256;
+      if (two) sh.zb *= 2;
+   } else {
+      sh.rows = 128;
+      sh.cols = 32 * sh.nt;
+      sh.kc = two ? 128 : 256;
+   }
+   return sh;
+}
+
+int gemm_i8_nsc_pad(int S, int b)
+{
+   const I8Shape s2 = i8_shape(S, b, false), s3 = i8_shape(S, b, true); // one padded width serves both kernels
+   return std::max(s2.zb * s2.cols, s3.zb * s3.cols);
+}
+
 // split-K factor: one workgroup per CU, so the grid should be close to a multiple of 256 workgroups; each extra split
 // costs one more int32 partial round trip (rows * 2 * nsc * 4 bytes written and read)
-int gemm_i8_splits(uint64_t rows_pad, uint64_t k_pad, int nsc, bool two)
+static int i8_splits(uint64_t rows_pad, uint64_t k_pad, const I8Shape &sh, int nsc)
 {
    static const char *env = getenv("FPCA_I8_SPLITS");
-   const uint64_t rows_wg = two ? I8Cfg<true>::ROWS : I8Cfg<false>::ROWS, cols_wg = two ? I8Cfg<true>::COLS : I8Cfg<false>::COLS;
-   const uint64_t tiles = rows_pad / rows_wg * ((uint64_t)nsc / cols_wg), chunks = k_pad / I8_KC;
+   const uint64_t tiles = rows_pad / sh.rows * (uint64_t)sh.zb, chunks = k_pad / sh.kc;
    if (env && atoi(env) > 0) return (int)std::min<uint64_t>((uint64_t)atoi(env), chunks);
-   const double t_chunk = 2.2e-6;                                      // one workgroup-chunk at ~3 POP/s
-   const double t_part = (double)rows_pad * 2 * nsc * 4 * 2 / 3.0e12;  // partial write + read per split
+   const double t_chunk = 2.2e-6 * (double)sh.rows * sh.cols * sh.kc / (128.0 * 256 * 256); // one workgroup-chunk at ~3 POP/s
+   const double t_part = (double)rows_pad * 2 * nsc * 4 * 2 / 3.0e12;                         // partial write + read per split
    double best = 1e30;
    int best_s = 1;
    for (uint64_t s = 1; s <= 16 && s * 4 <= std::max<uint64_t>(chunks, 4); s++) {
@@ -440,42 +512,77 @@ int gemm_i8_splits(uint64_t rows_pad, uint64_t k_pad, int nsc, bool two)
    return best_s;
 }
 
-int gemm_i8_nsc_pad(int S, int b) { return (S * b + 255) / 256 * 256; }
-
 size_t gemm_i8_workspace_ints(uint64_t rows_pad, uint64_t k_pad, int S, int b, bool two)
 {
+   const I8Shape sh = i8_shape(S, b, two);
    const int nsc = gemm_i8_nsc_pad(S, b);
-   return (size_t)gemm_i8_splits(rows_pad, k_pad, nsc, two) * rows_pad * 2 * (size_t)nsc;
+   return (size_t)i8_splits(rows_pad, k_pad, sh, nsc) * rows_pad * 2 * (size_t)nsc;
+}
+
+template <class C>
+static void launch_i8(dim3 grid, hipStream_t stream, const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, uint64_t k_pad,
+                      int nsc, int *ws, uint64_t rows_pad, int chunks_total, int cps)
+{
+   static bool attr_set = false;
+   if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::STAGE);
+      attr_set = true;
+   }
+   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<C>), grid, dim3(256), 2 * C::STAGE, stream, packed, pitch, Qg, Qm, k_pad, nsc, ws, rows_pad,
+                      chunks_total, cps);
 }
 
 void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, const double *wg, const double *wm,
-             const double *mean, const double *sd, double *out, int *ws, uint64_t rows_pad, uint64_t k_pad, int b, int S,
-             hipStream_t stream)
+             const long long *colsum_m, const double *mean, const double *sd, double *out, int *ws, uint64_t rows_pad, uint64_t k_pad,
+             int b, int S, hipStream_t stream)
 {
-   const int nsc = gemm_i8_nsc_pad(S, b); // Q holds nsc rows; rows >= S*b are zero
    const bool two = (Qg != Qm);
-   const int nsplit = gemm_i8_splits(rows_pad, k_pad, nsc, two);
-   const int chunks_total = (int)(k_pad / I8_KC);
-   int cps = (chunks_total + nsplit - 1) / nsplit;
+   const I8Shape sh = i8_shape(S, b, two);
+   const int nsc = gemm_i8_nsc_pad(S, b); // Q holds nsc rows; rows >= S*b are zero
+   const int nsplit = i8_splits(rows_pad, k_pad, sh, nsc);
+   const int chunks_total = (int)(k_pad / sh.kc);
+   const int cps = (chunks_total + nsplit - 1) / nsplit;
    const int nsplit_eff = (chunks_total + cps - 1) / cps; // no empty split
-   static bool attr_set = false;
-   if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * I8Cfg<false>::STAGE);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * I8Cfg<true>::STAGE);
-      attr_set = true;
-   }
-   if (two) {
-      dim3 grid((unsigned)(rows_pad / I8Cfg<true>::ROWS), (unsigned)nsplit_eff, (unsigned)(nsc / I8Cfg<true>::COLS));
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<true>), grid, dim3(256), 2 * I8Cfg<true>::STAGE, stream, packed, pitch, Qg, Qm, k_pad, nsc, ws,
-                         rows_pad, chunks_total, cps);
+   dim3 grid((unsigned)(rows_pad / sh.rows), (unsigned)nsplit_eff, (unsigned)sh.zb);
+#define FPCA_I8_ARGS grid, stream, packed, pitch, Qg, Qm, k_pad, nsc, ws, rows_pad, chunks_total, cps
+   if (sh.c) {
+      if (two) {
+         if (sh.nt == 3)
+            launch_i8<I8Cfg<true, 2, 3, 4, 1, 256, 1>>(FPCA_I8_ARGS);
+         else
+            launch_i8<I8Cfg<true, 2, 4, 4, 1, 256, 1>>(FPCA_I8_ARGS);
+      } else {
+         if (sh.nt == 3)
+            launch_i8<I8Cfg<false, 2, 3, 4, 1, 256, 1>>(FPCA_I8_ARGS);
+         else
+            launch_i8<I8Cfg<false, 2, 4, 4, 1, 256, 1>>(FPCA_I8_ARGS);
+      }
+   } else if (sh.a) {
+      if (two)
+         launch_i8<I8Cfg<true, 4, 2, 2, 2, 256, 1>>(FPCA_I8_ARGS);
+      else
+         launch_i8<I8Cfg<false, 2, 4, 2, 2, 256, 1>>(FPCA_I8_ARGS);
+   } else if (two) {
+      switch (sh.nt) {
+      case 4: launch_i8<I8Cfg<true, 1, 4, 4, 1, 128, 2>>(FPCA_I8_ARGS); break;
+      case 5: launch_i8<I8Cfg<true, 1, 5, 4, 1, 128, 2>>(FPCA_I8_ARGS); break;
+      case 6: launch_i8<I8Cfg<true, 1, 6, 4, 1, 128, 2>>(FPCA_I8_ARGS); break;
+      case 7: launch_i8<I8Cfg<true, 1, 7, 4, 1, 128, 2>>(FPCA_I8_ARGS); break;
+      default: launch_i8<I8Cfg<true, 1, 8, 4, 1, 128, 2>>(FPCA_I8_ARGS); break;
+      }
    } else {
-      dim3 grid((unsigned)(rows_pad / I8Cfg<false>::ROWS), (unsigned)nsplit_eff, (unsigned)(nsc / I8Cfg<false>::COLS));
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<false>), grid, dim3(256), 2 * I8Cfg<false>::STAGE, stream, packed, pitch, Qg, Qm, k_pad, nsc, ws,
-                         rows_pad, chunks_total, cps);
+      switch (sh.nt) {
+      case 4: launch_i8<I8Cfg<false, 1, 4, 4, 1, 256, 2>>(FPCA_I8_ARGS); break;
+      case 5: launch_i8<I8Cfg<false, 1, 5, 4, 1, 256, 2>>(FPCA_I8_ARGS); break;
+      case 6: launch_i8<I8Cfg<false, 1, 6, 4, 1, 256, 2>>(FPCA_I8_ARGS); break;
+      case 7: launch_i8<I8Cfg<false, 1, 7, 4, 1, 256, 2>>(FPCA_I8_ARGS); break;
+      default: launch_i8<I8Cfg<false, 1, 8, 4, 1, 256, 2>>(FPCA_I8_ARGS); break;
+      }
    }
+#undef FPCA_I8_ARGS
    HIP_CHECK_LAUNCH();
    unsigned blocks = (unsigned)std::min<uint64_t>(8192, (rows_pad * b + 255) / 256);
-   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, nsplit_eff, rows_pad, b, S, nsc, wg, wm, mean, sd, out);
+   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, nsplit_eff, rows_pad, b, S, nsc, wg, wm, colsum_m, mean, sd, out);
    HIP_CHECK_LAUNCH();
 }
 
