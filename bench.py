@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (vendor datasheet); HBM3E 8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X FP32 matrix peak (MI355X_MICROARCH.md)
+I8_MFMA_PEAK_TOPS = 5033.0  # v_mfma_i32_32x32x32_i8 issue rate: 256 CUs x 4 SIMDs x 65536 op / 32 clk x 2.4 GHz (= 2x bf16 dense)
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
@@ -48,9 +49,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--accum", default="fp64", choices=["fp64", "fp32"], help="fp32 = v_mfma_f32 products, fp64 long accumulation")
+    ap.add_argument("--accum", default="fp64", choices=["fp64", "fp32", "i8"] + ["i8x%d" % s for s in range(4, 10)],
+                    help="fp32 = v_mfma_f32 products, fp64 long accumulation; i8[xS] = exact-integer int8 MFMA on S (default 8) "
+                         "7-bit slices of the fp64 operand")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pca", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra exact-int8-mode measurement of the same workload")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the bounded baseline sample")
     args = ap.parse_args()
 
@@ -171,6 +175,13 @@ def main():
                     ms_xt_b=prof["ms_xt"], ms_x_t=prof["ms_x"], ms_allreduce=prof["ms_allreduce"],
                     flops_per_launch=flops_launch,
                     packed_gbs=((N + 3) // 4) * P_rank / (ms_dom * 1e-3) / 1e9)
+    if args.accum.startswith("i8"):
+        S = int(args.accum[3:]) if len(args.accum) > 2 else 8
+        ops_launch = 2.0 * flops_launch * S  # two integer matrices (G.M and 1-M) x S slices of every operand column
+        roofline.update(achieved=ops_launch / (ms_dom * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s", slices=S,
+                        ops_per_launch=ops_launch, fp64_equivalent_tflops=flops_launch / (ms_dom * 1e-3) / 1e12,
+                        peak_measured_pure_mfma_stream=3576.0)  # profiles/r01_mfma_i8_microbench.txt (random operands; power-limited)
+        del roofline["flops_per_launch"]
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
     if args.accum == "fp64":
         roofline["peak_measured_pure_mfma_stream"] = 74.3  # profiles/r01_mfma_f64_microbench.txt (2 waves/SIMD)
@@ -187,7 +198,9 @@ def main():
 
     out = dict(metric="genotype cells/sec (N x P x iters) for k=20 PCA", value=value, unit="cells/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
-               scaling=w["scaling"], vs_baseline=None, dtype="f64" if args.accum == "fp64" else "f32 (fp64 long accumulation)",
+               scaling=w["scaling"], vs_baseline=None,
+               dtype={"fp64": "f64", "fp32": "f32 (fp64 long accumulation)"}.get(
+                   args.accum, "i8 slices of the f64 operand x integer genotypes, exact i32 accumulation, f64 recombination"),
                data="synthetic",
                config=dict(workload=args.workload + ": " + w["desc"], samples=N, snps_total=P_total, snps_per_gpu=P_rank,
                            k=k, blockvec=b, parallelism="snp-shard x%d + all-reduce(N x b) [%s]" % (world, transport),
@@ -209,6 +222,39 @@ def main():
                           seconds_apply=info["seconds_apply"], seconds_ortho=info["seconds_ortho"],
                           seconds_host=info["seconds_host"], eigenvalue_1=float(r["d"][0]), eigenvalue_k=float(r["d"][-1]),
                           max_rel_residual=info["max_residual"])
+
+    # ---- the same workload in the exact-integer mode (FPCA_ACCUM_I8(8): fp64-equivalent results, int8 matrix cores) --
+    if world == 1 and args.accum == "fp64" and not args.no_alt:
+        with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=min(2 * k, 64), device=local_rank, accum="i8") as c8:
+            Y8 = torch.zeros_like(Y)
+            for _ in range(max(2, args.warmup)):
+                c8.apply_xxt_dev(B.data_ptr(), b, Y8.data_ptr())
+            c8.synchronize()
+            c8.profile_begin(args.steps)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                c8.apply_xxt_dev(B.data_ptr(), b, Y8.data_ptr())
+            c8.synchronize()
+            el8 = time.perf_counter() - t1
+            p8 = c8.profile_end(b)
+            scale = float(torch.max(torch.abs(Y)).item())
+            diff = float(torch.max(torch.abs(Y8 - Y)).item())
+            ops = 2.0 * flops_launch * 8
+            ms8 = max(p8["ms_xt"], p8["ms_x"])
+            alt = dict(accum="i8 (8 slices of 7 bits, exact int32 accumulation)", value=cells / el8, unit="cells/s",
+                       ms_per_step=el8 / args.steps * 1e3, ms_xt_b=p8["ms_xt"], ms_x_t=p8["ms_x"],
+                       max_abs_diff_vs_fp64_over_max_abs=diff / scale,
+                       roofline=dict(bound="mfma", achieved=ops / (ms8 * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s",
+                                     frac=ops / (ms8 * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, peak_measured_pure_mfma_stream=3576.0))
+            if not args.no_pca:
+                t1 = time.perf_counter()
+                r8 = c8.pca(ndim=k, allow_unconverged=True)
+                c8.synchronize()
+                alt["pca_wall_s"] = time.perf_counter() - t1
+                alt["pca_block_applies"] = r8["info"]["block_applies"]
+                if "pca" in out:
+                    alt["pca_eigenvalue_max_rel_diff_vs_fp64"] = float(max(abs(a - c) / abs(c) for a, c in zip(r8["d"], r["d"])))
+            out["exact_int8_mode"] = alt
 
     # ---- CPU baseline: the oracle (restated reference path) on a bounded sample, rank 0, N=1 only -----------
     if world == 1 and not args.no_cpu_baseline:

@@ -94,6 +94,12 @@ def test_cli_end_to_end(tmp_path, built_lib):
     assert r.returncode == 0, r.stderr
     ev32 = np.loadtxt(tmp_path / "eigenvalues_fp32.txt")
     assert np.allclose(ev32, ev, rtol=1e-6)
+    # exact-integer int8 mode: fp64-equivalent results
+    r = run(["--bfile", DATA, "--ndim", "10", "--accum", "i8", "--suffix", "_i8.txt", "--notime"], cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert np.allclose(np.loadtxt(tmp_path / "eigenvalues_i8.txt"), ev, rtol=1e-6)
+    r = run(["--bfile", DATA, "--ndim", "10", "--accum", "i9", "--notime"], cwd=tmp_path)
+    assert r.returncode == 1 and "unknown accumulate mode" in r.stderr
     # ndim limit (flashpca.cpp:623-633)
     r = run(["--bfile", DATA, "--ndim", "500", "--notime"], cwd=tmp_path)
     assert r.returncode == 1 and "You asked for 500 dimensions, but only 478allowed" in r.stderr

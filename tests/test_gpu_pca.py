@@ -153,6 +153,21 @@ def test_fp32_mode_tolerance_study(golden_dir, fp):
             assert abs(abs(U5[:, c] @ r["vectors"][:, c]) - 1.0) < 1e-5
 
 
+@pytest.mark.parametrize("mode,tol", [("i8", 1e-9), ("i8x6", 1e-9), ("i8x4", 1e-6)])
+def test_i8_mode_pca_vs_golden(golden_dir, fp, mode, tol):
+    """FPCA_ACCUM_I8(S): S = 8 and 6 reproduce the fp64 eigenvalues to the golden's own accuracy; S = 4 (28-bit operand)
+    still meets north_star's 1e-6."""
+    for name, k in (("hapmap3_data", 10), ("data_chr1", 20)):
+        g = json.load(open(os.path.join(golden_dir, "golden_%s_binom2.json" % name)))
+        r = fp.flashpca(os.path.join(golden_dir, name), ndim=k, accum=mode)
+        ev = np.array(g["eigenvalues_div_p"])[:k]
+        assert r["info"]["converged"] == 1
+        assert np.max(np.abs(r["values"] - ev) / ev) < tol
+        U5 = np.array(g["U_first5"]).T
+        for c in range(5):
+            assert abs(abs(U5[:, c] @ r["vectors"][:, c]) - 1.0) < 1e-5
+
+
 def test_config3_full_size_properties(fp):
     """BASELINE config 3 (500,000 x 100,000, k=20) at full size, where no CPU oracle run is possible: size-independent
     properties of the operator (symmetry, linearity, shard additivity) and the reference's own --check quantity
@@ -178,3 +193,9 @@ def test_config3_full_size_properties(fp):
     with fp.Context.synthetic(N, P, accum="fp32") as c32:
         r32 = c32.pca(ndim=k)
         assert np.max(np.abs(r32["d"] - d64) / d64) < 1e-7
+    with fp.Context.synthetic(N, P, accum="i8") as c8:
+        z = c8.apply_xxt(u[:, :1])
+        assert np.max(np.abs(z[:, 0] - Au[:, 0])) <= 1e-12 * np.max(np.abs(Au[:, 0]))  # exact-integer path == fp64 path
+        r8 = c8.pca(ndim=k)
+        assert r8["info"]["converged"] == 1
+        assert np.max(np.abs(r8["d"] - d64) / d64) < 1e-10
