@@ -8,18 +8,23 @@ import json
 import sys
 
 root = sys.argv[1]
+tag = sys.argv[2] if len(sys.argv) > 2 else ""  # e.g. "_i8": passes of `bench.py --accum i8`
 out = {}
 for wl in ("cfg2", "cfg3"):
     res = collections.defaultdict(dict)
     for kind in ("fetch", "write", "sq"):
-        fs = glob.glob("%s/pmc_%s_%s/*counter_collection.csv" % (root, kind, wl))
+        fs = glob.glob("%s/pmc_%s_%s%s/*counter_collection.csv" % (root, kind, wl, tag))
         if not fs:
             continue
         agg = collections.defaultdict(list)
         dur = collections.defaultdict(list)
         for r in csv.DictReader(open(fs[0])):
             name = r["Kernel_Name"]
-            key = "xt_b" if "k_xt_b" in name else "x_t" if "k_x_t" in name else "bed_stats" if "k_bed_stats" in name else "reduce_sum" if "k_reduce_sum" in name else None
+            key = ("xt_b" if "k_xt_b" in name else "x_t" if "k_x_t" in name else "bed_stats" if "k_bed_stats" in name
+                   else "reduce_sum" if "k_reduce_sum" in name
+                   else "gemm_i8_xt_b" if "k_gemm_i8" in name and "I8Cfg<false" in name
+                   else "gemm_i8_x_t" if "k_gemm_i8" in name and "I8Cfg<true" in name
+                   else "i8_combine" if "k_i8_combine" in name else "i8_slice" if "k_slice" in name else None)
             if key is None:
                 continue
             agg[(key, r["Counter_Name"])].append(float(r["Counter_Value"]))
