@@ -108,7 +108,7 @@ struct fpca_ctx {
    double *d_inv_sd = nullptr, *d_mu_inv_sd = nullptr, *d_i8w = nullptr;
    int8_t *d_Qb = nullptr, *d_Qg = nullptr, *d_Qm = nullptr;
    int i8_nsc = 0; // rows currently allocated (and zero-padded) in the Q buffers
-   int *d_i8ws = nullptr;
+   double *d_i8ws = nullptr;
    size_t i8ws_cap = 0;
    bool i8_scales_done = false, i8_transposed = false;
    // communication
@@ -133,11 +133,10 @@ struct fpca_ctx {
    bool multi() const { return comm != nullptr || ar_fn != nullptr; }
    void allreduce(double *dbuf, uint64_t count, hipStream_t s)
    {
-      if (comm)
-         RCCL_CHECK(rccl().AllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, comm, s));
-      else if (ar_fn) {
+      if (ar_fn) { // a caller-supplied hook wins over the built-in communicator (set after a failed / partial RCCL init)
          if (ar_fn(ar_user, dbuf, count, (void *)s) != 0) throw Error(FPCA_ECOMM, "caller-supplied all-reduce failed");
-      }
+      } else if (comm)
+         RCCL_CHECK(rccl().AllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, comm, s));
    }
 };
 
@@ -248,6 +247,9 @@ constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_CS = 1920 /* int64 colum
 void ensure_i8(fpca_ctx *c, int b)
 {
    hipStream_t s = c->stream;
+   // exact int32 accumulation: |sum| <= 2 * 64 * K must stay below 2^31
+   if (std::max(c->N_pad, c->P_pad) > (uint64_t)16000000)
+      throw Error(FPCA_EINVAL, "the int8-sliced mode supports up to 16,000,000 samples and SNPs per GPU (int32 accumulation)");
    if (!c->i8_transposed) {
       c->pitchT = (size_t)c->P_pad / 4;
       HIP_CHECK(hipMalloc(&c->d_packedT, c->pitchT * c->N_pad));
@@ -280,13 +282,13 @@ void ensure_i8(fpca_ctx *c, int b)
       HIP_CHECK(hipMemsetAsync(c->d_Qg + used * c->P_pad, 0, (nsc - used) * c->P_pad, s));
       HIP_CHECK(hipMemsetAsync(c->d_Qm + used * c->P_pad, 0, (nsc - used) * c->P_pad, s));
    }
-   const size_t need = std::max(kern::gemm_i8_workspace_ints(c->P_pad, c->N_pad, c->i8_S, b, false),
-                                kern::gemm_i8_workspace_ints(c->N_pad, c->P_pad, c->i8_S, b, true));
+   const size_t need = std::max(kern::gemm_i8_workspace_doubles(c->P_pad, c->N_pad, c->i8_S, b, false),
+                                kern::gemm_i8_workspace_doubles(c->N_pad, c->P_pad, c->i8_S, b, true));
    if (need > c->i8ws_cap) {
       if (c->d_i8ws) HIP_CHECK(hipFree(c->d_i8ws));
       c->d_i8ws = nullptr;
       c->i8ws_cap = 0;
-      HIP_CHECK(hipMalloc(&c->d_i8ws, need * sizeof(int)));
+      HIP_CHECK(hipMalloc(&c->d_i8ws, need * sizeof(double)));
       c->i8ws_cap = need;
    }
 }

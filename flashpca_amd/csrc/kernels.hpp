@@ -82,10 +82,10 @@ void census(uint32_t *d_out, int nwg, size_t lds_bytes, long long spin, hipStrea
 void slice_operand(const double *V, const double *rowscale, uint64_t rows_pad, uint64_t rows, int b, int S, int8_t *Q,
                    double *colw, long long *colsum, double *scratch, hipStream_t stream);
 int gemm_i8_nsc_pad(int S, int b); // rows of a Q operand: S*b rounded up to the 256-column workgroup tile
-size_t gemm_i8_workspace_ints(uint64_t rows_pad, uint64_t k_pad, int S, int b, bool two);
+size_t gemm_i8_workspace_doubles(uint64_t rows_pad, uint64_t k_pad, int S, int b, bool two);
 // out[rows_pad][b] = recombined ( (G.M) Qg' , M Qm' ); mean/sd non-null: K2 flavour (per-row standardisation)
 void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, const double *wg, const double *wm,
-             const long long *colsum_m, const double *mean, const double *sd, double *out, int *ws, uint64_t rows_pad, uint64_t k_pad,
+             const long long *colsum_m, const double *mean, const double *sd, double *out, double *ws, uint64_t rows_pad, uint64_t k_pad,
              int b, int S, hipStream_t stream);
 void i8_rowscales(const double *mean, const double *sd, uint64_t P_g, uint64_t P_pad, double *inv_sd, double *mu_inv_sd,
                   hipStream_t stream);

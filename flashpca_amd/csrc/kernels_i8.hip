@@ -69,10 +69,11 @@ __global__ __launch_bounds__(256) void k_colmax(const double *__restrict__ V, co
 }
 
 // weights: colw[s*b + c] = 2^e_c / 64 / 128^s with 2^e_c > max|column c|  (e_c from frexp; zero column -> e = 0)
-__global__ void k_slice_weights(const unsigned long long *__restrict__ colmax_bits, int b, int S, double *__restrict__ colw,
+__global__ void k_slice_weights(const unsigned long long *__restrict__ colmax_bits, int b, int S, int nsc_pad, double *__restrict__ colw,
                                 double *__restrict__ colinv)
 {
    const int c = threadIdx.x;
+   for (int t = S * b + c; t < nsc_pad; t += 64) colw[t] = 0.0; // padding slice-columns (their Q rows are zero too)
    if (c >= b) return;
    const double m = __longlong_as_double((long long)colmax_bits[c]);
    int e = 0;
@@ -134,6 +135,8 @@ __global__ __launch_bounds__(256) void k_slice(const double *__restrict__ V, con
    }
 }
 
+int gemm_i8_nsc_pad(int S, int b);
+
 void slice_operand(const double *V, const double *rowscale, uint64_t rows_pad, uint64_t rows, int b, int S, int8_t *Q,
                    double *colw /* [S*b] */, long long *colsum /* [S*b] or null */, double *scratch /* >= 2*b doubles */,
                    hipStream_t stream)
@@ -146,7 +149,7 @@ void slice_operand(const double *V, const double *rowscale, uint64_t rows_pad, u
    unsigned blocks = (unsigned)std::min<uint64_t>(1024, rows * b / 256 + 1);
    hipLaunchKernelGGL(k_colmax, dim3(blocks), dim3(256), 0, stream, V, rowscale, rows, b, bits);
    HIP_CHECK_LAUNCH();
-   hipLaunchKernelGGL(k_slice_weights, dim3(1), dim3(64), 0, stream, bits, b, S, colw, colinv);
+   hipLaunchKernelGGL(k_slice_weights, dim3(1), dim3(64), 0, stream, bits, b, S, gemm_i8_nsc_pad(S, b), colw, colinv);
    HIP_CHECK_LAUNCH();
    blocks = (unsigned)std::min<uint64_t>(16384, (rows_pad / 16 + (256 / b) - 1) / (256 / b));
    hipLaunchKernelGGL(k_slice, dim3(blocks), dim3(256), 0, stream, V, rowscale, rows_pad, rows, b, S, colinv, Q, colsum);
@@ -171,7 +174,7 @@ void slice_operand(const double *V, const double *rowscale, uint64_t rows_pad, u
 //   loads and hand-counted s_waitcnt: the operand fragments of the next micro-step are read from LDS and its genotype
 //   fragments decoded under this one's MFMAs, and the next chunk's global loads (first half of the chunk) and LDS
 //   stores (second half) ride in the MFMA shadow instead of a burst at the chunk boundary.
-//   Output: int32 partials part[split][row][mat][NSC], combined exactly by k_i8_combine.
+//   Output: fp64 partials part[split * zblocks][row][mat][bw] (slices already recombined), summed by k_i8_combine.
 template <int OFF>
 __device__ __forceinline__ v4i lds_read16(uint32_t addr) // explicit LDS read: the caller places the s_waitcnt
 {
@@ -242,8 +245,9 @@ __device__ __forceinline__ void i8_decode(uint32_t w, v4i &ag, v4i &am)
 template <class C>
 __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ packed, size_t pitch,
                                                      const int8_t *__restrict__ Qg, const int8_t *__restrict__ Qm,
-                                                     uint64_t k_pad, int nsc_total, int *__restrict__ part, uint64_t rows_pad,
-                                                     int chunks_total, int chunks_per_split)
+                                                     uint64_t k_pad, const double *__restrict__ wg, const double *__restrict__ wm, int bw,
+                                                     double *__restrict__ part, uint64_t rows_pad, int chunks_total,
+                                                     int chunks_per_split)
 {
    constexpr bool TWO = C::TWO;
    constexpr int MT = C::MT, NT = C::NT, NQ = C::NQ, KC = C::KC, NP = C::NP, NP1 = C::NP1, NSTEP = C::NSTEP, LDQ = C::LDQ,
@@ -396,44 +400,74 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
       __syncthreads();
    }
 
-   int *out = part + ((size_t)blockIdx.y * rows_pad + row0 + wr * 32 * MT) * 2 * nsc_total + col0 + wc * 32 * NT + li;
+   // epilogue: the slices are recombined here, per split and column block, into fp64 partial sums -- virtual column
+   // j = sc mod bw (bw = lcm(32, b): slice-column sc = s*b + c lands on j == c mod b), so a row of partials is
+   // 2 x bw doubles instead of 2 x S*b int32.  Every product w * acc is exact (w is a power of two, |acc| < 2^31); only
+   // the additions round, last slice (smallest terms) first.
+   const int tile0 = (col0 + wc * 32 * NT) / 32;
+   double *out = part + (((size_t)(blockIdx.y * gridDim.z + blockIdx.z) * rows_pad + row0 + wr * 32 * MT) * 2) * bw + li;
+   auto epilogue = [&](auto kbc) {
+      constexpr int KB = decltype(kbc)::value; // bw / 32: a lane's tiles n, n + KB, ... feed the same virtual column
+      double wgl[NT], wml[NT];
 #pragma unroll
-   for (int a = 0; a < 2; a++)
+      for (int n = 0; n < NT; n++) {
+         wgl[n] = wg[(tile0 + n) * 32 + li];
+         wml[n] = wm[(tile0 + n) * 32 + li];
+      }
+      int joff[KB];
+#pragma unroll
+      for (int k = 0; k < KB; k++) joff[k] = 32 * ((tile0 + k) % KB);
 #pragma unroll
       for (int m = 0; m < MT; m++)
 #pragma unroll
-         for (int n = 0; n < NT; n++)
+         for (int r = 0; r < 16; r++) {
+            const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            double bg[KB], bm[KB];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-               const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * kh;
-               out[((size_t)row * 2 + a) * nsc_total + 32 * n] = acc[a][m][n][r];
+            for (int k = 0; k < KB; k++) bg[k] = bm[k] = 0.0;
+#pragma unroll
+            for (int n = NT - 1; n >= 0; n--) {
+               bg[n % KB] += wgl[n] * (double)acc[0][m][n][r];
+               bm[n % KB] += wml[n] * (double)acc[1][m][n][r];
             }
+#pragma unroll
+            for (int k = 0; k < KB; k++) {
+               out[((size_t)row * 2 + 0) * bw + joff[k]] = bg[k];
+               out[((size_t)row * 2 + 1) * bw + joff[k]] = bm[k];
+            }
+         }
+   };
+   if (bw == 32)
+      epilogue(std::integral_constant<int, 1>{});
+   else if (bw == 64)
+      epilogue(std::integral_constant<int, 2>{});
+   else
+      epilogue(std::integral_constant<int, 3>{});
 }
 
-// exact combine of the int32 split-K partials and recombination of the slices:
-//   K2 (mean != null): out[row][c] = ( sum_s w[s,c] (G[row][s,c] - mean[row] M[row][s,c]) ) / sd[row]   (0 if sd <= 1e-9)
-//   K3               : out[row][c] = sum_s ( wg[s,c] G[row][s,c] - wm[s,c] M[row][s,c] )
-__global__ __launch_bounds__(256) void k_i8_combine(const int *__restrict__ part, int nsplit, uint64_t rows_pad, int b, int S,
-                                                     int NSC /* row stride of the partials: S*b rounded up to 256 */,
-                                                     const double *__restrict__ wg, const double *__restrict__ wm,
-                                                     const long long *__restrict__ colsum_m /* 1'Qm per slice-column */,
+// sum of the per-split / per-column-block fp64 partials, fold of the virtual columns (j == c mod b), M'Q = 1'Q - E'Q,
+// and the per-row standardisation:
+//   K2 (mean != null): out[row][c] = ( G[row][c] - mean[row] M[row][c] ) / sd[row]   (0 if sd <= 1e-9)
+//   K3               : out[row][c] =   G[row][c] - M[row][c]
+__global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ part, int nplanes, uint64_t rows_pad, int b, int bw, int S,
+                                                     const double *__restrict__ wm, const long long *__restrict__ colsum_m /* 1'Qm */,
                                                      const double *__restrict__ mean, const double *__restrict__ sd,
                                                      double *__restrict__ out)
 {
    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < rows_pad * b; t += (uint64_t)gridDim.x * 256) {
       const uint64_t row = t / b;
       const int c = (int)(t % b);
-      double accg = 0.0, accm = 0.0;
-      for (int s = S - 1; s >= 0; s--) { // small terms first
-         long long g = 0, m = 0;
-         for (int k = 0; k < nsplit; k++) {
-            const int *p = part + (((size_t)k * rows_pad + row) * 2) * NSC + s * b + c;
-            g += p[0];
-            m += p[NSC];
+      double accg = 0.0, acce = 0.0;
+      for (int p = 0; p < nplanes; p++) {
+         const double *q = part + (((size_t)p * rows_pad + row) * 2) * bw;
+         for (int j = c; j < bw; j += b) {
+            accg += q[j];
+            acce += q[bw + j];
          }
-         accg += wg[s * b + c] * (double)g;
-         accm += wm[s * b + c] * (double)(colsum_m[s * b + c] - m); // M'Q = 1'Q - E'Q
       }
+      double ones = 0.0; // 1'Qm recombined: sum_s w[s,c] colsum[s,c], small terms first
+      for (int s = S - 1; s >= 0; s--) ones += wm[s * b + c] * (double)colsum_m[s * b + c];
+      const double accm = ones - acce;
       double v;
       if (mean) {
          const double sdv = sd[row];
@@ -490,14 +524,14 @@ int gemm_i8_nsc_pad(int S, int b)
 }
 
 // split-K factor: one workgroup per CU, so the grid should be close to a multiple of 256 workgroups; each extra split
-// costs one more int32 partial round trip (rows * 2 * nsc * 4 bytes written and read)
-static int i8_splits(uint64_t rows_pad, uint64_t k_pad, const I8Shape &sh, int nsc)
+// costs one more fp64 partial round trip (rows * 2 * bw * 8 bytes per column block, written and read)
+static int i8_splits(uint64_t rows_pad, uint64_t k_pad, const I8Shape &sh, int bw)
 {
    static const char *env = getenv("FPCA_I8_SPLITS");
    const uint64_t tiles = rows_pad / sh.rows * (uint64_t)sh.zb, chunks = k_pad / sh.kc;
    if (env && atoi(env) > 0) return (int)std::min<uint64_t>((uint64_t)atoi(env), chunks);
    const double t_chunk = 2.2e-6 * (double)sh.rows * sh.cols * sh.kc / (128.0 * 256 * 256); // one workgroup-chunk at ~3 POP/s
-   const double t_part = (double)rows_pad * 2 * nsc * 4 * 2 / 3.0e12;                         // partial write + read per split
+   const double t_part = (double)rows_pad * 2 * bw * 8 * 2 * sh.zb / 3.0e12;                  // partial write + read per split
    double best = 1e30;
    int best_s = 1;
    for (uint64_t s = 1; s <= 16 && s * 4 <= std::max<uint64_t>(chunks, 4); s++) {
@@ -512,39 +546,43 @@ static int i8_splits(uint64_t rows_pad, uint64_t k_pad, const I8Shape &sh, int n
    return best_s;
 }
 
-size_t gemm_i8_workspace_ints(uint64_t rows_pad, uint64_t k_pad, int S, int b, bool two)
+static int i8_bw(int b) // lcm(32, b) for b in {16, 32, 48, 64}
+{
+   return b == 48 ? 96 : std::max(b, 32);
+}
+
+size_t gemm_i8_workspace_doubles(uint64_t rows_pad, uint64_t k_pad, int S, int b, bool two)
 {
    const I8Shape sh = i8_shape(S, b, two);
-   const int nsc = gemm_i8_nsc_pad(S, b);
-   return (size_t)i8_splits(rows_pad, k_pad, sh, nsc) * rows_pad * 2 * (size_t)nsc;
+   return (size_t)i8_splits(rows_pad, k_pad, sh, i8_bw(b)) * sh.zb * rows_pad * 2 * (size_t)i8_bw(b);
 }
 
 template <class C>
 static void launch_i8(dim3 grid, hipStream_t stream, const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, uint64_t k_pad,
-                      int nsc, int *ws, uint64_t rows_pad, int chunks_total, int cps)
+                      const double *wg, const double *wm, int bw, double *ws, uint64_t rows_pad, int chunks_total, int cps)
 {
    static bool attr_set = false;
    if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::STAGE);
       attr_set = true;
    }
-   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<C>), grid, dim3(256), 2 * C::STAGE, stream, packed, pitch, Qg, Qm, k_pad, nsc, ws, rows_pad,
-                      chunks_total, cps);
+   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<C>), grid, dim3(256), 2 * C::STAGE, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws,
+                      rows_pad, chunks_total, cps);
 }
 
 void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, const double *wg, const double *wm,
-             const long long *colsum_m, const double *mean, const double *sd, double *out, int *ws, uint64_t rows_pad, uint64_t k_pad,
+             const long long *colsum_m, const double *mean, const double *sd, double *out, double *ws, uint64_t rows_pad, uint64_t k_pad,
              int b, int S, hipStream_t stream)
 {
    const bool two = (Qg != Qm);
    const I8Shape sh = i8_shape(S, b, two);
-   const int nsc = gemm_i8_nsc_pad(S, b); // Q holds nsc rows; rows >= S*b are zero
-   const int nsplit = i8_splits(rows_pad, k_pad, sh, nsc);
+   const int bw = i8_bw(b); // Q holds gemm_i8_nsc_pad(S, b) rows; rows >= S*b are zero and carry zero weights
+   const int nsplit = i8_splits(rows_pad, k_pad, sh, bw);
    const int chunks_total = (int)(k_pad / sh.kc);
    const int cps = (chunks_total + nsplit - 1) / nsplit;
    const int nsplit_eff = (chunks_total + cps - 1) / cps; // no empty split
    dim3 grid((unsigned)(rows_pad / sh.rows), (unsigned)nsplit_eff, (unsigned)sh.zb);
-#define FPCA_I8_ARGS grid, stream, packed, pitch, Qg, Qm, k_pad, nsc, ws, rows_pad, chunks_total, cps
+#define FPCA_I8_ARGS grid, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws, rows_pad, chunks_total, cps
    if (sh.c) {
       if (two) {
          if (sh.nt == 3)
@@ -582,7 +620,7 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
 #undef FPCA_I8_ARGS
    HIP_CHECK_LAUNCH();
    unsigned blocks = (unsigned)std::min<uint64_t>(8192, (rows_pad * b + 255) / 256);
-   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, nsplit_eff, rows_pad, b, S, nsc, wg, wm, colsum_m, mean, sd, out);
+   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, nsplit_eff * sh.zb, rows_pad, b, bw, S, wm, colsum_m, mean, sd, out);
    HIP_CHECK_LAUNCH();
 }
 
