@@ -7,9 +7,9 @@
 // where G.M and M are tiny integers.  The fp64 operand (B, resp. T/sigma and mu T/sigma) is split per column into S
 // signed 7-bit slices sharing one power-of-two scale (q = d_0/64 + d_1/(64*128) + ..., |d_s| <= 64, remainder
 // < 2^-7S dropped), and the products run on v_mfma_i32_32x32x32_i8 with EXACT int32 accumulation (|sum| <= 128 N).
-// The only rounding of the whole product is the 2^-7S truncation of the fp64 operand and the final fp64
-// recombination -- there is no accumulation error at all -- so S = 8 (56 bits) is fp64-equivalent while the int8
-// MFMA runs ~64x faster than the fp64 one for 16x the multiply-adds.
+// The only rounding of the whole product is the 2^-7S truncation of the fp64 operand and the fp64 recombination of the
+// S exact slice sums (once per split-K part) -- nothing accumulates along K -- so S = 8 (56 bits) is fp64-equivalent
+// while the int8 MFMA issues 64x the multiply-adds per cycle of the fp64 one for 16x as many of them.
 //
 // MFMA operand maps (32x32x32 i8): lane l holds 16 int8 of A row i = l&31 and of B column j = l&31 for the K-half
 // l>>5; A and B use the same (half, byte) -> k assignment, so the dot products do not depend on it.  C/D register r of
@@ -479,41 +479,25 @@ __global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ p
 }
 
 // ---- shape selection ----
-// The slice-columns (S*b, rounded up to whole 32-column tiles) are cut into `zb` equal column blocks of NT tiles.
-//   shape 'B' (default): 4 x 1 waves, each 32 rows x all NT tiles (no redundant decode; KC = 256 for K2, 128 for K3)
-//   shape 'A'          : 2 x 2 waves, wave = 64 x 128 (K2) / 128 x 64 (K3), needs blocks of exactly 8 tiles
+// The slice-columns (S*b, rounded up to whole 32-column tiles) are cut into `zb` equal column blocks of NT tiles
+// (blockIdx.z); 4 x 1 waves per workgroup either way, KC = 256:
+//   K2: wave = 32 rows x NT <= 8 tiles (every packed row is decoded exactly once; any S without padding for b = 32)
+//   K3: wave = 64 rows x NT = 3..4 tiles of BOTH operands (two operand tiles per stage -> half the columns per block)
+// Measured alternatives at cfg3, S = 8 (K2 / K3 ms): 2 x 2 waves of 64 x 128 | 128 x 64: 19.2 / 22.4; K3 with 32-row waves,
+// all tiles and KC = 128: 24.3; K2 with the K3 shape: 18.9 -- versus 18.7 / 20.6 for the shapes kept.
 struct I8Shape {
    int nt, zb, rows, cols, kc;
-   bool a, c;
 };
 
 static I8Shape i8_shape(int S, int b, bool two)
 {
-   static const char *env = getenv("FPCA_I8_SHAPE");
-   const int tiles = (S * b + 31) / 32;
+   const int tiles = (S * b + 31) / 32, cap = two ? 4 : 8, lo = two ? 3 : 4; // largest / smallest instantiated block
    I8Shape sh;
-   sh.zb = (tiles + 7) / 8;
-   sh.nt = (tiles + sh.zb - 1) / sh.zb;
-   if (sh.nt < 4) sh.nt = 4; // smallest instantiated block
-   sh.a = (env && env[0] == 'A' && sh.nt == 8 && sh.zb * 8 == tiles);
-   sh.c = env ? (env[0] == 'C' || (env[0] == 'D' && two) || (env[0] == 'E' && !two)) : two; // default: K3 -> C, K2 -> B
-   if (sh.c) { // 4 x 1 waves, wave = 64 rows x NT (3 or 4) tiles, KC = 256: column blocks of at most 4 tiles
-      sh.zb = (tiles + 3) / 4;
-      sh.nt = (tiles + sh.zb - 1) / sh.zb;
-      if (sh.nt < 3) sh.nt = 3;
-      sh.rows = 256;
-      sh.cols = 32 * sh.nt;
-      sh.kc = 256;
-   } else if (sh.a) {
-      sh.rows = two ? 256 : 128;
-      sh.cols = two ? 128 : 256;
-      sh.kc = 256;
-      if (two) sh.zb *= 2;
-   } else {
-      sh.rows = 128;
-      sh.cols = 32 * sh.nt;
-      sh.kc = two ? 128 : 256;
-   }
+   sh.zb = (tiles + cap - 1) / cap;
+   sh.nt = std::max(lo, (tiles + sh.zb - 1) / sh.zb);
+   sh.rows = two ? 256 : 128;
+   sh.cols = 32 * sh.nt;
+   sh.kc = 256;
    return sh;
 }
 
@@ -583,31 +567,11 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
    const int nsplit_eff = (chunks_total + cps - 1) / cps; // no empty split
    dim3 grid((unsigned)(rows_pad / sh.rows), (unsigned)nsplit_eff, (unsigned)sh.zb);
 #define FPCA_I8_ARGS grid, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws, rows_pad, chunks_total, cps
-   if (sh.c) {
-      if (two) {
-         if (sh.nt == 3)
-            launch_i8<I8Cfg<true, 2, 3, 4, 1, 256, 1>>(FPCA_I8_ARGS);
-         else
-            launch_i8<I8Cfg<true, 2, 4, 4, 1, 256, 1>>(FPCA_I8_ARGS);
-      } else {
-         if (sh.nt == 3)
-            launch_i8<I8Cfg<false, 2, 3, 4, 1, 256, 1>>(FPCA_I8_ARGS);
-         else
-            launch_i8<I8Cfg<false, 2, 4, 4, 1, 256, 1>>(FPCA_I8_ARGS);
-      }
-   } else if (sh.a) {
-      if (two)
-         launch_i8<I8Cfg<true, 4, 2, 2, 2, 256, 1>>(FPCA_I8_ARGS);
+   if (two) {
+      if (sh.nt == 3)
+         launch_i8<I8Cfg<true, 2, 3, 4, 1, 256, 1>>(FPCA_I8_ARGS);
       else
-         launch_i8<I8Cfg<false, 2, 4, 2, 2, 256, 1>>(FPCA_I8_ARGS);
-   } else if (two) {
-      switch (sh.nt) {
-      case 4: launch_i8<I8Cfg<true, 1, 4, 4, 1, 128, 2>>(FPCA_I8_ARGS); break;
-      case 5: launch_i8<I8Cfg<true, 1, 5, 4, 1, 128, 2>>(FPCA_I8_ARGS); break;
-      case 6: launch_i8<I8Cfg<true, 1, 6, 4, 1, 128, 2>>(FPCA_I8_ARGS); break;
-      case 7: launch_i8<I8Cfg<true, 1, 7, 4, 1, 128, 2>>(FPCA_I8_ARGS); break;
-      default: launch_i8<I8Cfg<true, 1, 8, 4, 1, 128, 2>>(FPCA_I8_ARGS); break;
-      }
+         launch_i8<I8Cfg<true, 2, 4, 4, 1, 256, 1>>(FPCA_I8_ARGS);
    } else {
       switch (sh.nt) {
       case 4: launch_i8<I8Cfg<false, 1, 4, 4, 1, 256, 2>>(FPCA_I8_ARGS); break;
