@@ -240,9 +240,10 @@ void ensure_stats(fpca_ctx *c)
 }
 
 // ---- exact-integer mode --------------------------------------------------------------------------------
-// weights / scratch layout in d_i8w (8-byte words, S*b <= 9*64 = 576 each): wB, wg, wm, column sums, scratch
-constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_CS = 1920 /* int64 column sums of the M operand */, I8W_SCR = 2560,
-              I8W_TOTAL = 2560 + 128;
+// layout of d_i8w in 8-byte words: three weight vectors (S*b <= 9*64 = 576 entries each, padded), then the region that is
+// zeroed once per apply: column maxima (bit patterns) of the three operands and the column sums of the two M operands
+constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_ZERO = 1920, I8W_MAXB = 1920, I8W_MAXG = 1984, I8W_MAXM = 2048,
+              I8W_CSB = 2112, I8W_CSM = 2752, I8W_TOTAL = 3392;
 
 void ensure_i8(fpca_ctx *c, int b)
 {
@@ -293,23 +294,43 @@ void ensure_i8(fpca_ctx *c, int b)
    }
 }
 
-// T = X' B : slices of B against the SNP-major stream, per-SNP mean / sd applied in the exact combine
-void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s)
+kern::SliceOp i8_op_b(fpca_ctx *c)
 {
-   long long *cs = reinterpret_cast<long long *>(c->d_i8w + I8W_CS);
-   kern::slice_operand(dB, nullptr, c->N_pad, c->N, b, c->i8_S, c->d_Qb, c->d_i8w + I8W_B, cs, c->d_i8w + I8W_SCR, s);
-   kern::gemm_i8(c->d_packed, c->pitch, c->d_Qb, c->d_Qb, c->d_i8w + I8W_B, c->d_i8w + I8W_B, cs, c->d_mean, c->d_sd, c->d_T, c->d_i8ws,
-                 c->P_pad, c->N_pad, b, c->i8_S, s);
+   return kern::SliceOp{nullptr, reinterpret_cast<unsigned long long *>(c->d_i8w + I8W_MAXB), c->d_Qb, c->d_i8w + I8W_B,
+                        reinterpret_cast<long long *>(c->d_i8w + I8W_CSB)};
+}
+void i8_ops_t(fpca_ctx *c, kern::SliceOp *ops) // the two K3 operands: T/sd and mean T/sd
+{
+   ops[0] = kern::SliceOp{c->d_inv_sd, reinterpret_cast<unsigned long long *>(c->d_i8w + I8W_MAXG), c->d_Qg, c->d_i8w + I8W_G, nullptr};
+   ops[1] = kern::SliceOp{c->d_mu_inv_sd, reinterpret_cast<unsigned long long *>(c->d_i8w + I8W_MAXM), c->d_Qm, c->d_i8w + I8W_M,
+                          reinterpret_cast<long long *>(c->d_i8w + I8W_CSM)};
+}
+void i8_zero_meta(fpca_ctx *c, hipStream_t s)
+{
+   HIP_CHECK(hipMemsetAsync(c->d_i8w + I8W_ZERO, 0, (I8W_TOTAL - I8W_ZERO) * sizeof(double), s));
 }
 
-// Y = X T : slices of T/sd and mean T/sd against the sample-major copy
-void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s)
+// T = X' B : slices of B against the SNP-major stream, per-SNP mean / sd applied in the combine; with `chain` the
+// combine also leaves the column maxima of the two K3 operands (the meta region must have been zeroed by the caller)
+void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain)
 {
-   long long *cs = reinterpret_cast<long long *>(c->d_i8w + I8W_CS);
-   kern::slice_operand(c->d_T, c->d_inv_sd, c->P_pad, c->P_g, b, c->i8_S, c->d_Qg, c->d_i8w + I8W_G, nullptr, c->d_i8w + I8W_SCR, s);
-   kern::slice_operand(c->d_T, c->d_mu_inv_sd, c->P_pad, c->P_g, b, c->i8_S, c->d_Qm, c->d_i8w + I8W_M, cs, c->d_i8w + I8W_SCR, s);
-   kern::gemm_i8(c->d_packedT, c->pitchT, c->d_Qg, c->d_Qm, c->d_i8w + I8W_G, c->d_i8w + I8W_M, cs, nullptr, nullptr, dY, c->d_i8ws,
-                 c->N_pad, c->P_pad, b, c->i8_S, s);
+   kern::SliceOp ob = i8_op_b(c), ot[2];
+   i8_ops_t(c, ot);
+   kern::i8_colmax(dB, c->N, b, 1, &ob, s);
+   kern::i8_slice(dB, c->N_pad, c->N, b, c->i8_S, 1, &ob, s);
+   kern::gemm_i8(c->d_packed, c->pitch, c->d_Qb, c->d_Qb, ob.colw, ob.colw, ob.colsum, c->d_mean, c->d_sd, c->d_T, c->d_i8ws, c->P_pad,
+                 c->N_pad, b, c->i8_S, chain ? ot : nullptr, s);
+}
+
+// Y = X T : slices of T/sd and mean T/sd (one pass over T) against the sample-major copy
+void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max)
+{
+   kern::SliceOp ot[2];
+   i8_ops_t(c, ot);
+   if (!have_max) kern::i8_colmax(c->d_T, c->P_g, b, 2, ot, s);
+   kern::i8_slice(c->d_T, c->P_pad, c->P_g, b, c->i8_S, 2, ot, s);
+   kern::gemm_i8(c->d_packedT, c->pitchT, c->d_Qg, c->d_Qm, ot[0].colw, ot[1].colw, ot[1].colsum, nullptr, nullptr, dY, c->d_i8ws, c->N_pad,
+                 c->P_pad, b, c->i8_S, nullptr, s);
 }
 
 // the operator on device-resident blocks: dY = X_g X_g' dB (+ all-reduce).  ev (optional): 4 events recorded
@@ -321,9 +342,10 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
       ensure_i8(c, b);
       c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
       if (ev) HIP_CHECK(hipEventRecord(ev[0], s));
-      xt_i8(c, dB, b, s);
+      i8_zero_meta(c, s);
+      xt_i8(c, dB, b, s, true);
       if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
-      x_i8(c, b, dY, s);
+      x_i8(c, b, dY, s, true);
       if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
       if (c->multi()) c->allreduce(dY, (uint64_t)c->N_pad * b, s);
       if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
@@ -359,7 +381,8 @@ void xt_dev(fpca_ctx *c, const double *dB, int b, hipStream_t s)
    if (c->i8_S) {
       ensure_i8(c, b);
       c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
-      xt_i8(c, dB, b, s);
+      i8_zero_meta(c, s);
+      xt_i8(c, dB, b, s, false);
       return;
    }
    const int s2 = c->dense ? kern::xt_b_dense_splits(c->N_pad, c->P_pad) : kern::xt_b_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
@@ -377,7 +400,8 @@ void x_dev(fpca_ctx *c, int b, double *dY, hipStream_t s)
    ensure_stats(c);
    if (c->i8_S) {
       ensure_i8(c, b);
-      x_i8(c, b, dY, s);
+      i8_zero_meta(c, s);
+      x_i8(c, b, dY, s, false);
       return;
    }
    const int s3 = c->dense ? kern::x_t_dense_splits(c->N_pad, c->P_pad) : kern::x_t_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);

@@ -78,15 +78,23 @@ double mfma_peak_tflops(int waves_per_simd, int iters, int pattern, hipStream_t 
 void census(uint32_t *d_out, int nwg, size_t lds_bytes, long long spin, hipStream_t stream);
 
 // ---- exact-integer int8-sliced path (kernels_i8.hip) ----
-// V[rows_pad][b] fp64 (optionally times rowscale[row]) -> Q[S*b][rows_pad] int8 digits + per slice-column weights
-void slice_operand(const double *V, const double *rowscale, uint64_t rows_pad, uint64_t rows, int b, int S, int8_t *Q,
-                   double *colw, long long *colsum, double *scratch, hipStream_t stream);
+// one int8 operand cut from an fp64 matrix V[rows_pad][b]: Q[S*b][rows_pad] digits of V * rowscale[row], weights colw,
+// optional exact column sums; maxbits = per-column max |V * rowscale| as double bit patterns (input of i8_slice)
+struct SliceOp {
+   const double *rowscale;      // null: none
+   unsigned long long *maxbits; // [b]
+   int8_t *Q;
+   double *colw;       // [gemm_i8_nsc_pad(S, b)]
+   long long *colsum;  // [S*b] or null; accumulated with atomics: zero it first
+};
+void i8_colmax(const double *V, uint64_t rows, int b, int nops, const SliceOp *ops, hipStream_t stream); // maxbits must be zeroed
+void i8_slice(const double *V, uint64_t rows_pad, uint64_t rows, int b, int S, int nops, const SliceOp *ops, hipStream_t stream);
 int gemm_i8_nsc_pad(int S, int b); // rows of a Q operand: S*b rounded up to the 256-column workgroup tile
 size_t gemm_i8_workspace_doubles(uint64_t rows_pad, uint64_t k_pad, int S, int b, bool two);
 // out[rows_pad][b] = recombined ( (G.M) Qg' , M Qm' ); mean/sd non-null: K2 flavour (per-row standardisation)
 void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, const double *wg, const double *wm,
              const long long *colsum_m, const double *mean, const double *sd, double *out, double *ws, uint64_t rows_pad, uint64_t k_pad,
-             int b, int S, hipStream_t stream);
+             int b, int S, const SliceOp *next_ops, hipStream_t stream);
 void i8_rowscales(const double *mean, const double *sd, uint64_t P_g, uint64_t P_pad, double *inv_sd, double *mu_inv_sd,
                   hipStream_t stream);
 void transpose_packed(const uint8_t *in, size_t pitch_in, uint64_t N_pad, uint64_t P_pad, uint8_t *out, size_t pitch_out,

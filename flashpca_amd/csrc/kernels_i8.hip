@@ -45,91 +45,138 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 // Inside every aligned group of 16 rows the bytes are stored in the order the decoded genotype operand uses:
 // position 4q + t holds row q + 4t (see decode in k_gemm_i8).
 
-// per-column max |v * rowscale|; doubles >= 0 order like their bit patterns, so an integer atomicMax is exact
-__global__ __launch_bounds__(256) void k_colmax(const double *__restrict__ V, const double *__restrict__ rowscale,
-                                                uint64_t rows, int b, unsigned long long *__restrict__ colmax_bits)
+// One pass over V can serve two operands that differ only by a per-row factor (K3: T/sd and mean T/sd).
+//
+// Column maxima travel as the bit patterns of non-negative doubles (they order like integers, so an integer
+// atomicMax is exact); the caller zeroes them -- and the column sums -- once per apply.
+
+// block-level max over the 256/b row slots of each column, then one atomic per column
+__device__ __forceinline__ void colmax_commit(double m, int b, double *smax /* [256] */, unsigned long long *bits)
+{
+   __syncthreads();
+   smax[threadIdx.x] = m;
+   __syncthreads();
+   if ((int)threadIdx.x < b) {
+      for (int k = 1; k < 256 / b; k++) m = fmax(m, smax[k * b + threadIdx.x]);
+      atomicMax(&bits[threadIdx.x], (unsigned long long)__double_as_longlong(m));
+   }
+}
+
+// per-column max |v * rowscale| for one or two row scalings (standalone pass; the hot path gets K3's maxima from the
+// K2 combine instead)
+template <int NOPS>
+__global__ __launch_bounds__(256) void k_colmax(const double *__restrict__ V, uint64_t rows, int b, const double *__restrict__ rs0,
+                                                unsigned long long *__restrict__ bits0, const double *__restrict__ rs1,
+                                                unsigned long long *__restrict__ bits1)
 {
    __shared__ double smax[256];
    const int c = threadIdx.x % b;
    const int r_in = threadIdx.x / b, r_step = 256 / b;
-   double m = 0.0;
-   if (r_in < r_step)
-      for (uint64_t r = (uint64_t)blockIdx.x * r_step + r_in; r < rows; r += (uint64_t)gridDim.x * r_step) {
-         double v = V[r * b + c];
-         if (rowscale) v *= rowscale[r];
-         v = fabs(v);
-         if (v > m) m = v; // NaN never wins: a NaN operand would poison the fp64 path as well
+   double m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0}; // 4 independent chains: 4 loads in flight per thread
+   if (r_in < r_step) {
+      const uint64_t stride = (uint64_t)gridDim.x * r_step;
+      for (uint64_t r = (uint64_t)blockIdx.x * r_step + r_in; r < rows; r += 4 * stride) {
+#pragma unroll
+         for (int u = 0; u < 4; u++) {
+            const uint64_t rr = r + u * stride;
+            if (rr < rows) {
+               const double v = V[rr * b + c];
+               const double a = fabs(rs0 ? v * rs0[rr] : v);
+               if (a > m0[u]) m0[u] = a; // NaN never wins: a NaN operand would poison the fp64 path as well
+               if (NOPS == 2) {
+                  const double a1 = fabs(v * rs1[rr]);
+                  if (a1 > m1[u]) m1[u] = a1;
+               }
+            }
+         }
       }
-   smax[threadIdx.x] = m;
-   __syncthreads();
-   if (threadIdx.x < b) {
-      for (int k = 1; k < r_step; k++) m = fmax(m, smax[k * b + threadIdx.x]);
-      atomicMax(&colmax_bits[threadIdx.x], (unsigned long long)__double_as_longlong(m));
    }
+   colmax_commit(fmax(fmax(m0[0], m0[1]), fmax(m0[2], m0[3])), b, smax, bits0);
+   if (NOPS == 2) colmax_commit(fmax(fmax(m1[0], m1[1]), fmax(m1[2], m1[3])), b, smax, bits1);
 }
 
-// weights: colw[s*b + c] = 2^e_c / 64 / 128^s with 2^e_c > max|column c|  (e_c from frexp; zero column -> e = 0)
-__global__ void k_slice_weights(const unsigned long long *__restrict__ colmax_bits, int b, int S, int nsc_pad, double *__restrict__ colw,
-                                double *__restrict__ colinv)
+// scale of column c: 2^e > max|column| (e from frexp; zero column -> e = 0)
+__device__ __forceinline__ int slice_exponent(unsigned long long bits)
 {
-   const int c = threadIdx.x;
-   for (int t = S * b + c; t < nsc_pad; t += 64) colw[t] = 0.0; // padding slice-columns (their Q rows are zero too)
-   if (c >= b) return;
-   const double m = __longlong_as_double((long long)colmax_bits[c]);
+   const double m = __longlong_as_double((long long)bits);
    int e = 0;
    if (m > 0.0 && isfinite(m)) (void)frexp(m, &e); // m = f 2^e, f in [0.5, 1)  =>  m < 2^e
-   colinv[c] = ldexp(1.0, -e);
-   double w = ldexp(1.0, e - 6);
-   for (int s = 0; s < S; s++) {
-      colw[s * b + c] = w;
-      w *= 1.0 / 128.0;
-   }
+   return e;
 }
 
-// one thread = one 16-row group of one column: 16 strided fp64 in, one 16-byte store per slice out; optionally the
-// exact integer column sums of every slice (for  M'Q = 1'Q - E'Q, see k_gemm_i8) -- block-reduced, one atomic per
+// one thread = one 16-row group of one column: 16 strided fp64 in, one 16-byte store per slice and operand out; block 0
+// also writes the weights colw[s*b + c] = 2^e_c / 64 / 128^s (0 for the padding slice-columns); optionally the exact
+// integer column sums of every slice (for  M'Q = 1'Q - E'Q, see k_gemm_i8) -- block-reduced, one atomic per
 // slice-column per block
-__global__ __launch_bounds__(256) void k_slice(const double *__restrict__ V, const double *__restrict__ rowscale, uint64_t rows_pad,
-                                               uint64_t rows, int b, int S, const double *__restrict__ colinv,
-                                               int8_t *__restrict__ Q, long long *__restrict__ colsum)
+template <int NOPS>
+__global__ __launch_bounds__(256) void k_slice(const double *__restrict__ V, uint64_t rows_pad, uint64_t rows, int b, int S, int nsc_pad,
+                                               SliceOp o0, SliceOp o1)
 {
-   __shared__ int ssum[9][256];
+   __shared__ int ssum[NOPS][9][256];
    const uint64_t groups = rows_pad / 16;
    const int c = threadIdx.x % b, gl = threadIdx.x / b, gpb = 256 / b; // column, local group, groups per block
-   const double sc = colinv[c] * 64.0;
+   const SliceOp *ops[2] = {&o0, &o1};
+   double sc[NOPS];
+#pragma unroll
+   for (int o = 0; o < NOPS; o++) {
+      const int e = slice_exponent(ops[o]->maxbits[c]);
+      sc[o] = ldexp(1.0, 6 - e);
+      if (blockIdx.x == 0) {
+         if (gl == 0) {
+            double w = ldexp(1.0, e - 6);
+            for (int s = 0; s < S; s++) {
+               ops[o]->colw[s * b + c] = w;
+               w *= 1.0 / 128.0;
+            }
+         }
+         for (int t = S * b + threadIdx.x; t < nsc_pad; t += 256) ops[o]->colw[t] = 0.0;
+      }
+   }
    for (uint64_t g0 = (uint64_t)blockIdx.x * gpb; g0 < groups; g0 += (uint64_t)gridDim.x * gpb) {
       const uint64_t g = g0 + gl;
       const bool act = gl < gpb && g < groups;
       const uint64_t r0 = g * 16;
-      double q[16];
+      double v[16];
 #pragma unroll
       for (int j = 0; j < 16; j++) {
          const uint64_t r = r0 + j;
-         double v = (act && r < rows) ? V[r * b + c] : 0.0;
-         if (rowscale && act && r < rows) v *= rowscale[r];
-         q[j] = v * sc; // |q| < 64; exact (power-of-two scaling)
+         v[j] = (act && r < rows) ? V[r * b + c] : 0.0;
       }
-      for (int s = 0; s < S; s++) {
-         u4 word = {0u, 0u, 0u, 0u};
-         int tot = 0;
+#pragma unroll
+      for (int o = 0; o < NOPS; o++) {
+         double q[16];
 #pragma unroll
          for (int j = 0; j < 16; j++) {
-            const double d = rint(q[j]);
-            q[j] = (q[j] - d) * 128.0; // exact
-            tot += (int)d;
-            word[j & 3] |= ((uint32_t)(int)d & 0xFFu) << (8 * (j >> 2)); // position 4 (j&3) + (j>>2)
+            const uint64_t r = r0 + j;
+            double x = v[j];
+            if (ops[o]->rowscale && act && r < rows) x *= ops[o]->rowscale[r];
+            q[j] = x * sc[o]; // |q| < 64; exact (power-of-two scaling)
          }
-         if (act) *reinterpret_cast<u4 *>(Q + ((uint64_t)(s * b + c)) * rows_pad + r0) = word;
-         ssum[s][threadIdx.x] = tot;
+         for (int s = 0; s < S; s++) {
+            u4 word = {0u, 0u, 0u, 0u};
+            int tot = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+               const double d = rint(q[j]);
+               q[j] = (q[j] - d) * 128.0; // exact
+               tot += (int)d;
+               word[j & 3] |= ((uint32_t)(int)d & 0xFFu) << (8 * (j >> 2)); // position 4 (j&3) + (j>>2)
+            }
+            if (act) *reinterpret_cast<u4 *>(ops[o]->Q + ((uint64_t)(s * b + c)) * rows_pad + r0) = word;
+            ssum[o][s][threadIdx.x] = tot;
+         }
       }
-      if (colsum) {
+      if (o0.colsum || (NOPS == 2 && o1.colsum)) {
          __syncthreads();
-         for (int t = threadIdx.x; t < S * b; t += 256) {
-            const int s = t / b, cc = t % b;
-            long long a = 0;
-            for (int k = 0; k < gpb; k++) a += ssum[s][k * b + cc];
-            if (a) atomicAdd(reinterpret_cast<unsigned long long *>(&colsum[t]), (unsigned long long)a);
-         }
+#pragma unroll
+         for (int o = 0; o < NOPS; o++)
+            if (ops[o]->colsum)
+               for (int t = threadIdx.x; t < S * b; t += 256) {
+                  const int s = t / b, cc = t % b;
+                  long long a = 0;
+                  for (int k = 0; k < gpb; k++) a += ssum[o][s][k * b + cc];
+                  if (a) atomicAdd(reinterpret_cast<unsigned long long *>(&ops[o]->colsum[t]), (unsigned long long)a);
+               }
          __syncthreads();
       }
    }
@@ -137,22 +184,28 @@ __global__ __launch_bounds__(256) void k_slice(const double *__restrict__ V, con
 
 int gemm_i8_nsc_pad(int S, int b);
 
-void slice_operand(const double *V, const double *rowscale, uint64_t rows_pad, uint64_t rows, int b, int S, int8_t *Q,
-                   double *colw /* [S*b] */, long long *colsum /* [S*b] or null */, double *scratch /* >= 2*b doubles */,
-                   hipStream_t stream)
+void i8_colmax(const double *V, uint64_t rows, int b, int nops, const SliceOp *ops, hipStream_t stream)
 {
-   if (S > 9 || b > 64) throw Error(-1, "slice_operand: S <= 9 and b <= 64");
-   if (colsum) (void)hipMemsetAsync(colsum, 0, sizeof(long long) * S * b, stream);
-   unsigned long long *bits = reinterpret_cast<unsigned long long *>(scratch);
-   double *colinv = scratch + b;
-   (void)hipMemsetAsync(bits, 0, sizeof(unsigned long long) * b, stream);
-   unsigned blocks = (unsigned)std::min<uint64_t>(1024, rows * b / 256 + 1);
-   hipLaunchKernelGGL(k_colmax, dim3(blocks), dim3(256), 0, stream, V, rowscale, rows, b, bits);
+   // few blocks: every block ends with one atomic per column, and same-address atomics serialise in L2 (~20 ns each)
+   const unsigned blocks = (unsigned)std::min<uint64_t>(256, rows * b / 1024 + 1);
+   if (nops == 2)
+      hipLaunchKernelGGL(k_colmax<2>, dim3(blocks), dim3(256), 0, stream, V, rows, b, ops[0].rowscale, ops[0].maxbits, ops[1].rowscale,
+                         ops[1].maxbits);
+   else
+      hipLaunchKernelGGL(k_colmax<1>, dim3(blocks), dim3(256), 0, stream, V, rows, b, ops[0].rowscale, ops[0].maxbits, nullptr, nullptr);
    HIP_CHECK_LAUNCH();
-   hipLaunchKernelGGL(k_slice_weights, dim3(1), dim3(64), 0, stream, bits, b, S, gemm_i8_nsc_pad(S, b), colw, colinv);
-   HIP_CHECK_LAUNCH();
-   blocks = (unsigned)std::min<uint64_t>(16384, (rows_pad / 16 + (256 / b) - 1) / (256 / b));
-   hipLaunchKernelGGL(k_slice, dim3(blocks), dim3(256), 0, stream, V, rowscale, rows_pad, rows, b, S, colinv, Q, colsum);
+}
+
+void i8_slice(const double *V, uint64_t rows_pad, uint64_t rows, int b, int S, int nops, const SliceOp *ops, hipStream_t stream)
+{
+   if (S > 9 || b > 64 || nops < 1 || nops > 2) throw Error(-1, "i8_slice: S <= 9, b <= 64, 1 or 2 operands");
+   const unsigned blocks = (unsigned)std::min<uint64_t>(ops[0].colsum || (nops == 2 && ops[1].colsum) ? 512 : 4096,
+                                                        (rows_pad / 16 + (256 / b) - 1) / (256 / b));
+   const int nsc = gemm_i8_nsc_pad(S, b);
+   if (nops == 2)
+      hipLaunchKernelGGL(k_slice<2>, dim3(blocks), dim3(256), 0, stream, V, rows_pad, rows, b, S, nsc, ops[0], ops[1]);
+   else
+      hipLaunchKernelGGL(k_slice<1>, dim3(blocks), dim3(256), 0, stream, V, rows_pad, rows, b, S, nsc, ops[0], ops[0]);
    HIP_CHECK_LAUNCH();
 }
 
@@ -449,32 +502,47 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
 // and the per-row standardisation:
 //   K2 (mean != null): out[row][c] = ( G[row][c] - mean[row] M[row][c] ) / sd[row]   (0 if sd <= 1e-9)
 //   K3               : out[row][c] =   G[row][c] - M[row][c]
+// The K2 flavour can also leave the column maxima of out * rs0 and out * rs1 behind (the two K3 operands), which saves
+// the next stage a pass over T.
 __global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ part, int nplanes, uint64_t rows_pad, int b, int bw, int S,
                                                      const double *__restrict__ wm, const long long *__restrict__ colsum_m /* 1'Qm */,
                                                      const double *__restrict__ mean, const double *__restrict__ sd,
-                                                     double *__restrict__ out)
+                                                     double *__restrict__ out, const double *__restrict__ rs0,
+                                                     unsigned long long *__restrict__ bits0, const double *__restrict__ rs1,
+                                                     unsigned long long *__restrict__ bits1)
 {
-   for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < rows_pad * b; t += (uint64_t)gridDim.x * 256) {
-      const uint64_t row = t / b;
-      const int c = (int)(t % b);
-      double accg = 0.0, acce = 0.0;
-      for (int p = 0; p < nplanes; p++) {
-         const double *q = part + (((size_t)p * rows_pad + row) * 2) * bw;
-         for (int j = c; j < bw; j += b) {
-            accg += q[j];
-            acce += q[bw + j];
-         }
-      }
+   __shared__ double smax[256];
+   const int c = threadIdx.x % b, r_in = threadIdx.x / b, r_step = 256 / b;
+   double m0 = 0.0, m1 = 0.0;
+   if (r_in < r_step) {
       double ones = 0.0; // 1'Qm recombined: sum_s w[s,c] colsum[s,c], small terms first
       for (int s = S - 1; s >= 0; s--) ones += wm[s * b + c] * (double)colsum_m[s * b + c];
-      const double accm = ones - acce;
-      double v;
-      if (mean) {
-         const double sdv = sd[row];
-         v = (sdv > 1e-9) ? (accg - mean[row] * accm) / sdv : 0.0;
-      } else
-         v = accg - accm;
-      out[t] = v;
+      for (uint64_t row = (uint64_t)blockIdx.x * r_step + r_in; row < rows_pad; row += (uint64_t)gridDim.x * r_step) {
+         double accg = 0.0, acce = 0.0;
+         for (int p = 0; p < nplanes; p++) {
+            const double *q = part + (((size_t)p * rows_pad + row) * 2) * bw;
+            for (int j = c; j < bw; j += b) {
+               accg += q[j];
+               acce += q[bw + j];
+            }
+         }
+         const double accm = ones - acce;
+         double v;
+         if (mean) {
+            const double sdv = sd[row];
+            v = (sdv > 1e-9) ? (accg - mean[row] * accm) / sdv : 0.0;
+         } else
+            v = accg - accm;
+         out[row * b + c] = v;
+         if (bits0) {
+            m0 = fmax(m0, fabs(v * rs0[row]));
+            m1 = fmax(m1, fabs(v * rs1[row]));
+         }
+      }
+   }
+   if (bits0) {
+      colmax_commit(m0, b, smax, bits0);
+      colmax_commit(m1, b, smax, bits1);
    }
 }
 
@@ -508,6 +576,9 @@ int gemm_i8_nsc_pad(int S, int b)
 }
 
 // split-K factor: one workgroup per CU, so the grid should be close to a multiple of 256 workgroups; each extra split
+// (A stream-K schedule would remove the round quantisation, but it also breaks the lock-step in which the workgroups of a
+// round stream the same operand chunks through L2: rotating the chunk order per workgroup costs 4-8 %, measured, so it
+// would only pay where the last round is less than ~3/4 full.)
 // costs one more fp64 partial round trip (rows * 2 * bw * 8 bytes per column block, written and read)
 static int i8_splits(uint64_t rows_pad, uint64_t k_pad, const I8Shape &sh, int bw)
 {
@@ -556,7 +627,8 @@ static void launch_i8(dim3 grid, hipStream_t stream, const uint8_t *packed, size
 
 void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, const double *wg, const double *wm,
              const long long *colsum_m, const double *mean, const double *sd, double *out, double *ws, uint64_t rows_pad, uint64_t k_pad,
-             int b, int S, hipStream_t stream)
+             int b, int S, const SliceOp *next_ops /* null, or the two operands whose column maxima the combine should leave */,
+             hipStream_t stream)
 {
    const bool two = (Qg != Qm);
    const I8Shape sh = i8_shape(S, b, two);
@@ -583,8 +655,10 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
    }
 #undef FPCA_I8_ARGS
    HIP_CHECK_LAUNCH();
-   unsigned blocks = (unsigned)std::min<uint64_t>(8192, (rows_pad * b + 255) / 256);
-   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, nsplit_eff * sh.zb, rows_pad, b, bw, S, wm, colsum_m, mean, sd, out);
+   const unsigned blocks = (unsigned)std::min<uint64_t>(next_ops ? 512 : 4096, (rows_pad + (256 / b) - 1) / (256 / b));
+   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, nsplit_eff * sh.zb, rows_pad, b, bw, S, wm, colsum_m, mean, sd, out,
+                      next_ops ? next_ops[0].rowscale : nullptr, next_ops ? next_ops[0].maxbits : nullptr,
+                      next_ops ? next_ops[1].rowscale : nullptr, next_ops ? next_ops[1].maxbits : nullptr);
    HIP_CHECK_LAUNCH();
 }
 
