@@ -13,6 +13,11 @@ Workload (BASELINE.json configs[1]): synthetic 50,000 samples x 20,000 SNPs per 
 every rank holds its own 20,000-SNP shard of a (20,000 * N)-SNP matrix, generated directly in HBM.
 `--workload cfg3` selects the 500,000 x 100,000 paper-headline matrix (configs[2]/[3], SNP-sharded = strong).
 
+Arithmetic: `--accum i8` (default; the product's default FPCA_ACCUM_AUTO resolves to it) runs the two GEMMs on the int8 matrix
+cores -- integer genotype matrices x 7-bit slices of the fp64 operand, exact int32 accumulation, fp64 recombination
+-- with results equal to the fp64 MFMA kernels (`--accum fp64`) to ~3e-15; the line carries the other mode's timing and the
+measured difference between the two as `fp64_mode` / `exact_int8_mode`.
+
 The same JSON line also carries: the roofline of the dominant kernel (HIP events recorded live on the
 kernels' stream inside the timed region), a bounded CPU baseline (the oracle = restated reference path, one
 thread, like the shipped reference), and the wall-clock of one full k=20 PCA solve to convergence.
@@ -49,9 +54,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--accum", default="fp64", choices=["fp64", "fp32", "i8"] + ["i8x%d" % s for s in range(4, 10)],
-                    help="fp32 = v_mfma_f32 products, fp64 long accumulation; i8[xS] = exact-integer int8 MFMA on S (default 8) "
-                         "7-bit slices of the fp64 operand")
+    ap.add_argument("--accum", default="i8", choices=["fp64", "fp32", "i8"] + ["i8x%d" % s for s in range(4, 10)],
+                    help="i8[xS] (default: the product's default mode) = exact-integer int8 MFMA on S (default 8) 7-bit slices of the "
+                         "fp64 operand, results equal to the fp64 path; fp64 = v_mfma_f64; fp32 = v_mfma_f32 products, fp64 long "
+                         "accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pca", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra exact-int8-mode measurement of the same workload")
@@ -188,6 +194,11 @@ def main():
     # HBM traffic per launch of the dominant kernel from the committed PMC passes of this workload (bench.py cannot
     # collect hardware counters itself; scripts/gpu_profile_round.sh does, in separate --pmc runs, as the guide asks)
     try:
+        if world == 1 and args.accum == "i8":
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_i8.json")))[args.workload]["gemm_i8_" + dom]
+            roofline["traffic"] = pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/r01_pmc_summary_i8.json (FETCH_SIZE x2 + WRITE_SIZE of the int8 GEMM, rocprofv3 --pmc)"
+            roofline["algorithmic_bytes"] = float((N + 3) // 4) * P_rank + 8.0 * b * (N + P_rank)
         if world == 1 and args.accum == "fp64":
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))[args.workload][dom]
             roofline["traffic"] = pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]
@@ -200,7 +211,8 @@ def main():
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
                scaling=w["scaling"], vs_baseline=None,
                dtype={"fp64": "f64", "fp32": "f32 (fp64 long accumulation)"}.get(
-                   args.accum, "i8 slices of the f64 operand x integer genotypes, exact i32 accumulation, f64 recombination"),
+                   args.accum, "i8 (integer genotypes x 7-bit slices of the f64 operand; exact i32 accumulation, f64 recombination; "
+                               "agrees with the f64 kernels to ~3e-15, see fp64_mode)"),
                data="synthetic",
                config=dict(workload=args.workload + ": " + w["desc"], samples=N, snps_total=P_total, snps_per_gpu=P_rank,
                            k=k, blockvec=b, parallelism="snp-shard x%d + all-reduce(N x b) [%s]" % (world, transport),
@@ -223,38 +235,42 @@ def main():
                           seconds_host=info["seconds_host"], eigenvalue_1=float(r["d"][0]), eigenvalue_k=float(r["d"][-1]),
                           max_rel_residual=info["max_residual"])
 
-    # ---- the same workload in the exact-integer mode (FPCA_ACCUM_I8(8): fp64-equivalent results, int8 matrix cores) --
-    if world == 1 and args.accum == "fp64" and not args.no_alt:
-        with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=min(2 * k, 64), device=local_rank, accum="i8") as c8:
-            Y8 = torch.zeros_like(Y)
+    # ---- the same workload through the other exact path (fp64 MFMA kernels <-> int8 slices): timing and agreement ------
+    if world == 1 and args.accum in ("fp64", "i8") and not args.no_alt:
+        other = "fp64" if args.accum == "i8" else "i8"
+        with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=min(2 * k, 64), device=local_rank, accum=other) as c2:
+            Y2 = torch.zeros_like(Y)
             for _ in range(max(2, args.warmup)):
-                c8.apply_xxt_dev(B.data_ptr(), b, Y8.data_ptr())
-            c8.synchronize()
-            c8.profile_begin(args.steps)
+                c2.apply_xxt_dev(B.data_ptr(), b, Y2.data_ptr())
+            c2.synchronize()
+            c2.profile_begin(args.steps)
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                c8.apply_xxt_dev(B.data_ptr(), b, Y8.data_ptr())
-            c8.synchronize()
-            el8 = time.perf_counter() - t1
-            p8 = c8.profile_end(b)
+                c2.apply_xxt_dev(B.data_ptr(), b, Y2.data_ptr())
+            c2.synchronize()
+            el2 = time.perf_counter() - t1
+            p2 = c2.profile_end(b)
             scale = float(torch.max(torch.abs(Y)).item())
-            diff = float(torch.max(torch.abs(Y8 - Y)).item())
-            ops = 2.0 * flops_launch * 8
-            ms8 = max(p8["ms_xt"], p8["ms_x"])
-            alt = dict(accum="i8 (8 slices of 7 bits, exact int32 accumulation)", value=cells / el8, unit="cells/s",
-                       ms_per_step=el8 / args.steps * 1e3, ms_xt_b=p8["ms_xt"], ms_x_t=p8["ms_x"],
-                       max_abs_diff_vs_fp64_over_max_abs=diff / scale,
-                       roofline=dict(bound="mfma", achieved=ops / (ms8 * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s",
-                                     frac=ops / (ms8 * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, peak_measured_pure_mfma_stream=3576.0))
+            diff = float(torch.max(torch.abs(Y2 - Y)).item())
+            ms2 = max(p2["ms_xt"], p2["ms_x"])
+            if other == "i8":
+                ops = 2.0 * flops_launch * 8
+                rf = dict(bound="mfma", achieved=ops / (ms2 * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s",
+                          frac=ops / (ms2 * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, peak_measured_pure_mfma_stream=3576.0)
+            else:
+                rf = dict(bound="mfma", achieved=flops_launch / (ms2 * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                          frac=flops_launch / (ms2 * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, peak_measured_pure_mfma_stream=74.3)
+            alt = dict(accum=other, value=cells / el2, unit="cells/s", ms_per_step=el2 / args.steps * 1e3, ms_xt_b=p2["ms_xt"],
+                       ms_x_t=p2["ms_x"], max_abs_diff_between_modes_over_max_abs=diff / scale, roofline=rf)
             if not args.no_pca:
                 t1 = time.perf_counter()
-                r8 = c8.pca(ndim=k, allow_unconverged=True)
-                c8.synchronize()
+                r2 = c2.pca(ndim=k, allow_unconverged=True)
+                c2.synchronize()
                 alt["pca_wall_s"] = time.perf_counter() - t1
-                alt["pca_block_applies"] = r8["info"]["block_applies"]
+                alt["pca_block_applies"] = r2["info"]["block_applies"]
                 if "pca" in out:
-                    alt["pca_eigenvalue_max_rel_diff_vs_fp64"] = float(max(abs(a - c) / abs(c) for a, c in zip(r8["d"], r["d"])))
-            out["exact_int8_mode"] = alt
+                    alt["pca_eigenvalue_max_rel_diff_between_modes"] = float(max(abs(a - c) / abs(c) for a, c in zip(r2["d"], r["d"])))
+            out["fp64_mode" if other == "fp64" else "exact_int8_mode"] = alt
 
     # ---- CPU baseline: the oracle (restated reference path) on a bounded sample, rank 0, N=1 only -----------
     if world == 1 and not args.no_cpu_baseline:

@@ -76,6 +76,7 @@ SIGNATURES = {
     "fpca_destroy": (None, [_P]),
     "fpca_nsamples": (_U64, [_P]),
     "fpca_nsnps": (_U64, [_P]),
+    "fpca_accum": (_I, [_P]),
     "fpca_download_packed": (_I, [_P, _P]),
     "fpca_stats": (_I, [_P, _P, C.POINTER(_D)]),
     "fpca_set_meansd": (_I, [_P, _P]),

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import DIVISOR, STANDARDISE, BenchResult, FpcaError, PcaInfo, PcaOpts, check, lib  # noqa: F401
 
 
-ACCUM = {"fp64": 64, "fp32": 32, 64: 64, 32: 32, "i8": 808}
+ACCUM = {"auto": 0, 0: 0, "fp64": 64, "fp32": 32, 64: 64, 32: 32, "i8": 808}
 ACCUM.update({"i8x%d" % s: 800 + s for s in range(2, 10)})
 ACCUM.update({800 + s: 800 + s for s in range(2, 10)})
 
@@ -35,6 +35,12 @@ class Context:
         L = lib()
         self.N = int(L.fpca_nsamples(handle))
         self.P = int(L.fpca_nsnps(handle))
+
+    @property
+    def accum(self):
+        """The arithmetic mode in effect: 'fp64', 'fp32' or 'i8xS' ("auto" resolved)."""
+        code = int(lib().fpca_accum(self.h))
+        return {64: "fp64", 32: "fp32"}.get(code, "i8x%d" % (code - 800))
         self.P_total = self.P
         self._keep = []
 
@@ -209,7 +215,7 @@ class Context:
 
 
 def flashpca(X, ndim=10, stand="binom2", divisor="p", maxiter=500, tol=1e-6, do_loadings=False, return_scale=True,
-             device=0, verbose=False, accum="fp64", **solver_kw):
+             device=0, verbose=False, accum="auto", **solver_kw):
     """PCA of a PLINK fileset; mirrors flashpca() of the reference's R package for the PLINK-prefix input
     (flashpcaR/R/flashpca.R:99-204 -> flashpca_plink_internal, flashpcaR/src/flashpca.cpp:96-197).
 

@@ -103,6 +103,7 @@ struct fpca_ctx {
    double *d_small = nullptr;                   // small device scratch (scalars, column scales)
    // exact-integer mode (FPCA_ACCUM_I8(S)): sample-major packed copy, K3 row scales, sliced operands, int32 partials
    int i8_S = 0;
+   bool i8_auto = false; // mode chosen by FPCA_ACCUM_AUTO: falls back to fp64 if the extra buffers do not fit
    uint8_t *d_packedT = nullptr;
    size_t pitchT = 0;
    double *d_inv_sd = nullptr, *d_mu_inv_sd = nullptr, *d_i8w = nullptr;
@@ -149,9 +150,15 @@ void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int devi
       throw Error(FPCA_EINVAL, "unknown standardisation method: " + std::to_string(stand)); // data.cpp:283-288
    if (dense && (stand < FPCA_STANDARDISE_NONE || stand > FPCA_STANDARDISE_CENTER))
       throw Error(FPCA_EINVAL, "unknown standardization method"); // util.cpp:183
+   if (accum == FPCA_ACCUM_AUTO) {
+      // the exact-integer path when it applies (2-bit input, int32-safe sizes), else the fp64 MFMA path
+      const bool fits = !dense && std::max<uint64_t>(N, P_g) <= (uint64_t)15000000;
+      accum = fits ? FPCA_ACCUM_I8(8) : FPCA_ACCUM_FP64;
+      c->i8_auto = fits;
+   }
    const bool i8 = accum >= FPCA_ACCUM_I8(2) && accum <= FPCA_ACCUM_I8(9);
    if (accum != FPCA_ACCUM_FP64 && accum != FPCA_ACCUM_FP32 && !i8)
-      throw Error(FPCA_EINVAL, "accum must be FPCA_ACCUM_FP64, FPCA_ACCUM_FP32 or FPCA_ACCUM_I8(2..9)");
+      throw Error(FPCA_EINVAL, "accum must be FPCA_ACCUM_AUTO, FPCA_ACCUM_FP64, FPCA_ACCUM_FP32 or FPCA_ACCUM_I8(2..9)");
    if (i8 && dense) throw Error(FPCA_EINVAL, "the int8-sliced mode needs 2-bit genotype input");
    int ndev = 0;
    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -245,7 +252,35 @@ void ensure_stats(fpca_ctx *c)
 constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_ZERO = 1920, I8W_MAXB = 1920, I8W_MAXG = 1984, I8W_MAXM = 2048,
               I8W_CSB = 2112, I8W_CSM = 2752, I8W_TOTAL = 3392;
 
-void ensure_i8(fpca_ctx *c, int b)
+void ensure_i8_alloc(fpca_ctx *c, int b);
+
+// true: the int8 path is ready for blocks of width b.  false (FPCA_ACCUM_AUTO only): its extra buffers did not fit, the
+// context has been switched to the fp64 kernels for good.
+bool ensure_i8(fpca_ctx *c, int b)
+{
+   try {
+      ensure_i8_alloc(c, b);
+      return true;
+   } catch (const Error &e) {
+      if (!c->i8_auto || (e.code != FPCA_EHIP && e.code != FPCA_ENOMEM)) throw;
+      (void)hipGetLastError();
+      std::fprintf(stderr, "[fpca] exact-integer mode needs more device memory than is free (%s); using the fp64 kernels\n", e.what());
+      void **ptrs[] = {(void **)&c->d_packedT, (void **)&c->d_Qb, (void **)&c->d_Qg, (void **)&c->d_Qm, (void **)&c->d_i8ws};
+      for (void **p : ptrs)
+         if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+         }
+      c->i8_transposed = false;
+      c->i8_nsc = 0;
+      c->i8ws_cap = 0;
+      c->i8_S = 0;
+      c->accum = FPCA_ACCUM_FP64;
+      return false;
+   }
+}
+
+void ensure_i8_alloc(fpca_ctx *c, int b)
 {
    hipStream_t s = c->stream;
    // exact int32 accumulation: |sum| <= 2 * 64 * K must stay below 2^31
@@ -253,11 +288,11 @@ void ensure_i8(fpca_ctx *c, int b)
       throw Error(FPCA_EINVAL, "the int8-sliced mode supports up to 16,000,000 samples and SNPs per GPU (int32 accumulation)");
    if (!c->i8_transposed) {
       c->pitchT = (size_t)c->P_pad / 4;
+      if (!c->d_inv_sd) HIP_CHECK(hipMalloc(&c->d_inv_sd, c->P_pad * sizeof(double)));
+      if (!c->d_mu_inv_sd) HIP_CHECK(hipMalloc(&c->d_mu_inv_sd, c->P_pad * sizeof(double)));
+      if (!c->d_i8w) HIP_CHECK(hipMalloc(&c->d_i8w, I8W_TOTAL * sizeof(double)));
       HIP_CHECK(hipMalloc(&c->d_packedT, c->pitchT * c->N_pad));
       kern::transpose_packed(c->d_packed, c->pitch, c->N_pad, c->P_pad, c->d_packedT, c->pitchT, s);
-      HIP_CHECK(hipMalloc(&c->d_inv_sd, c->P_pad * sizeof(double)));
-      HIP_CHECK(hipMalloc(&c->d_mu_inv_sd, c->P_pad * sizeof(double)));
-      HIP_CHECK(hipMalloc(&c->d_i8w, I8W_TOTAL * sizeof(double)));
       c->i8_transposed = true;
    }
    if (!c->i8_scales_done) {
@@ -338,8 +373,7 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max)
 void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t s, hipEvent_t *ev)
 {
    ensure_stats(c);
-   if (c->i8_S) {
-      ensure_i8(c, b);
+   if (c->i8_S && ensure_i8(c, b)) {
       c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
       if (ev) HIP_CHECK(hipEventRecord(ev[0], s));
       i8_zero_meta(c, s);
@@ -378,8 +412,7 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
 void xt_dev(fpca_ctx *c, const double *dB, int b, hipStream_t s)
 {
    ensure_stats(c);
-   if (c->i8_S) {
-      ensure_i8(c, b);
+   if (c->i8_S && ensure_i8(c, b)) {
       c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
       i8_zero_meta(c, s);
       xt_i8(c, dB, b, s, false);
@@ -398,8 +431,7 @@ void xt_dev(fpca_ctx *c, const double *dB, int b, hipStream_t s)
 void x_dev(fpca_ctx *c, int b, double *dY, hipStream_t s)
 {
    ensure_stats(c);
-   if (c->i8_S) {
-      ensure_i8(c, b);
+   if (c->i8_S && ensure_i8(c, b)) {
       i8_zero_meta(c, s);
       x_i8(c, b, dY, s, false);
       return;
@@ -800,6 +832,8 @@ int fpca_set_meansd(fpca_ctx *ctx, const double *mean_sd)
       ctx->trace_local = 0;
    });
 }
+
+int fpca_accum(const fpca_ctx *ctx) { return ctx ? ctx->accum : FPCA_EINVAL; }
 
 // ---- operator, host pointers -------------------------------------------------------------------------
 int fpca_apply_xxt(fpca_ctx *ctx, const double *B, int64_t ldb, int b, double *Y, int64_t ldy)

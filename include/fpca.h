@@ -45,7 +45,9 @@ extern "C" {
 #define FPCA_DIVISOR_NONE 0
 #define FPCA_DIVISOR_N1 1
 #define FPCA_DIVISOR_P 2
-/* accumulate type of the two genotype GEMMs */
+/* arithmetic of the two genotype GEMMs.  AUTO = the exact-integer path FPCA_ACCUM_I8(8) for 2-bit input (falling back to
+ * FP64 if its extra buffers -- a second, sample-major 2-bit copy and the int8 operands -- do not fit), FP64 for dense input */
+#define FPCA_ACCUM_AUTO 0
 #define FPCA_ACCUM_FP64 64
 #define FPCA_ACCUM_FP32 32
 /* exact-integer mode: the fp64 operand is cut into S signed 7-bit slices (shared power-of-two scale per column) and
@@ -102,6 +104,7 @@ void fpca_destroy(fpca_ctx *ctx);
 
 uint64_t fpca_nsamples(const fpca_ctx *ctx);   /* Data::N */
 uint64_t fpca_nsnps(const fpca_ctx *ctx);      /* shard's P_g (Data::nsnps for a 1-shard run) */
+int fpca_accum(const fpca_ctx *ctx);           /* the FPCA_ACCUM_* mode in effect (AUTO resolved; may drop to FP64 at the first apply) */
 /* copy the shard's packed stream back (P_g * ceil(N/4) bytes, .bed body layout) -- used by the tests to feed
  * the CPU oracle the exact matrix a synthetic context holds */
 int fpca_download_packed(fpca_ctx *ctx, uint8_t *out);

@@ -258,3 +258,17 @@ def test_i8_mode_ragged_shapes(N, P, fp, orc):
     assert np.all(np.isfinite(Z))
     assert np.max(np.abs(Z - Z_ref)) <= 1e-11 * max(1.0, np.max(np.abs(Z_ref)))
     ctx.close()
+
+
+def test_auto_mode_resolution(golden_dir, fp):
+    """FPCA_ACCUM_AUTO: the exact-integer path for 2-bit input; explicit modes are reported as given."""
+    N = fp.count_fam_rows(os.path.join(golden_dir, "data_chr1.fam"))
+    bed = os.path.join(golden_dir, "data_chr1.bed")
+    with fp.Context.from_bed(bed, N, accum="auto") as c:
+        assert c.accum == "i8x8"
+    with fp.Context.from_bed(bed, N, accum="fp64") as c:
+        assert c.accum == "fp64"
+    with fp.Context.from_bed(bed, N, accum="i8x6") as c:
+        assert c.accum == "i8x6"
+    with fp.Context.from_dense(np.random.default_rng(0).standard_normal((50, 20)), stand="sd") as c:
+        assert c.accum == "fp64"

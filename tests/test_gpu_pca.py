@@ -27,11 +27,12 @@ def orc():
     return O
 
 
+@pytest.mark.parametrize("accum", ["fp64", "auto"])  # auto = the exact-integer path (FPCA_ACCUM_I8(8)): same tolerances
 @pytest.mark.parametrize("name,k,stand", [("hapmap3_data", 10, "binom2"), ("data_chr1", 50, "binom2"),
                                           ("data_chr1", 10, "binom"), ("data_chr1", 3, "binom2")])
-def test_pca_matches_golden(golden_dir, name, k, stand, fp):
+def test_pca_matches_golden(golden_dir, name, k, stand, accum, fp):
     g = json.load(open(os.path.join(golden_dir, "golden_%s_%s.json" % (name, stand))))
-    r = fp.flashpca(os.path.join(golden_dir, name), ndim=k, stand=stand, do_loadings=True, tol=1e-8)
+    r = fp.flashpca(os.path.join(golden_dir, name), ndim=k, stand=stand, do_loadings=True, tol=1e-8, accum=accum)
     ev = np.array(g["eigenvalues_div_p"])[:k]
     assert r["info"]["converged"] == 1
     assert np.max(np.abs(r["values"] - ev) / ev) < 1e-9
@@ -56,7 +57,7 @@ def test_pca_vs_oracle_reference_path(golden_dir, fp, orc):
     N = fp.count_fam_rows(os.path.join(golden_dir, name + ".fam"))
     od = orc.OracleData(os.path.join(golden_dir, name + ".bed"), N, "binom2")
     ref = orc.pca_fast(od, k, do_loadings=True)
-    r = fp.flashpca(os.path.join(golden_dir, name), ndim=k, do_loadings=True)
+    r = fp.flashpca(os.path.join(golden_dir, name), ndim=k, do_loadings=True, accum="fp64")
     assert np.max(np.abs(r["values"] - ref["d"]) / ref["d"]) < 1e-6  # both converged to tol 1e-6: agree far better
     assert np.max(np.abs(r["pve"] - ref["pve"])) < 1e-8
     for c in range(5):  # well-separated components; up to sign
