@@ -576,10 +576,10 @@ int gemm_i8_nsc_pad(int S, int b)
 }
 
 // split-K factor: one workgroup per CU, so the grid should be close to a multiple of 256 workgroups; each extra split
-// (A stream-K schedule would remove the round quantisation, but it also breaks the lock-step in which the workgroups of a
-// round stream the same operand chunks through L2: rotating the chunk order per workgroup costs 4-8 %, measured, so it
-// would only pay where the last round is less than ~3/4 full.)
-// costs one more fp64 partial round trip (rows * 2 * bw * 8 bytes per column block, written and read)
+// (A stream-K schedule -- one persistent workgroup per CU walking a contiguous range of (tile, chunk) units -- was built
+// and measured: it removes the round quantisation (cfg2's K3 has 392 tiles = 1.53 rounds) but breaks the lock-step in
+// which the workgroups of a round stream the same operand chunks through L2 and adds a prologue/epilogue per segment;
+// net: K3 0.561 vs 0.568 ms at cfg2, +10 % time at cfg3.  Not kept.)
 static int i8_splits(uint64_t rows_pad, uint64_t k_pad, const I8Shape &sh, int bw)
 {
    static const char *env = getenv("FPCA_I8_SPLITS");

@@ -1,8 +1,9 @@
 #!/bin/bash
-# int8-sliced mode: parity tests then timing
+# int8-sliced mode: parity tests (split-K, forced stream-K) then timing
 mkdir -p gpurun_out
-for sh in D; do
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "i8" 2>&1 | tail -3 | tee -a gpurun_out/i8_tests.log
+for k in ""; do
+echo "FPCA_I8_STREAM=$k"; FPCA_I8_STREAM=$k timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "i8" 2>&1 | tail -3 | tee -a gpurun_out/i8_tests.log
 done
-timeout 900 python -m pytest tests/test_gpu_pca.py tests/test_cli.py -x -q -m gpu 2>&1 | tail -3
-timeout 900 python scripts/i8_timing.py 2>&1 | tee -a gpurun_out/i8_timing.log
+for k in ""; do
+echo "FPCA_I8_STREAM=$k"; FPCA_I8_STREAM=$k timeout 900 python scripts/i8_timing.py 2>&1 | grep "i8 {" | tee -a gpurun_out/i8_timing.log
+done
