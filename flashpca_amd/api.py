@@ -35,14 +35,14 @@ class Context:
         L = lib()
         self.N = int(L.fpca_nsamples(handle))
         self.P = int(L.fpca_nsnps(handle))
+        self.P_total = self.P
+        self._keep = []
 
     @property
     def accum(self):
         """The arithmetic mode in effect: 'fp64', 'fp32' or 'i8xS' ("auto" resolved)."""
         code = int(lib().fpca_accum(self.h))
         return {64: "fp64", 32: "fp32"}.get(code, "i8x%d" % (code - 800))
-        self.P_total = self.P
-        self._keep = []
 
     # ---- constructors -----------------------------------------------------------------------------
     @classmethod

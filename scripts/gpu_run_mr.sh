@@ -5,7 +5,7 @@ echo "---- single-rank RCCL communicator (nranks=1) through the library"
 python - <<'PY'
 import sys; sys.path.insert(0,".")
 import numpy as np, flashpca_amd as fp
-ctx = fp.Context.synthetic(4000, 3000, n_pop=8)
+ctx = fp.Context.synthetic(4000, 3000, n_pop=8, accum="auto")
 uid = fp.Context.comm_unique_id()
 ctx.comm_init_rank(1, 0, uid)
 r = ctx.pca(ndim=5)

@@ -272,3 +272,27 @@ def test_auto_mode_resolution(golden_dir, fp):
         assert c.accum == "i8x6"
     with fp.Context.from_dense(np.random.default_rng(0).standard_normal((50, 20)), stand="sd") as c:
         assert c.accum == "fp64"
+
+
+@pytest.mark.parametrize("accum", ["fp64", "auto"])
+def test_allreduce_hook_and_native_single_rank(fp, accum):
+    """The two multi-GPU transports on one rank: the caller-supplied hook (called once per block apply with the N_pad x b
+    product, and it wins over a built-in communicator) and the built-in RCCL communicator with nranks = 1."""
+    N, P = 3000, 900
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((N, 16))
+    with fp.Context.synthetic(N, P, n_pop=6, accum=accum) as ref:
+        Z0 = ref.apply_xxt(B)
+    calls = []
+    with fp.Context.synthetic(N, P, n_pop=6, accum=accum) as c:
+        c.comm_init_rank(1, 0, fp.Context.comm_unique_id())
+        assert np.array_equal(c.apply_xxt(B), Z0)
+
+        def hook(ptr, count, stream):
+            calls.append(count)
+            return 0
+
+        c.set_allreduce(hook)
+        assert np.array_equal(c.apply_xxt(B), Z0)
+        assert len(calls) == 1 and calls[0] == c.block_rows() * 16
+        assert c.P_total == P
