@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
                                                      const int8_t *__restrict__ Qg, const int8_t *__restrict__ Qm,
                                                      uint64_t k_pad, const double *__restrict__ wg, const double *__restrict__ wm, int bw,
                                                      double *__restrict__ part, uint64_t rows_pad, int chunks_total,
-                                                     int chunks_per_split)
+                                                     int chunks_per_split, int zb)
 {
    constexpr bool TWO = C::TWO;
    constexpr int MT = C::MT, NT = C::NT, NQ = C::NQ, KC = C::KC, NP = C::NP, NP1 = C::NP1, NSTEP = C::NSTEP, LDQ = C::LDQ,
@@ -309,9 +309,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int li = lane & 31, kh = lane >> 5;
    const int wr = wave / C::WC, wc = wave % C::WC;
-   const uint64_t row0 = (uint64_t)blockIdx.x * C::ROWS;
-   const int col0 = blockIdx.z * C::COLS;
-   const int c_begin = blockIdx.y * chunks_per_split;
+   // XCD-aware 1-D grid (workgroup w runs on XCD w % 8, each XCD has its own L2): the zb column blocks of a row tile
+   // re-read the same packed rows, so they are given to the SAME XCD back to back (w and w + 8); the row tiles of one
+   // split are dealt round-robin over the XCDs; splits are outermost, so that a round of workgroups streams one K range
+   // of the operand in lock-step.  (With the plain 3-D grid the column blocks ran a whole grid apart and K3 read the
+   // packed stream from HBM twice: 29.9 GB per launch at cfg3 for 12.7 GB algorithmic.)
+   const int rtiles = (int)(rows_pad / C::ROWS), rtl = (rtiles + 7) / 8;
+   const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+   const int zblk = sidx % zb, qidx = sidx / zb;
+   const int split = qidx / rtl, rt = (qidx % rtl) * 8 + xcd;
+   if (rt >= rtiles) return;
+   const uint64_t row0 = (uint64_t)rt * C::ROWS;
+   const int col0 = zblk * C::COLS;
+   const int c_begin = split * chunks_per_split;
    int c_end = c_begin + chunks_per_split;
    if (c_end > chunks_total) c_end = chunks_total;
 
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
    // 2 x bw doubles instead of 2 x S*b int32.  Every product w * acc is exact (w is a power of two, |acc| < 2^31); only
    // the additions round, last slice (smallest terms) first.
    const int tile0 = (col0 + wc * 32 * NT) / 32;
-   double *out = part + (((size_t)(blockIdx.y * gridDim.z + blockIdx.z) * rows_pad + row0 + wr * 32 * MT) * 2) * bw + li;
+   double *out = part + (((size_t)(split * zb + zblk) * rows_pad + row0 + wr * 32 * MT) * 2) * bw + li;
    auto epilogue = [&](auto kbc) {
       constexpr int KB = decltype(kbc)::value; // bw / 32: a lane's tiles n, n + KB, ... feed the same virtual column
       double wgl[NT], wml[NT];
@@ -614,7 +624,7 @@ size_t gemm_i8_workspace_doubles(uint64_t rows_pad, uint64_t k_pad, int S, int b
 
 template <class C>
 static void launch_i8(dim3 grid, hipStream_t stream, const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, uint64_t k_pad,
-                      const double *wg, const double *wm, int bw, double *ws, uint64_t rows_pad, int chunks_total, int cps)
+                      const double *wg, const double *wm, int bw, double *ws, uint64_t rows_pad, int chunks_total, int cps, int zb)
 {
    static bool attr_set = false;
    if (!attr_set) {
@@ -622,7 +632,7 @@ static void launch_i8(dim3 grid, hipStream_t stream, const uint8_t *packed, size
       attr_set = true;
    }
    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<C>), grid, dim3(256), 2 * C::STAGE, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws,
-                      rows_pad, chunks_total, cps);
+                      rows_pad, chunks_total, cps, zb);
 }
 
 void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, const double *wg, const double *wm,
@@ -637,8 +647,9 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
    const int chunks_total = (int)(k_pad / sh.kc);
    const int cps = (chunks_total + nsplit - 1) / nsplit;
    const int nsplit_eff = (chunks_total + cps - 1) / cps; // no empty split
-   dim3 grid((unsigned)(rows_pad / sh.rows), (unsigned)nsplit_eff, (unsigned)sh.zb);
-#define FPCA_I8_ARGS grid, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws, rows_pad, chunks_total, cps
+   const unsigned rtl = (unsigned)((rows_pad / sh.rows + 7) / 8); // row tiles per XCD
+   dim3 grid(8u * rtl * (unsigned)sh.zb * (unsigned)nsplit_eff);
+#define FPCA_I8_ARGS grid, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws, rows_pad, chunks_total, cps, sh.zb
    if (two) {
       if (sh.nt == 3)
          launch_i8<I8Cfg<true, 2, 3, 4, 1, 256, 1>>(FPCA_I8_ARGS);
