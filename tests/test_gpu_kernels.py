@@ -296,3 +296,15 @@ def test_allreduce_hook_and_native_single_rank(fp, accum):
         assert np.array_equal(c.apply_xxt(B), Z0)
         assert len(calls) == 1 and calls[0] == c.block_rows() * 16
         assert c.P_total == P
+
+
+@pytest.mark.parametrize("accum", ["fp64", "auto"])
+def test_empty_shard(fp, accum):
+    """A rank may own zero SNPs (more GPUs than SNP tiles): its partial product is exactly zero."""
+    N = 300
+    with fp.Context.from_packed(np.zeros((0, (N + 3) // 4), dtype=np.uint8), N, 0, accum=accum) as c:
+        B = np.random.default_rng(0).standard_normal((N, 4))
+        Z = c.apply_xxt(B)
+        assert Z.shape == (N, 4) and np.all(Z == 0.0)
+        ms, trace = c.stats()
+        assert ms.shape[0] == 0 and trace == 0.0
