@@ -249,8 +249,9 @@ void ensure_stats(fpca_ctx *c)
 // ---- exact-integer mode --------------------------------------------------------------------------------
 // layout of d_i8w in 8-byte words: three weight vectors (S*b <= 9*64 = 576 entries each, padded), then the region that is
 // zeroed once per apply: column maxima (bit patterns) of the three operands and the column sums of the two M operands
-constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_ZERO = 1920, I8W_MAXB = 1920, I8W_MAXG = 1984, I8W_MAXM = 2048,
-              I8W_CSB = 2112, I8W_CSM = 2752, I8W_TOTAL = 3392;
+constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_ZERO = 1920, I8W_MAXB = I8W_ZERO, I8W_MAXG = I8W_MAXB + 64 * kern::I8_SHARDS,
+              I8W_MAXM = I8W_MAXG + 64 * kern::I8_SHARDS, I8W_CSB = I8W_MAXM + 64 * kern::I8_SHARDS,
+              I8W_CSM = I8W_CSB + kern::I8_CS_STRIDE * kern::I8_SHARDS, I8W_TOTAL = I8W_CSM + kern::I8_CS_STRIDE * kern::I8_SHARDS;
 
 void ensure_i8_alloc(fpca_ctx *c, int b);
 

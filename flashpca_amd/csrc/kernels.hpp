@@ -80,12 +80,13 @@ void census(uint32_t *d_out, int nwg, size_t lds_bytes, long long spin, hipStrea
 // ---- exact-integer int8-sliced path (kernels_i8.hip) ----
 // one int8 operand cut from an fp64 matrix V[rows_pad][b]: Q[S*b][rows_pad] digits of V * rowscale[row], weights colw,
 // optional exact column sums; maxbits = per-column max |V * rowscale| as double bit patterns (input of i8_slice)
+constexpr int I8_SHARDS = 8, I8_CS_STRIDE = 640; // accumulator sharding (see kernels_i8.hip)
 struct SliceOp {
    const double *rowscale;      // null: none
-   unsigned long long *maxbits; // [b]
+   unsigned long long *maxbits; // [I8_SHARDS][64]
    int8_t *Q;
    double *colw;       // [gemm_i8_nsc_pad(S, b)]
-   long long *colsum;  // [S*b] or null; accumulated with atomics: zero it first
+   long long *colsum;  // [I8_SHARDS][I8_CS_STRIDE] or null; accumulated with atomics: zero it first
 };
 void i8_colmax(const double *V, uint64_t rows, int b, int nops, const SliceOp *ops, hipStream_t stream); // maxbits must be zeroed
 void i8_slice(const double *V, uint64_t rows_pad, uint64_t rows, int b, int S, int nops, const SliceOp *ops, hipStream_t stream);

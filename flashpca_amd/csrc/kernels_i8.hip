@@ -50,6 +50,10 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 // Column maxima travel as the bit patterns of non-negative doubles (they order like integers, so an integer
 // atomicMax is exact); the caller zeroes them -- and the column sums -- once per apply.
 
+// Both kinds of accumulator are sharded I8_SHARDS ways by block index: same-address atomics serialise in L2 (~20 ns
+// each), and with hundreds of blocks that was longer than the kernels' useful work.  Consumers fold the shards.
+// maxbits: [I8_SHARDS][64], colsum: [I8_SHARDS][I8_CS_STRIDE]
+
 // block-level max over the 256/b row slots of each column, then one atomic per column
 __device__ __forceinline__ void colmax_commit(double m, int b, double *smax /* [256] */, unsigned long long *bits)
 {
@@ -58,8 +62,23 @@ __device__ __forceinline__ void colmax_commit(double m, int b, double *smax /* [
    __syncthreads();
    if ((int)threadIdx.x < b) {
       for (int k = 1; k < 256 / b; k++) m = fmax(m, smax[k * b + threadIdx.x]);
-      atomicMax(&bits[threadIdx.x], (unsigned long long)__double_as_longlong(m));
+      atomicMax(&bits[(blockIdx.x % I8_SHARDS) * 64 + threadIdx.x], (unsigned long long)__double_as_longlong(m));
    }
+}
+
+__device__ __forceinline__ unsigned long long maxbits_fold(const unsigned long long *bits, int c)
+{
+   unsigned long long m = 0;
+#pragma unroll
+   for (int k = 0; k < I8_SHARDS; k++) m = bits[k * 64 + c] > m ? bits[k * 64 + c] : m;
+   return m;
+}
+__device__ __forceinline__ long long colsum_fold(const long long *cs, int t)
+{
+   long long a = 0;
+#pragma unroll
+   for (int k = 0; k < I8_SHARDS; k++) a += cs[k * I8_CS_STRIDE + t];
+   return a;
 }
 
 // per-column max |v * rowscale| for one or two row scalings (standalone pass; the hot path gets K3's maxima from the
@@ -119,7 +138,7 @@ __global__ __launch_bounds__(256) void k_slice(const double *__restrict__ V, uin
    double sc[NOPS];
 #pragma unroll
    for (int o = 0; o < NOPS; o++) {
-      const int e = slice_exponent(ops[o]->maxbits[c]);
+      const int e = slice_exponent(maxbits_fold(ops[o]->maxbits, c));
       sc[o] = ldexp(1.0, 6 - e);
       if (blockIdx.x == 0) {
          if (gl == 0) {
@@ -175,7 +194,9 @@ __global__ __launch_bounds__(256) void k_slice(const double *__restrict__ V, uin
                   const int s = t / b, cc = t % b;
                   long long a = 0;
                   for (int k = 0; k < gpb; k++) a += ssum[o][s][k * b + cc];
-                  if (a) atomicAdd(reinterpret_cast<unsigned long long *>(&ops[o]->colsum[t]), (unsigned long long)a);
+                  if (a)
+                     atomicAdd(reinterpret_cast<unsigned long long *>(&ops[o]->colsum[(blockIdx.x % I8_SHARDS) * I8_CS_STRIDE + t]),
+                               (unsigned long long)a);
                }
          __syncthreads();
       }
@@ -186,8 +207,7 @@ int gemm_i8_nsc_pad(int S, int b);
 
 void i8_colmax(const double *V, uint64_t rows, int b, int nops, const SliceOp *ops, hipStream_t stream)
 {
-   // few blocks: every block ends with one atomic per column, and same-address atomics serialise in L2 (~20 ns each)
-   const unsigned blocks = (unsigned)std::min<uint64_t>(256, rows * b / 1024 + 1);
+   const unsigned blocks = (unsigned)std::min<uint64_t>(1024, rows * b / 1024 + 1);
    if (nops == 2)
       hipLaunchKernelGGL(k_colmax<2>, dim3(blocks), dim3(256), 0, stream, V, rows, b, ops[0].rowscale, ops[0].maxbits, ops[1].rowscale,
                          ops[1].maxbits);
@@ -199,8 +219,7 @@ void i8_colmax(const double *V, uint64_t rows, int b, int nops, const SliceOp *o
 void i8_slice(const double *V, uint64_t rows_pad, uint64_t rows, int b, int S, int nops, const SliceOp *ops, hipStream_t stream)
 {
    if (S > 9 || b > 64 || nops < 1 || nops > 2) throw Error(-1, "i8_slice: S <= 9, b <= 64, 1 or 2 operands");
-   const unsigned blocks = (unsigned)std::min<uint64_t>(ops[0].colsum || (nops == 2 && ops[1].colsum) ? 512 : 4096,
-                                                        (rows_pad / 16 + (256 / b) - 1) / (256 / b));
+   const unsigned blocks = (unsigned)std::min<uint64_t>(4096, (rows_pad / 16 + (256 / b) - 1) / (256 / b));
    const int nsc = gemm_i8_nsc_pad(S, b);
    if (nops == 2)
       hipLaunchKernelGGL(k_slice<2>, dim3(blocks), dim3(256), 0, stream, V, rows_pad, rows, b, S, nsc, ops[0], ops[1]);
@@ -521,12 +540,20 @@ __global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ p
                                                      unsigned long long *__restrict__ bits0, const double *__restrict__ rs1,
                                                      unsigned long long *__restrict__ bits1)
 {
-   __shared__ double smax[256];
+   __shared__ double smax[256], sw[9 * 64], sones[64];
    const int c = threadIdx.x % b, r_in = threadIdx.x / b, r_step = 256 / b;
    double m0 = 0.0, m1 = 0.0;
+   // 1'Qm recombined once per block: sum_s w[s,c] colsum[s,c] (shards folded), small terms first
+   for (int t = threadIdx.x; t < S * b; t += 256) sw[t] = wm[t] * (double)colsum_fold(colsum_m, t);
+   __syncthreads();
+   if ((int)threadIdx.x < b) {
+      double o = 0.0;
+      for (int s = S - 1; s >= 0; s--) o += sw[s * b + threadIdx.x];
+      sones[threadIdx.x] = o;
+   }
+   __syncthreads();
    if (r_in < r_step) {
-      double ones = 0.0; // 1'Qm recombined: sum_s w[s,c] colsum[s,c], small terms first
-      for (int s = S - 1; s >= 0; s--) ones += wm[s * b + c] * (double)colsum_m[s * b + c];
+      const double ones = sones[c];
       for (uint64_t row = (uint64_t)blockIdx.x * r_step + r_in; row < rows_pad; row += (uint64_t)gridDim.x * r_step) {
          double accg = 0.0, acce = 0.0;
          for (int p = 0; p < nplanes; p++) {
@@ -666,7 +693,7 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
    }
 #undef FPCA_I8_ARGS
    HIP_CHECK_LAUNCH();
-   const unsigned blocks = (unsigned)std::min<uint64_t>(next_ops ? 512 : 4096, (rows_pad + (256 / b) - 1) / (256 / b));
+   const unsigned blocks = (unsigned)std::min<uint64_t>(1024, (rows_pad + (256 / b) - 1) / (256 / b));
    hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, nsplit_eff * sh.zb, rows_pad, b, bw, S, wm, colsum_m, mean, sd, out,
                       next_ops ? next_ops[0].rowscale : nullptr, next_ops ? next_ops[0].maxbits : nullptr,
                       next_ops ? next_ops[1].rowscale : nullptr, next_ops ? next_ops[1].maxbits : nullptr);

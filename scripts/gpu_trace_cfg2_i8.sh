@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_cfg2_i8 -o t -- python bench.py --accum i8 --steps 20 --warmup 3 --no-cpu-baseline --no-pca > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_cfg2_i8 -o t -- python bench.py --accum i8 --steps 20 --warmup 3 --no-cpu-baseline --no-pca --no-alt > /dev/null 2>&1
 python - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/trace_cfg2_i8/*kernel_trace.csv")[0]
