@@ -318,8 +318,8 @@ template <class C>
 __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ packed, size_t pitch,
                                                      const int8_t *__restrict__ Qg, const int8_t *__restrict__ Qm,
                                                      uint64_t k_pad, const double *__restrict__ wg, const double *__restrict__ wm, int bw,
-                                                     double *__restrict__ part, uint64_t rows_pad, int chunks_total,
-                                                     int chunks_per_split, int zb)
+                                                     double *__restrict__ part, uint64_t rows_pad, int chunks_total, int zb,
+                                                     int nA, int sB, int cpsB, uint64_t rowB0, uint64_t rowsB)
 {
    constexpr bool TWO = C::TWO;
    constexpr int MT = C::MT, NT = C::NT, NQ = C::NQ, KC = C::KC, NP = C::NP, NP1 = C::NP1, NSTEP = C::NSTEP, LDQ = C::LDQ,
@@ -331,18 +331,27 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
    // XCD-aware 1-D grid (workgroup w runs on XCD w % 8, each XCD has its own L2): the zb column blocks of a row tile
    // re-read the same packed rows, so they are given to the SAME XCD back to back (w and w + 8); the row tiles of one
    // split are dealt round-robin over the XCDs; splits are outermost, so that a round of workgroups streams one K range
-   // of the operand in lock-step.  (With the plain 3-D grid the column blocks ran a whole grid apart and K3 read the
+   // of the operand in lock-step (nB is a multiple of 8, so the XCD of a phase-B workgroup is still w0 % 8).  (With the plain 3-D grid the column blocks ran a whole grid apart and K3 read the
    // packed stream from HBM twice: 29.9 GB per launch at cfg3 for 12.7 GB algorithmic.)
-   const int rtiles = (int)(rows_pad / C::ROWS), rtl = (rtiles + 7) / 8;
-   const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
-   const int zblk = sidx % zb, qidx = sidx / zb;
-   const int split = qidx / rtl, rt = (qidx % rtl) * 8 + xcd;
-   if (rt >= rtiles) return;
+   //
+   // Two-phase split-K.  Tile ids w0 (in the XCD-aware order) below nA -- whole rounds of one workgroup per CU -- run
+   // UNSPLIT (phase A: no partial planes beyond plane 0, the whole round streams the operand in lock-step); the
+   // remaining nB < #CU.. tiles, which would otherwise be a mostly idle last round, are cut sB ways along K (phase B,
+   // workgroup ids nA + split * nB + k).  nA = 0 is plain split-K.
+   const int rtiles = (int)(rows_pad / C::ROWS), rtl = (rtiles + 7) / 8, ids = 8 * rtl * zb, nB = ids - nA;
+   int w0 = blockIdx.x, split = 0, c_begin = 0, c_end = chunks_total;
+   if (w0 >= nA) {
+      const int wp = w0 - nA;
+      split = wp / nB;
+      w0 = nA + wp % nB;
+      c_begin = split * cpsB;
+      c_end = c_begin + cpsB < chunks_total ? c_begin + cpsB : chunks_total;
+   }
+   const int xcd = w0 & 7, sidx = w0 >> 3;
+   const int zblk = sidx % zb, rt = (sidx / zb) * 8 + xcd;
+   if (rt >= rtiles || c_begin >= c_end) return;
    const uint64_t row0 = (uint64_t)rt * C::ROWS;
    const int col0 = zblk * C::COLS;
-   const int c_begin = split * chunks_per_split;
-   int c_end = c_begin + chunks_per_split;
-   if (c_end > chunks_total) c_end = chunks_total;
 
    v16i acc[2][MT][NT]; // [mat][m][n]
 #pragma unroll
@@ -487,7 +496,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
    // 2 x bw doubles instead of 2 x S*b int32.  Every product w * acc is exact (w is a power of two, |acc| < 2^31); only
    // the additions round, last slice (smallest terms) first.
    const int tile0 = (col0 + wc * 32 * NT) / 32;
-   double *out = part + (((size_t)(split * zb + zblk) * rows_pad + row0 + wr * 32 * MT) * 2) * bw + li;
+   // partial planes: plane 0 holds every row, planes 1 .. sB-1 only the rows of the phase-B tiles (rows >= rowB0)
+   double *out = (split == 0 ? part + (((size_t)zblk * rows_pad + row0 + wr * 32 * MT) * 2) * bw
+                             : part + (size_t)zb * rows_pad * 2 * bw +
+                                  ((((size_t)(split - 1) * zb + zblk) * rowsB + (row0 - rowB0) + wr * 32 * MT) * 2) * bw) +
+                 li;
    auto epilogue = [&](auto kbc) {
       constexpr int KB = decltype(kbc)::value; // bw / 32: a lane's tiles n, n + KB, ... feed the same virtual column
       double wgl[NT], wml[NT];
@@ -533,7 +546,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
 //   K3               : out[row][c] =   G[row][c] - M[row][c]
 // The K2 flavour can also leave the column maxima of out * rs0 and out * rs1 behind (the two K3 operands), which saves
 // the next stage a pass over T.
-__global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ part, int nplanes, uint64_t rows_pad, int b, int bw, int S,
+__global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ part, int zb, int rows_tile, int nA, int sB, uint64_t rowB0,
+                                                     uint64_t rowsB, uint64_t rows_pad, int b, int bw, int S,
                                                      const double *__restrict__ wm, const long long *__restrict__ colsum_m /* 1'Qm */,
                                                      const double *__restrict__ mean, const double *__restrict__ sd,
                                                      double *__restrict__ out, const double *__restrict__ rs0,
@@ -556,11 +570,17 @@ __global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ p
       const double ones = sones[c];
       for (uint64_t row = (uint64_t)blockIdx.x * r_step + r_in; row < rows_pad; row += (uint64_t)gridDim.x * r_step) {
          double accg = 0.0, acce = 0.0;
-         for (int p = 0; p < nplanes; p++) {
-            const double *q = part + (((size_t)p * rows_pad + row) * 2) * bw;
-            for (int j = c; j < bw; j += b) {
-               accg += q[j];
-               acce += q[bw + j];
+         const int rt = (int)(row / rows_tile);
+         for (int z = 0; z < zb; z++) {
+            const int w0 = ((rt >> 3) * zb + z) * 8 + (rt & 7);
+            const int np = w0 < nA ? 1 : sB; // phase-A tiles were not split
+            for (int p = 0; p < np; p++) {
+               const double *q = p == 0 ? part + (((size_t)z * rows_pad + row) * 2) * bw
+                                        : part + (size_t)zb * rows_pad * 2 * bw + ((((size_t)(p - 1) * zb + z) * rowsB + (row - rowB0)) * 2) * bw;
+               for (int j = c; j < bw; j += b) {
+                  accg += q[j];
+                  acce += q[bw + j];
+               }
             }
          }
          const double accm = ones - acce;
@@ -612,30 +632,63 @@ int gemm_i8_nsc_pad(int S, int b)
    return std::max(s2.zb * s2.cols, s3.zb * s3.cols);
 }
 
-// split-K factor: one workgroup per CU, so the grid should be close to a multiple of 256 workgroups; each extra split
+// Work decomposition of one GEMM launch (see k_gemm_i8): one workgroup per CU, so whole rounds of #CU tiles run unsplit
+// (phase A) and only the leftover tiles are split along K (phase B); each extra split of phase B costs a partial plane
+// for ITS rows only.  Plain split-K (nA = 0) is kept for problems with less than one round of tiles.
 // (A stream-K schedule -- one persistent workgroup per CU walking a contiguous range of (tile, chunk) units -- was built
-// and measured: it removes the round quantisation (cfg2's K3 has 392 tiles = 1.53 rounds) but breaks the lock-step in
-// which the workgroups of a round stream the same operand chunks through L2 and adds a prologue/epilogue per segment;
-// net: K3 0.561 vs 0.568 ms at cfg2, +10 % time at cfg3.  Not kept.)
-static int i8_splits(uint64_t rows_pad, uint64_t k_pad, const I8Shape &sh, int bw)
+// and measured: it removes the round quantisation too, but it breaks the lock-step in which the workgroups of a round
+// stream the same operand chunks through L2 and adds a prologue/epilogue per segment; net: K3 0.561 vs 0.568 ms at cfg2,
+// +10 % time at cfg3.  Not kept.)
+struct I8Plan {
+   int nA, sB, cpsB;
+   uint64_t rowB0, rowsB;
+   unsigned grid;
+};
+
+static I8Plan i8_plan(uint64_t rows_pad, uint64_t k_pad, const I8Shape &sh, int bw)
 {
-   static const char *env = getenv("FPCA_I8_SPLITS");
-   const uint64_t tiles = rows_pad / sh.rows * (uint64_t)sh.zb, chunks = k_pad / sh.kc;
-   if (env && atoi(env) > 0) return (int)std::min<uint64_t>((uint64_t)atoi(env), chunks);
+   static const char *env_s = getenv("FPCA_I8_SPLITS"); // force plain split-K with this factor
+   static int ncu = 0;
+   if (!ncu) {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) ? prop.multiProcessorCount / 8 * 8 : 256;
+   }
+   const int rtiles = (int)(rows_pad / sh.rows), rtl = (rtiles + 7) / 8, ids = 8 * rtl * sh.zb;
+   const int chunks = (int)(k_pad / sh.kc);
    const double t_chunk = 2.2e-6 * (double)sh.rows * sh.cols * sh.kc / (128.0 * 256 * 256); // one workgroup-chunk at ~3 POP/s
-   const double t_part = (double)rows_pad * 2 * bw * 8 * 2 * sh.zb / 3.0e12;                  // partial write + read per split
+   const double t_seg = 5e-6;                                                               // prologue + epilogue of a workgroup
+   const double t_row_plane = 2.0 * bw * 8 * 2 * sh.rows / 3.0e12;                          // one tile's partial, written + read
    double best = 1e30;
-   int best_s = 1;
-   for (uint64_t s = 1; s <= 16 && s * 4 <= std::max<uint64_t>(chunks, 4); s++) {
-      const uint64_t cps = (chunks + s - 1) / s;
-      const uint64_t rounds = (tiles * s + 255) / 256;
-      const double t = (double)rounds * (double)cps * t_chunk + (double)s * t_part;
-      if (t < best * 0.995) {
-         best = t;
-         best_s = (int)s;
+   int best_nA = 0, best_s = 1;
+   const int nA_full = ids / ncu * ncu;
+   for (int pass = 0; pass < 2; pass++) {
+      const int nA = pass == 0 ? 0 : (nA_full == ids ? ids - ncu : nA_full);
+      if (pass == 1 && (nA <= 0 || (env_s && atoi(env_s) > 0))) break;
+      const int nB = ids - nA;
+      for (int s = 1; s <= 16 && (s == 1 || s * 4 <= chunks); s++) {
+         if (pass == 0 && env_s && atoi(env_s) > 0 && s != std::min(atoi(env_s), std::max(chunks / 4, 1))) continue;
+         const int cps = (chunks + s - 1) / s;
+         const double tA = (double)(nA / ncu) * (chunks * t_chunk + t_seg);
+         const double tB = (double)((nB * s + ncu - 1) / ncu) * (cps * t_chunk + t_seg);
+         const double t = tA + tB + (s > 1 ? (double)s * nB * t_row_plane : 0.0);
+         if (t < best * 0.995) {
+            best = t;
+            best_nA = nA;
+            best_s = s;
+         }
       }
    }
-   return best_s;
+   I8Plan p;
+   p.nA = best_nA;
+   p.cpsB = (chunks + best_s - 1) / best_s;
+   p.sB = (chunks + p.cpsB - 1) / p.cpsB; // no empty split
+   const int qA = (p.nA / 8) / sh.zb;     // phase-B tiles have row tile >= 8 qA
+   p.rowB0 = std::min<uint64_t>((uint64_t)qA * 8 * sh.rows, rows_pad);
+   p.rowsB = rows_pad - p.rowB0;
+   p.grid = (unsigned)(p.nA + (ids - p.nA) * p.sB);
+   return p;
 }
 
 static int i8_bw(int b) // lcm(32, b) for b in {16, 32, 48, 64}
@@ -646,20 +699,21 @@ static int i8_bw(int b) // lcm(32, b) for b in {16, 32, 48, 64}
 size_t gemm_i8_workspace_doubles(uint64_t rows_pad, uint64_t k_pad, int S, int b, bool two)
 {
    const I8Shape sh = i8_shape(S, b, two);
-   return (size_t)i8_splits(rows_pad, k_pad, sh, i8_bw(b)) * sh.zb * rows_pad * 2 * (size_t)i8_bw(b);
+   const I8Plan p = i8_plan(rows_pad, k_pad, sh, i8_bw(b));
+   return ((size_t)rows_pad + (size_t)(p.sB - 1) * p.rowsB) * sh.zb * 2 * (size_t)i8_bw(b);
 }
 
 template <class C>
-static void launch_i8(dim3 grid, hipStream_t stream, const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, uint64_t k_pad,
-                      const double *wg, const double *wm, int bw, double *ws, uint64_t rows_pad, int chunks_total, int cps, int zb)
+static void launch_i8(const I8Plan &pl, hipStream_t stream, const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm,
+                      uint64_t k_pad, const double *wg, const double *wm, int bw, double *ws, uint64_t rows_pad, int chunks_total, int zb)
 {
    static bool attr_set = false;
    if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::STAGE);
       attr_set = true;
    }
-   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<C>), grid, dim3(256), 2 * C::STAGE, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws,
-                      rows_pad, chunks_total, cps, zb);
+   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<C>), dim3(pl.grid), dim3(256), 2 * C::STAGE, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw,
+                      ws, rows_pad, chunks_total, zb, pl.nA, pl.sB, pl.cpsB, pl.rowB0, pl.rowsB);
 }
 
 void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, const double *wg, const double *wm,
@@ -670,13 +724,9 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
    const bool two = (Qg != Qm);
    const I8Shape sh = i8_shape(S, b, two);
    const int bw = i8_bw(b); // Q holds gemm_i8_nsc_pad(S, b) rows; rows >= S*b are zero and carry zero weights
-   const int nsplit = i8_splits(rows_pad, k_pad, sh, bw);
+   const I8Plan pl = i8_plan(rows_pad, k_pad, sh, bw);
    const int chunks_total = (int)(k_pad / sh.kc);
-   const int cps = (chunks_total + nsplit - 1) / nsplit;
-   const int nsplit_eff = (chunks_total + cps - 1) / cps; // no empty split
-   const unsigned rtl = (unsigned)((rows_pad / sh.rows + 7) / 8); // row tiles per XCD
-   dim3 grid(8u * rtl * (unsigned)sh.zb * (unsigned)nsplit_eff);
-#define FPCA_I8_ARGS grid, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws, rows_pad, chunks_total, cps, sh.zb
+#define FPCA_I8_ARGS pl, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws, rows_pad, chunks_total, sh.zb
    if (two) {
       if (sh.nt == 3)
          launch_i8<I8Cfg<true, 2, 3, 4, 1, 256, 1>>(FPCA_I8_ARGS);
@@ -694,7 +744,7 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
 #undef FPCA_I8_ARGS
    HIP_CHECK_LAUNCH();
    const unsigned blocks = (unsigned)std::min<uint64_t>(1024, (rows_pad + (256 / b) - 1) / (256 / b));
-   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, nsplit_eff * sh.zb, rows_pad, b, bw, S, wm, colsum_m, mean, sd, out,
+   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, sh.zb, sh.rows, pl.nA, pl.sB, pl.rowB0, pl.rowsB, rows_pad, b, bw, S, wm, colsum_m, mean, sd, out,
                       next_ops ? next_ops[0].rowscale : nullptr, next_ops ? next_ops[0].maxbits : nullptr,
                       next_ops ? next_ops[1].rowscale : nullptr, next_ops ? next_ops[1].maxbits : nullptr);
    HIP_CHECK_LAUNCH();

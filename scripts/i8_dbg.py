@@ -7,10 +7,11 @@ import flashpca_amd as fp
 N, P = %d, %d
 ctx = fp.Context.synthetic(N, P, n_pop=40, accum="i8")
 r = ctx.bench_apply(b=32, steps=%d, warmup=2)
+r = ctx.bench_apply(b=32, steps=%d, warmup=2)
 print(json.dumps(dict(ms_xt=round(r["ms_xt"], 4), ms_x=round(r["ms_x"], 4))))
 '''
-for name, N, P, steps in (("cfg2", 50000, 20000, 20),):
-    for env in [dict()] + [dict(FPCA_I8_SPLITS=s) for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16)]:
+for name, N, P, steps in (("cfg2", 50000, 20000, 20), ("cfg3", 500000, 100000, 3)):
+    for env in [dict(), dict(FPCA_I8_SPLITS=1), dict(FPCA_I8_SPLITS=3), dict(FPCA_I8_SPLITS=5), dict()]:
         e = dict(os.environ); e.update({k: str(v) for k, v in env.items()})
-        out = subprocess.run([sys.executable, "-c", CHILD % (ROOT, N, P, steps)], env=e, capture_output=True, text=True)
+        out = subprocess.run([sys.executable, "-c", CHILD % (ROOT, N, P, steps, steps)], env=e, capture_output=True, text=True)
         print(name, env, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:], flush=True)
