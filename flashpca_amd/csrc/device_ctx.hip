@@ -284,6 +284,7 @@ bool ensure_i8(fpca_ctx *c, int b)
 void ensure_i8_alloc(fpca_ctx *c, int b)
 {
    hipStream_t s = c->stream;
+   if (getenv("FPCA_DEBUG_I8_NOMEM")) throw Error(FPCA_ENOMEM, "FPCA_DEBUG_I8_NOMEM is set"); // exercises the fallback in the tests
    // exact int32 accumulation: |sum| <= 2 * 64 * K must stay below 2^31
    if (std::max(c->N_pad, c->P_pad) > (uint64_t)16000000)
       throw Error(FPCA_EINVAL, "the int8-sliced mode supports up to 16,000,000 samples and SNPs per GPU (int32 accumulation)");

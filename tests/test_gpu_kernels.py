@@ -308,3 +308,21 @@ def test_empty_shard(fp, accum):
         assert Z.shape == (N, 4) and np.all(Z == 0.0)
         ms, trace = c.stats()
         assert ms.shape[0] == 0 and trace == 0.0
+
+
+def test_auto_mode_falls_back_to_fp64_when_buffers_do_not_fit(fp, monkeypatch):
+    """FPCA_ACCUM_AUTO switches to the fp64 kernels (and says so) if the int8 path cannot allocate its buffers; an
+    explicitly requested int8 mode reports the error instead."""
+    N, P = 2000, 700
+    B = np.random.default_rng(1).standard_normal((N, 8))
+    with fp.Context.synthetic(N, P, n_pop=6, accum="fp64") as ref:
+        Z0 = ref.apply_xxt(B)
+    monkeypatch.setenv("FPCA_DEBUG_I8_NOMEM", "1")
+    with fp.Context.synthetic(N, P, n_pop=6, accum="auto") as c:
+        assert c.accum == "i8x8"
+        Z = c.apply_xxt(B)
+        assert c.accum == "fp64"
+        assert np.array_equal(Z, Z0)
+    with fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:
+        with pytest.raises(fp.FpcaError):
+            c.apply_xxt(B)
