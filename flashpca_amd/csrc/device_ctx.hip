@@ -115,6 +115,8 @@ struct fpca_ctx {
    // communication
    ncclComm_t comm = nullptr;
    int nranks = 1, rank = 0;
+   hipStream_t comm_stream = nullptr; // the all-reduce of a row chunk of Y runs here while the next chunk is computed
+   hipEvent_t ev_chunk[4] = {nullptr, nullptr, nullptr, nullptr}, ev_comm_done = nullptr;
    fpca_allreduce_fn ar_fn = nullptr;
    void *ar_user = nullptr;
    // live profiling (fpca_profile_begin/end)
@@ -222,6 +224,10 @@ void ctx_free(fpca_ctx *c)
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+   for (hipEvent_t e : c->ev_chunk)
+      if (e) (void)hipEventDestroy(e);
+   if (c->ev_comm_done) (void)hipEventDestroy(c->ev_comm_done);
+   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
    if (c->stream) (void)hipStreamDestroy(c->stream);
    delete c;
 }
@@ -254,6 +260,7 @@ constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_ZERO = 1920, I8W_MAXB = 
               I8W_CSM = I8W_CSB + kern::I8_CS_STRIDE * kern::I8_SHARDS, I8W_TOTAL = I8W_CSM + kern::I8_CS_STRIDE * kern::I8_SHARDS;
 
 void ensure_i8_alloc(fpca_ctx *c, int b);
+uint64_t ar_chunk_begin(const fpca_ctx *c, int nchunks, int i);
 
 // true: the int8 path is ready for blocks of width b.  false (FPCA_ACCUM_AUTO only): its extra buffers did not fit, the
 // context has been switched to the fp64 kernels for good.
@@ -320,8 +327,13 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
       HIP_CHECK(hipMemsetAsync(c->d_Qg + used * c->P_pad, 0, (nsc - used) * c->P_pad, s));
       HIP_CHECK(hipMemsetAsync(c->d_Qm + used * c->P_pad, 0, (nsc - used) * c->P_pad, s));
    }
-   const size_t need = std::max(kern::gemm_i8_workspace_doubles(c->P_pad, c->N_pad, c->i8_S, b, false),
-                                kern::gemm_i8_workspace_doubles(c->N_pad, c->P_pad, c->i8_S, b, true));
+   size_t need = std::max(kern::gemm_i8_workspace_doubles(c->P_pad, c->N_pad, c->i8_S, b, false),
+                          kern::gemm_i8_workspace_doubles(c->N_pad, c->P_pad, c->i8_S, b, true));
+   for (int nch = 2; nch <= 4; nch++) // K3 in row chunks (overlapped all-reduce): the plan of a chunk may use more planes
+      for (int i = 0; i < nch; i++) {
+         const uint64_t rows = ar_chunk_begin(c, nch, i + 1) - ar_chunk_begin(c, nch, i);
+         if (rows) need = std::max(need, kern::gemm_i8_workspace_doubles(rows, c->P_pad, c->i8_S, b, true));
+      }
    if (need > c->i8ws_cap) {
       if (c->d_i8ws) HIP_CHECK(hipFree(c->d_i8ws));
       c->d_i8ws = nullptr;
@@ -359,15 +371,39 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain)
                  c->N_pad, b, c->i8_S, chain ? ot : nullptr, s);
 }
 
-// Y = X T : slices of T/sd and mean T/sd (one pass over T) against the sample-major copy
-void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max)
+// Row chunks of Y for the overlapped all-reduce (built-in communicator only): the all-reduce of chunk i runs on the
+// communication stream while K3 computes chunk i + 1, so only the last chunk's all-reduce is exposed.  Chunks are whole
+// K3 row tiles.  Only for large N: measured on one GPU, two chunks cost +0.06 ms at N = 50k (each chunk is less than
+// one round of workgroups) -- about what they would hide there -- and +0.07 ms of 23 ms at N = 500k.
+// FPCA_AR_CHUNKS=n forces n (1 disables).
+int ar_chunks(const fpca_ctx *c)
+{
+   if (!c->comm || c->ar_fn || !c->comm_stream) return 1;
+   static const char *env = getenv("FPCA_AR_CHUNKS");
+   int n = c->N_pad >= 400000 ? 4 : c->N_pad >= 200000 ? 2 : 1;
+   if (env && atoi(env) >= 1) n = std::min(atoi(env), 4);
+   while (n > 1 && c->N_pad / n < 512) n--;
+   return n;
+}
+uint64_t ar_chunk_begin(const fpca_ctx *c, int nchunks, int i) // multiples of 512 rows
+{
+   const uint64_t per = round_up((c->N_pad + nchunks - 1) / nchunks, 512);
+   return std::min<uint64_t>(per * i, c->N_pad);
+}
+
+// Y = X T : slices of T/sd and mean T/sd (one pass over T) against the sample-major copy, rows [r0, r1) of Y
+void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_slice = true, uint64_t r0 = 0, uint64_t r1 = 0)
 {
    kern::SliceOp ot[2];
    i8_ops_t(c, ot);
-   if (!have_max) kern::i8_colmax(c->d_T, c->P_g, b, 2, ot, s);
-   kern::i8_slice(c->d_T, c->P_pad, c->P_g, b, c->i8_S, 2, ot, s);
-   kern::gemm_i8(c->d_packedT, c->pitchT, c->d_Qg, c->d_Qm, ot[0].colw, ot[1].colw, ot[1].colsum, nullptr, nullptr, dY, c->d_i8ws, c->N_pad,
-                 c->P_pad, b, c->i8_S, nullptr, s);
+   if (do_slice) {
+      if (!have_max) kern::i8_colmax(c->d_T, c->P_g, b, 2, ot, s);
+      kern::i8_slice(c->d_T, c->P_pad, c->P_g, b, c->i8_S, 2, ot, s);
+   }
+   if (r1 == 0) r1 = c->N_pad;
+   if (r1 <= r0) return;
+   kern::gemm_i8(c->d_packedT + r0 * c->pitchT, c->pitchT, c->d_Qg, c->d_Qm, ot[0].colw, ot[1].colw, ot[1].colsum, nullptr, nullptr,
+                 dY + r0 * b, c->d_i8ws, r1 - r0, c->P_pad, b, c->i8_S, nullptr, s);
 }
 
 // the operator on device-resident blocks: dY = X_g X_g' dB (+ all-reduce).  ev (optional): 4 events recorded
@@ -381,6 +417,22 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
       i8_zero_meta(c, s);
       xt_i8(c, dB, b, s, true);
       if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
+      const int nch = ar_chunks(c);
+      if (nch > 1) {
+         for (int i = 0; i < nch; i++) {
+            const uint64_t r0 = ar_chunk_begin(c, nch, i), r1 = ar_chunk_begin(c, nch, i + 1);
+            x_i8(c, b, dY, s, true, i == 0, r0, r1);
+            if (r1 <= r0) continue;
+            HIP_CHECK(hipEventRecord(c->ev_chunk[i], s));
+            HIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_chunk[i], 0));
+            RCCL_CHECK(rccl().AllReduce(dY + r0 * b, dY + r0 * b, (r1 - r0) * b, ncclDouble, ncclSum, c->comm, c->comm_stream));
+         }
+         if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
+         HIP_CHECK(hipEventRecord(c->ev_comm_done, c->comm_stream));
+         HIP_CHECK(hipStreamWaitEvent(s, c->ev_comm_done, 0));
+         if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
+         return;
+      }
       x_i8(c, b, dY, s, true);
       if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
       if (c->multi()) c->allreduce(dY, (uint64_t)c->N_pad * b, s);
@@ -935,6 +987,11 @@ int fpca_comm_init_rank(fpca_ctx *ctx, int nranks, int rank, const uint8_t id[FP
       RCCL_CHECK(rccl().CommInitRank(&ctx->comm, nranks, u, rank));
       ctx->nranks = nranks;
       ctx->rank = rank;
+      if (!ctx->comm_stream) {
+         HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+         for (hipEvent_t &e : ctx->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+         HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_comm_done, hipEventDisableTiming));
+      }
       // self-test: sum of (rank+1) over ranks must be n(n+1)/2 on every rank
       double v = rank + 1.0;
       HIP_CHECK(hipMemcpyAsync(ctx->d_small, &v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
