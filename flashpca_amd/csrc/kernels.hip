@@ -59,6 +59,45 @@ void fix_last_byte(uint8_t *packed, size_t pitch, uint64_t np, int valid_in_last
 }
 
 // ------------------------------------------------------------------------------------------------
+// records of np bytes, back to back (the .bed layout) -> pitched rows; one workgroup per record, byte granularity on the
+// source side (np is arbitrary), so this is only for the upload path (a 2-D host-to-device copy runs at ~18 GB/s, a 1-D
+// copy into a staging buffer at 57 GB/s, and this kernel at HBM speed)
+__global__ __launch_bounds__(256) void k_repitch(const uint8_t *__restrict__ src, uint64_t np, uint8_t *__restrict__ dst, size_t pitch)
+{
+   const uint8_t *s = src + (uint64_t)blockIdx.x * np;
+   uint8_t *d = dst + (uint64_t)blockIdx.x * pitch;
+   const uint64_t mis = (16 - ((uint64_t)s & 15)) & 15; // bytes before the first 16-byte boundary of the source
+   for (uint64_t i = threadIdx.x; i < mis && i < np; i += 256) d[i] = s[i];
+   if (np > mis) {
+      const uint64_t n16 = (np - mis) / 16;
+      // source aligned, destination not necessarily: 16-byte loads, byte-wise funnel is not worth it -- 4 x 4-byte stores
+      // when the destination offset is 4-byte aligned, else bytes
+      const uint4 *s16 = reinterpret_cast<const uint4 *>(s + mis);
+      uint8_t *dd = d + mis;
+      if ((((uint64_t)dd) & 3) == 0) {
+         for (uint64_t i = threadIdx.x; i < n16; i += 256) {
+            const uint4 v = s16[i];
+            uint32_t *o = reinterpret_cast<uint32_t *>(dd + i * 16);
+            o[0] = v.x;
+            o[1] = v.y;
+            o[2] = v.z;
+            o[3] = v.w;
+         }
+      } else {
+         for (uint64_t i = threadIdx.x; i < n16 * 16; i += 256) dd[i] = s[mis + i];
+      }
+      for (uint64_t i = mis + n16 * 16 + threadIdx.x; i < np; i += 256) d[i] = s[i];
+   }
+}
+
+void repitch(const uint8_t *src, uint64_t np, uint64_t nrec, uint8_t *dst, size_t pitch, hipStream_t stream)
+{
+   if (!nrec) return;
+   hipLaunchKernelGGL(k_repitch, dim3((unsigned)nrec), dim3(256), 0, stream, src, np, dst, pitch);
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1 bed_stats.  One workgroup per SNP record; 16-byte coalesced loads of the packed stream; the four
 // 2-bit codes are counted with popcount on the even/odd bit planes.  Padding bytes are "01" so they only
 // inflate the missing count, which is not used.  HBM-bound: reads pitch bytes per SNP once.

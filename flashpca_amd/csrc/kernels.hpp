@@ -10,6 +10,8 @@ namespace fpca {
 namespace kern {
 
 // rewrite the pad bits of the last valid byte of every record to the "missing" code (N % 4 != 0)
+// back-to-back records of np bytes -> rows of `pitch` bytes (upload path)
+void repitch(const uint8_t *src, uint64_t np, uint64_t nrec, uint8_t *dst, size_t pitch, hipStream_t stream);
 void fix_last_byte(uint8_t *packed, size_t pitch, uint64_t np, int valid_in_last, uint64_t P_g, hipStream_t stream);
 
 // K1: per-SNP code counts -> mean, sd, lookup table (by raw PLINK code), sum of squares
