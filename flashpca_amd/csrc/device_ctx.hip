@@ -711,7 +711,7 @@ namespace {
 bool parallel_pread(int fd, uint8_t *buf, uint64_t want, off_t off)
 {
    const unsigned hw = std::thread::hardware_concurrency();
-   static const int cap = getenv("FPCA_READ_THREADS") ? std::max(1, atoi(getenv("FPCA_READ_THREADS"))) : 8;
+   static const int cap = getenv("FPCA_READ_THREADS") ? std::max(1, atoi(getenv("FPCA_READ_THREADS"))) : 16;
    const int nt = want < (8u << 20) ? 1 : (int)std::min<unsigned>((unsigned)cap, hw ? hw : 1);
    std::atomic<bool> ok(true);
    auto work = [&](int t) {
