@@ -10,7 +10,8 @@
  * HapMap3/test_pca.R:121-246).  So this oracle is "parity unpinned" in the strict sense (no
  * reference-run outputs, no reference-held goldens); it IS pinned the way the reference's own tests
  * pin the reference: against an independent dense eigendecomposition of X X'/P on the reference's
- * bundled filesets (tests/golden/make_golden.py -> golden_*.json, tests/test_oracle_golden.py).
+ * bundled filesets (tests/golden/make_golden.py -> golden_*.json, tests/test_oracle_golden.py), and against the known
+ * answers printed in SURVEY.md 8(c) (a third, independent computation).
  *
  * Every function cites the reference file:line it follows (paths relative to the reference root).
  * All matrices are fp64 column-major, like the reference's Eigen::MatrixXd.

@@ -200,3 +200,21 @@ def test_config3_full_size_properties(fp):
         r8 = c8.pca(ndim=k)
         assert r8["info"]["converged"] == 1
         assert np.max(np.abs(r8["d"] - d64) / d64) < 1e-10
+
+
+@pytest.mark.parametrize("accum", ["auto", "fp64"])
+def test_product_reproduces_survey_known_answers(golden_dir, fp, accum):
+    """The known answers printed in SURVEY.md 8(c) (a third, independent computation): eigenvalues, trace, pve, and the
+    text the CLI would write at precision 7."""
+    from test_oracle_golden import SURVEY_KAT
+
+    for name, kat in SURVEY_KAT.items():
+        k = 50 if "eig50" in kat else 10
+        r = fp.flashpca(os.path.join(golden_dir, name), ndim=k, tol=1e-8, accum=accum)
+        n = len(kat["eig"])
+        assert np.max(np.abs(r["values"][:n] - kat["eig"]) / np.array(kat["eig"])) < 1e-10
+        if "eig50" in kat:
+            assert abs(r["values"][49] - kat["eig50"]) < 1e-10 * kat["eig50"]
+        if "pve1" in kat:
+            assert abs(r["pve"][0] - kat["pve1"]) < 1e-11
+            assert ["%.7g" % v for v in r["values"]] == kat["eigenvalues_txt"]

@@ -112,3 +112,46 @@ def test_edge_cases_monomorphic_missing_and_padding():
     assert X[1, 2] == 0.0  # sample 1 of SNP 2 is missing (code 01) -> imputed to the mean -> 0
     lut = d.lookup()
     assert lut[2, 1] == 0.0 and lut[2, 3] < lut[2, 2] < lut[2, 0]
+
+
+# Known answers printed in SURVEY.md section 8(c): computed by the surveyor's own throw-away numpy restatement, i.e. a
+# third implementation independent of both oracle/ and tests/golden/make_golden.py.
+SURVEY_KAT = {
+    "hapmap3_data": dict(
+        N=957, P=14389, code_counts={0: 2845704, 1: 21221, 2: 6131675, 3: 4771673}, snps_with_na=7823, monomorphic=0,
+        eig=[26.467988137205, 23.514010331154, 6.957985524321, 6.085561261752, 4.425828379855, 2.664165852825,
+             2.466606768219, 2.311790389987, 2.265891967763, 2.218548237411],
+        trace_over_p=990.429613283002, pve1=0.026723744709,
+        eigenvalues_txt=["26.46799", "23.51401", "6.957986", "6.085561", "4.425828", "2.664166", "2.466607", "2.31179",
+                         "2.265892", "2.218548"]),
+    "data_chr1": dict(N=957, P=1129, eig=[28.011938222135, 25.068103599102, 7.805220828638, 6.847117690206, 5.00003151225],
+                      eig50=2.877077388029, trace_over_p=987.2553072389829),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SURVEY_KAT))
+def test_oracle_reproduces_survey_known_answers(golden_dir, name):
+    kat = SURVEY_KAT[name]
+    d, g = _open(golden_dir, name, "binom2")
+    assert (d.N, d.P) == (kat["N"], kat["P"])
+    k = 50 if "eig50" in kat else 10
+    r = O.pca_fast(d, k)
+    n = len(kat["eig"])
+    assert np.max(np.abs(r["d"][:n] - kat["eig"]) / np.array(kat["eig"])) < 1e-10
+    assert abs(r["trace"] / 1.0 - kat["trace_over_p"]) < 1e-9 * kat["trace_over_p"]  # trace is already divided by P
+    if "eig50" in kat:
+        assert abs(r["d"][49] - kat["eig50"]) < 1e-10 * kat["eig50"]
+    if "pve1" in kat:
+        assert abs(r["pve"][0] - kat["pve1"]) < 1e-11
+        assert [O.format_number(v) for v in r["d"]] == kat["eigenvalues_txt"]
+    if "code_counts" in kat:
+        raw = np.fromfile(os.path.join(golden_dir, name + ".bed"), dtype=np.uint8)
+        assert raw[:3].tolist() == [0x6C, 0x1B, 0x01]
+        rec = raw[3:].reshape(d.P, -1)
+        codes = np.stack([(rec >> (2 * s)) & 3 for s in range(4)], axis=-1).reshape(d.P, -1)[:, :d.N]
+        assert {c: int((codes == c).sum()) for c in range(4)} == kat["code_counts"]
+        assert int(((codes == 1).sum(axis=1) > 0).sum()) == kat["snps_with_na"]
+        ms = d.meansd() if np.isfinite(d.meansd()).all() else None
+        d.dense()
+        sd = d.meansd()[:, 1]
+        assert int((~(sd > 1e-9)).sum()) == kat["monomorphic"]
