@@ -124,6 +124,10 @@ SURVEY_KAT = {
         trace_over_p=990.429613283002, pve1=0.026723744709,
         eigenvalues_txt=["26.46799", "23.51401", "6.957986", "6.085561", "4.425828", "2.664166", "2.466607", "2.31179",
                          "2.265892", "2.218548"]),
+    "hm3_thinned": dict(N=957, P=14079,
+                        eig=[26.160628146661, 23.393816760033, 6.915728456122, 6.049831829496, 4.402504579185, 2.651956041155,
+                             2.466051075037, 2.309857529632, 2.264242412552, 2.21310683549],
+                        trace_over_p=987.3561801334836),
     "data_chr1": dict(N=957, P=1129, eig=[28.011938222135, 25.068103599102, 7.805220828638, 6.847117690206, 5.00003151225],
                       eig50=2.877077388029, trace_over_p=987.2553072389829),
 }
@@ -132,7 +136,7 @@ SURVEY_KAT = {
 @pytest.mark.parametrize("name", sorted(SURVEY_KAT))
 def test_oracle_reproduces_survey_known_answers(golden_dir, name):
     kat = SURVEY_KAT[name]
-    d, g = _open(golden_dir, name, "binom2")
+    d = O.OracleData(os.path.join(golden_dir, name + ".bed"), O.count_fam_rows(os.path.join(golden_dir, name + ".fam")), "binom2")
     assert (d.N, d.P) == (kat["N"], kat["P"])
     k = 50 if "eig50" in kat else 10
     r = O.pca_fast(d, k)
