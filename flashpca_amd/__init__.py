@@ -5,6 +5,7 @@ The product is the C-ABI library flashpca_amd/_build/libfpca.so (include/fpca.h;
 by tests and bench.py.  There is no CPU fallback.
 """
 from ._lib import LIB_PATH, CLI_PATH, build, lib, FpcaError  # noqa: F401
-from .api import Context, flashpca, count_fam_rows  # noqa: F401
+from .api import Context, flashpca, project, count_fam_rows  # noqa: F401
+from .api import check_pca as check  # noqa: F401  (R: check())
 
 __version__ = "0.1.0"

@@ -242,3 +242,100 @@ def flashpca(X, ndim=10, stand="binom2", divisor="p", maxiter=500, tol=1e-6, do_
         res["center"] = r["meansd"][:, 0]
         res["scale"] = r["meansd"][:, 1]
     return res
+
+
+def _read_bim(prefix):
+    rows = [l.split() for l in open(prefix + ".bim").read().splitlines() if l.strip()]
+    return [r[1] for r in rows], [r[4] for r in rows]
+
+
+def project(X, loadings, orig_mean=None, orig_sd=None, ref_alleles=None, divisor="p", device=0, check_bim=True):
+    """Project samples onto existing principal components; mirrors project() of the reference's R package
+    (flashpcaR/R/project.R:56-163): same arguments, same input checks (raised as ValueError), same result
+    `{"projection": Z V / sqrt(div)}` with Z standardised by orig_mean / orig_sd and missing -> 0.
+
+    X: PLINK root name, or a numeric N x P matrix (NaN = missing).  ref_alleles: mapping SNP name -> reference allele in
+    .bim order (the R function's named character vector); required for the PLINK input unless check_bim=False.
+    """
+    if divisor not in DIVISOR:
+        raise ValueError("divisor must be one of %s" % sorted(DIVISOR))
+    if orig_mean is None:
+        raise ValueError("The vector of means used for standardising the data must be provided via 'orig_mean'")
+    if orig_sd is None:
+        raise ValueError("The vector of standard deviations used for standardising the data must be provided via 'orig_sd'")
+    loadings = np.asarray(loadings, dtype=np.float64)
+    orig_mean = np.asarray(orig_mean, dtype=np.float64).ravel()
+    orig_sd = np.asarray(orig_sd, dtype=np.float64).ravel()
+    if isinstance(X, str):
+        snp, ref = _read_bim(X)
+        p = len(snp)
+        if check_bim:
+            if loadings.ndim != 2 or loadings.shape[0] != p:
+                raise ValueError("The number of rows in %s.bim and the number of columns in the loadings don't match" % X)
+            if ref_alleles is None or list(ref_alleles.keys()) != snp:
+                raise ValueError("The SNP names in %s.bim do not match the names of the ref_alleles vector" % X)
+            if list(ref_alleles.values()) != ref:
+                raise ValueError("The reference alleles in %s.bim do not match the ref_alleles vector" % X)
+            if orig_mean.size != p:
+                raise ValueError("The number of rows in %s.bim and the length of orig_mean don't match" % X)
+            if orig_sd.size != p:
+                raise ValueError("The number of rows in %s.bim and the length of orig_sd don't match" % X)
+            if np.any(orig_sd <= 0):
+                raise ValueError("orig_sd cannot be zero or negative")
+        n = count_fam_rows(X + ".fam")
+        ctx = Context.from_bed(X + ".bed", n, device=device, accum="auto")
+        with ctx:
+            ctx.set_meansd(np.column_stack([orig_mean, orig_sd]))
+            Z = ctx.apply_x(np.asfortranarray(loadings))
+    else:
+        Xm = np.asarray(X, dtype=np.float64)
+        if loadings.ndim != 2 or loadings.shape[0] != Xm.shape[1]:
+            raise ValueError("The number of rows in X and number of columns of the loadings don't match")
+        if orig_mean.size != Xm.shape[1]:
+            raise ValueError("The number of rows in X and length of orig_mean don't match")
+        if orig_sd.size != Xm.shape[1]:
+            raise ValueError("The number of rows in X and length of orig_sd don't match")
+        if np.any(orig_sd <= 0):
+            raise ValueError("orig_sd cannot be zero or negative")
+        if np.isnan(Xm).any():
+            import warnings
+
+            warnings.warn("X contains missing values, will be mean imputed")
+        n = Xm.shape[0]
+        S = (Xm - orig_mean) / orig_sd  # R: scale(X, center, scale); the product itself runs on the GPU
+        S[np.isnan(S)] = 0.0
+        with Context.from_dense(S, stand="none", device=device) as ctx:
+            Z = ctx.apply_x(np.asfortranarray(loadings))
+    div_val = {"p": loadings.shape[0], "n1": n, "none": 1}[divisor]  # project.R:137-142 (as written there)
+    return dict(projection=Z / np.sqrt(div_val))
+
+
+def check_pca(X, evec, eval, stand="binom2", divisor="p", device=0, check_fam=True):  # noqa: A002 (R's argument name)
+    """Check the accuracy of an eigen-decomposition; mirrors check() of the reference's R package
+    (flashpcaR/R/check.R): err_j = || X X' u_j / div - d_j u_j ||^2, mse, rmse (RandomPCA::check, randompca.cpp:663-703)."""
+    if divisor not in DIVISOR:
+        raise ValueError("divisor must be one of %s" % sorted(DIVISOR))
+    evec = np.asarray(evec, dtype=np.float64)
+    evals = np.asarray(eval, dtype=np.float64).ravel()
+    if isinstance(X, str):
+        if stand not in STANDARDISE:
+            raise ValueError("When using PLINK data, you must use stand='binom' or 'binom2'")
+        n = count_fam_rows(X + ".fam")
+        if check_fam and n != evec.shape[0]:
+            raise ValueError("The number of rows in %s.fam and evec don't match" % X)
+        ctx = Context.from_bed(X + ".bed", n, stand=stand, device=device, accum="auto")
+    else:
+        Xm = np.asarray(X, dtype=np.float64)
+        if stand not in _lib.STANDARDISE_DENSE:
+            raise ValueError("stand must be one of %s" % sorted(_lib.STANDARDISE_DENSE))
+        if stand in ("binom", "binom2") and not np.all(np.isin(Xm[~np.isnan(Xm)], (0.0, 1.0, 2.0))):
+            raise ValueError("Your data contains values other than {0, 1, 2}, stand='binom'/'binom2' can't be used here")
+        if evec.shape[0] != Xm.shape[0]:
+            raise ValueError("The number of rows in X and evec don't match")
+        ctx = Context.from_dense(Xm, stand=stand, device=device)
+    if evec.ndim != 2 or evec.shape[1] != evals.size:
+        ctx.close()
+        raise ValueError("The number of columns of evec doesn't match the number of eigenvalues eval")
+    with ctx:
+        err, mse, rmse = ctx.check(evec, evals, div=divisor)
+    return dict(err=err, mse=mse, rmse=rmse)
