@@ -99,3 +99,48 @@ def test_projection_input_checking(fp):  # test_project.R:49-95
     osd[0], osd[1] = 0, -1
     with pytest.raises(ValueError):
         fp.project(BEDF, loadings=f["loadings"], ref_alleles=ref, orig_mean=c1, orig_sd=osd)
+
+
+def test_standardisation_and_mean_imputation(fp):  # test_standardisation.R:4-87
+    """standardise_impute(X, method) is the matrix the dense path holds after fpca_create_dense; it is read back as X_std I."""
+    n, m = 50, 10
+    rng = np.random.default_rng(3)
+    X = rng.binomial(2, 0.3, size=(n, m)).astype(float)
+
+    def standardise_impute(A, stand):
+        with fp.Context.from_dense(A, stand=stand) as c:
+            return c.apply_x(np.eye(m))
+
+    def r_scale(A, center=True, scale=True):
+        mu = np.nanmean(A, axis=0) if center else np.zeros(m)
+        sd = np.nanstd(A, axis=0, ddof=1) if scale else np.ones(m)
+        return (A - mu) / sd
+
+    tol = 1.5e-8  # expect_equal
+    assert np.allclose(standardise_impute(X, "none"), X, atol=tol)
+    s2 = standardise_impute(X, "sd")
+    assert np.allclose(s2.mean(axis=0), 0, atol=tol) and np.allclose(s2.std(axis=0, ddof=1), 1, atol=tol)
+    for stand, t in (("binom", "1"), ("binom2", "2")):
+        s = standardise_impute(X, stand)
+        assert np.allclose(s.mean(axis=0), 0, atol=tol)
+        assert np.allclose(s, scale2(X, t)[0], atol=tol)
+    assert np.allclose(standardise_impute(X, "center"), r_scale(X, True, False), atol=tol)
+    # missing values: imputed to the column mean
+    X2 = X.copy()
+    X2[np.arange(m), np.arange(m)] = np.nan
+    xmean = np.nanmean(X2, axis=0)
+    s7 = standardise_impute(X2, "none")
+    assert np.allclose(xmean, np.diag(s7[:m]), atol=tol) and np.allclose(xmean, s7.mean(axis=0), atol=tol)
+    assert not np.isnan(s7).any()
+    e = r_scale(X2)
+    e[np.isnan(e)] = 0
+    s8 = standardise_impute(X2, "sd")
+    assert np.allclose(s8.mean(axis=0), 0, atol=tol) and np.allclose(s8, e, atol=tol)
+    for stand, t in (("binom", "1"), ("binom2", "2")):
+        s = standardise_impute(X2, stand)
+        assert np.allclose(s.mean(axis=0), 0, atol=tol)
+        assert np.allclose(s, scale2(X2, t)[0], atol=tol)
+    e = r_scale(X2, True, False)
+    e[np.isnan(e)] = 0
+    s10 = standardise_impute(X2, "center")
+    assert np.allclose(s10.mean(axis=0), 0, atol=tol) and np.allclose(s10, e, atol=tol)
