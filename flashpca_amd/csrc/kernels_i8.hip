@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -501,43 +502,50 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
                              : part + (size_t)zb * rows_pad * 2 * bw +
                                   ((((size_t)(split - 1) * zb + zblk) * rowsB + (row0 - rowB0) + wr * 32 * MT) * 2) * bw) +
                  li;
-   auto epilogue = [&](auto kbc) {
-      constexpr int KB = decltype(kbc)::value; // bw / 32: a lane's tiles n, n + KB, ... feed the same virtual column
-      double wgl[NT], wml[NT];
+   //
+   // Register discipline: the 256 accumulators own every AGPR, and reading ONE element of an AGPR-resident 16-vector makes
+   // the compiler copy the whole vector to VGPRs, so any epilogue that walks rows across tiles keeps hundreds of extra
+   // VGPRs alive and the allocator answers by spilling INSIDE the main loop (measured: 10 scratch stores per chunk,
+   // 3.5 GB of spill traffic per launch, matrix pipe 48 % busy).  So the tiles are dumped to LDS one at a time (the operand
+   // tiles are dead by now; 4 KB per tile and wave) and the recombination runs from LDS with a handful of registers.
+   __syncthreads(); // every wave has finished reading the operand tiles
+   constexpr int WREG = NT * 4096; // bytes of a wave's private tile area: [NT][32 rows][32 cols] int32
+   double *sW = reinterpret_cast<double *>(smem + 4 * WREG); // weights of this workgroup's slice-columns: [2][COLS]
+   for (int t = tid; t < C::COLS; t += 256) {
+      sW[t] = wg[col0 + t];
+      sW[C::COLS + t] = wm[col0 + t];
+   }
+   __syncthreads();
+   static_assert(2 * C::STAGE >= 4 * WREG + 2 * C::COLS * 8, "epilogue LDS layout");
+   int *sT = reinterpret_cast<int *>(smem + wave * WREG);
+   const double *sWl = sW + wc * 32 * NT + li;
+   const int kb = bw / 32; // a lane's tiles n, n + kb, ... feed the same virtual column 32 ((tile0 + n) % kb) + li
 #pragma unroll
-      for (int n = 0; n < NT; n++) {
-         wgl[n] = wg[(tile0 + n) * 32 + li];
-         wml[n] = wm[(tile0 + n) * 32 + li];
-      }
-      int joff[KB];
+   for (int a = 0; a < 2; a++)
 #pragma unroll
-      for (int k = 0; k < KB; k++) joff[k] = 32 * ((tile0 + k) % KB);
+      for (int m = 0; m < MT; m++) {
 #pragma unroll
-      for (int m = 0; m < MT; m++)
+         for (int n = 0; n < NT; n++) {
+            const v16i v = acc[a][m][n];
 #pragma unroll
-         for (int r = 0; r < 16; r++) {
-            const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            double bg[KB], bm[KB];
-#pragma unroll
-            for (int k = 0; k < KB; k++) bg[k] = bm[k] = 0.0;
-#pragma unroll
-            for (int n = NT - 1; n >= 0; n--) {
-               bg[n % KB] += wgl[n] * (double)acc[0][m][n][r];
-               bm[n % KB] += wml[n] * (double)acc[1][m][n][r];
-            }
-#pragma unroll
-            for (int k = 0; k < KB; k++) {
-               out[((size_t)row * 2 + 0) * bw + joff[k]] = bg[k];
-               out[((size_t)row * 2 + 1) * bw + joff[k]] = bm[k];
+            for (int r = 0; r < 16; r++) sT[(n * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + li] = v[r];
+            __builtin_amdgcn_sched_barrier(0);
+         }
+         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+         __builtin_amdgcn_wave_barrier();
+         // lane (li, kh) recombines rows 16 kh .. 16 kh + 15 of column li
+         for (int j = 0; j < 16; j++) {
+            const int row = 16 * kh + j;
+            for (int k = 0; k < kb; k++) {
+               double acc64 = 0.0;
+               for (int n = NT - 1 - ((NT - 1 - k) % kb); n >= 0; n -= kb) // tiles n == k (mod kb), last slice first
+                  acc64 += sWl[a * C::COLS + 32 * n] * (double)sT[(n * 32 + row) * 32 + li];
+               out[((size_t)(32 * m + row) * 2 + a) * bw + 32 * ((tile0 + k) % kb)] = acc64;
             }
          }
-   };
-   if (bw == 32)
-      epilogue(std::integral_constant<int, 1>{});
-   else if (bw == 64)
-      epilogue(std::integral_constant<int, 2>{});
-   else
-      epilogue(std::integral_constant<int, 3>{});
+         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+         __builtin_amdgcn_wave_barrier();
+      }
 }
 
 // sum of the per-split / per-column-block fp64 partials, fold of the virtual columns (j == c mod b), M'Q = 1'Q - E'Q,
@@ -688,6 +696,11 @@ static I8Plan i8_plan(uint64_t rows_pad, uint64_t k_pad, const I8Shape &sh, int 
    p.rowB0 = std::min<uint64_t>((uint64_t)qA * 8 * sh.rows, rows_pad);
    p.rowsB = rows_pad - p.rowB0;
    p.grid = (unsigned)(p.nA + (ids - p.nA) * p.sB);
+   static const bool verbose = getenv("FPCA_I8_VERBOSE") != nullptr;
+   if (verbose)
+      std::fprintf(stderr, "[fpca] int8 GEMM plan: rows %llu K %llu tile %dx%d zb %d -> %d tile ids, %d chunks; %d unsplit + %d tiles x %d splits (%d chunks each), %u workgroups, est %.3f ms\n",
+                   (unsigned long long)rows_pad, (unsigned long long)k_pad, sh.rows, sh.cols, sh.zb, ids, chunks, p.nA, ids - p.nA, p.sB, p.cpsB, p.grid,
+                   best * 1e3);
    return p;
 }
 
