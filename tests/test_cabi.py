@@ -80,3 +80,25 @@ def test_default_opts_match_reference_cli(built_lib):
     fp.lib().fpca_pca_default_opts(C.byref(o))
     # flashpca.cpp:325 (ndim 10), :426 (maxiter 500), :440 (tol 1e-6), :484 (div p), :276 (seed 1)
     assert (o.ndim, o.maxiter, o.tol, o.divisor, o.seed) == (10, 500, 1e-6, 2, 1)
+
+
+def test_gemm_kernels_do_not_spill():
+    """Register discipline of the hot kernels: every GEMM kernel must compile without VGPR spills -- a
+    spill inside the main loop once cost 15 % while every parity test stayed green."""
+    import re
+    import subprocess
+    import tempfile
+
+    csrc = os.path.join(ROOT, "flashpca_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        for src, pat in (("kernels_i8.hip", "k_gemm_i8"), ("kernels.hip", "k_xt_b|k_x_t")):
+            out = os.path.join(tmp, src + ".s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                                   os.path.join(csrc, src), "-o", out], stderr=subprocess.DEVNULL)
+            txt = open(out).read()
+            names = re.findall(r"\.name:\s+(\S+)", txt)
+            spills = re.findall(r"\.vgpr_spill_count:\s+(\d+)", txt)
+            assert len(names) == len(spills) and names
+            hot = [(n, int(s)) for n, s in zip(names, spills) if re.search(pat, n)]
+            assert hot, src
+            assert all(s == 0 for _, s in hot), [(n, s) for n, s in hot if s]
