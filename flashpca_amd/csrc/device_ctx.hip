@@ -93,6 +93,8 @@ struct fpca_ctx {
    bool dense = false;
    double *d_lut = nullptr, *d_mean = nullptr, *d_sd = nullptr, *d_sumsq = nullptr;
    bool stats_done = false;
+   bool missing_known = false; // n_missing counted by K1 (not when mean/sd were preloaded)
+   uint64_t n_missing = 0;     // missing calls in this shard
    double trace_local = 0;
    // workspaces (grown on demand)
    double *d_T = nullptr;
@@ -238,10 +240,18 @@ void ensure_stats(fpca_ctx *c)
 {
    if (c->stats_done) return;
    HIP_CHECK(hipSetDevice(c->device));
-   kern::bed_stats(c->d_packed, c->pitch, c->N, c->P_g, c->stand, c->d_lut, c->d_mean, c->d_sd, c->d_sumsq, c->stream);
+   uint32_t *d_nmiss = nullptr;
+   std::vector<uint32_t> nm(c->P_g);
+   if (c->P_g) HIP_CHECK(hipMalloc(&d_nmiss, c->P_g * sizeof(uint32_t)));
+   kern::bed_stats(c->d_packed, c->pitch, c->N, c->P_g, c->stand, c->d_lut, c->d_mean, c->d_sd, c->d_sumsq, d_nmiss, c->stream);
    std::vector<double> ss(c->P_g);
    HIP_CHECK(hipMemcpyAsync(ss.data(), c->d_sumsq, c->P_g * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+   if (c->P_g) HIP_CHECK(hipMemcpyAsync(nm.data(), d_nmiss, c->P_g * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
    HIP_CHECK(hipStreamSynchronize(c->stream));
+   if (d_nmiss) (void)hipFree(d_nmiss);
+   c->n_missing = 0;
+   for (uint32_t v : nm) c->n_missing += v;
+   c->missing_known = true;
    // pairwise-ish (blocked) summation for a reproducible, accurate trace
    double tot = 0;
    for (size_t i0 = 0; i0 < ss.size(); i0 += 1024) {
@@ -330,11 +340,14 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
       HIP_CHECK(hipMemsetAsync(c->d_Qm + used * c->P_pad, 0, (nsc - used) * c->P_pad, s));
    }
    size_t need = std::max(kern::gemm_i8_workspace_doubles(c->P_pad, c->N_pad, c->i8_S, b, false),
-                          kern::gemm_i8_workspace_doubles(c->N_pad, c->P_pad, c->i8_S, b, true));
+                          std::max(kern::gemm_i8_workspace_doubles(c->N_pad, c->P_pad, c->i8_S, b, true),
+                                   kern::gemm_i8_workspace_doubles(c->N_pad, c->P_pad, c->i8_S, b, false)));
    for (int nch = 2; nch <= 4; nch++) // K3 in row chunks (overlapped all-reduce): the plan of a chunk may use more planes
       for (int i = 0; i < nch; i++) {
          const uint64_t rows = ar_chunk_begin(c, nch, i + 1) - ar_chunk_begin(c, nch, i);
-         if (rows) need = std::max(need, kern::gemm_i8_workspace_doubles(rows, c->P_pad, c->i8_S, b, true));
+         if (rows)
+            need = std::max(need, std::max(kern::gemm_i8_workspace_doubles(rows, c->P_pad, c->i8_S, b, true),
+                                           kern::gemm_i8_workspace_doubles(rows, c->P_pad, c->i8_S, b, false)));
       }
    if (need > c->i8ws_cap) {
       if (c->d_i8ws) HIP_CHECK(hipFree(c->d_i8ws));
@@ -343,6 +356,17 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
       HIP_CHECK(hipMalloc(&c->d_i8ws, need * sizeof(double)));
       c->i8ws_cap = need;
    }
+}
+
+// how the int8 GEMMs treat the missing-indicator matrix (kernels_i8.hip: I8_FULL / I8_SKIP_EMPTY / I8_NO_MISSING)
+int i8_mode(const fpca_ctx *c)
+{
+   static const char *env = getenv("FPCA_I8_MODE"); // 0 / 1 / 2: force (tests; 2 is wrong unless nothing is missing)
+   if (env) return atoi(env);
+   if (!c->missing_known) return 0;
+   if (c->n_missing == 0) return 2;
+   const double rate = (double)c->n_missing / ((double)c->N * (double)std::max<uint64_t>(c->P_g, 1));
+   return rate < 3e-4 ? 1 : 0; // break-even of the block-skipping variant, measured at N x P = 500k x 100k
 }
 
 kern::SliceOp i8_op_b(fpca_ctx *c)
@@ -370,7 +394,7 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain)
    kern::i8_colmax(dB, c->N, b, 1, &ob, s);
    kern::i8_slice(dB, c->N_pad, c->N, b, c->i8_S, 1, &ob, s);
    kern::gemm_i8(c->d_packed, c->pitch, c->d_Qb, c->d_Qb, ob.colw, ob.colw, ob.colsum, c->d_mean, c->d_sd, c->d_T, c->d_i8ws, c->P_pad,
-                 c->N_pad, b, c->i8_S, chain ? ot : nullptr, s);
+                 c->N_pad, c->P_g, i8_mode(c), b, c->i8_S, chain ? ot : nullptr, s);
 }
 
 // Row chunks of Y for the overlapped all-reduce (built-in communicator only): the all-reduce of chunk i runs on the
@@ -404,8 +428,11 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_
    }
    if (r1 == 0) r1 = c->N_pad;
    if (r1 <= r0) return;
-   kern::gemm_i8(c->d_packedT + r0 * c->pitchT, c->pitchT, c->d_Qg, c->d_Qm, ot[0].colw, ot[1].colw, ot[1].colsum, nullptr, nullptr,
-                 dY + r0 * b, c->d_i8ws, r1 - r0, c->P_pad, b, c->i8_S, nullptr, s);
+   const int mode = i8_mode(c);
+   // without missing genotypes only G.M is multiplied: one operand (Qm is still sliced: its column sums are 1'Qm = M'Qm)
+   kern::gemm_i8(c->d_packedT + r0 * c->pitchT, c->pitchT, c->d_Qg, mode == 2 ? c->d_Qg : c->d_Qm, ot[0].colw, ot[1].colw, ot[1].colsum,
+                 nullptr, nullptr, dY + r0 * b, c->d_i8ws, r1 - r0, c->P_pad, c->N > r0 ? std::min(c->N - r0, r1 - r0) : 0, mode, b, c->i8_S,
+                 nullptr, s);
 }
 
 // the operator on device-resident blocks: dY = X_g X_g' dB (+ all-reduce).  ev (optional): 4 events recorded
@@ -1242,10 +1269,10 @@ int fpca_bench_stats(fpca_ctx *ctx, int reps, double *ms_per_launch, double *byt
       hipEvent_t e0, e1;
       HIP_CHECK(hipEventCreate(&e0));
       HIP_CHECK(hipEventCreate(&e1));
-      kern::bed_stats(ctx->d_packed, ctx->pitch, ctx->N, ctx->P_g, ctx->stand, ctx->d_lut, ctx->d_mean, ctx->d_sd, ctx->d_sumsq, ctx->stream);
+      kern::bed_stats(ctx->d_packed, ctx->pitch, ctx->N, ctx->P_g, ctx->stand, ctx->d_lut, ctx->d_mean, ctx->d_sd, ctx->d_sumsq, nullptr, ctx->stream);
       HIP_CHECK(hipEventRecord(e0, ctx->stream));
       for (int i = 0; i < reps; i++)
-         kern::bed_stats(ctx->d_packed, ctx->pitch, ctx->N, ctx->P_g, ctx->stand, ctx->d_lut, ctx->d_mean, ctx->d_sd, ctx->d_sumsq, ctx->stream);
+         kern::bed_stats(ctx->d_packed, ctx->pitch, ctx->N, ctx->P_g, ctx->stand, ctx->d_lut, ctx->d_mean, ctx->d_sd, ctx->d_sumsq, nullptr, ctx->stream);
       HIP_CHECK(hipEventRecord(e1, ctx->stream));
       HIP_CHECK(hipEventSynchronize(e1));
       float ms = 0;

@@ -124,9 +124,10 @@ __device__ __forceinline__ void make_lut(double mean, double sd, double *lut4)
    lut4[3] = v3;
 }
 
-__global__ __launch_bounds__(256) void k_bed_stats(const uint8_t *__restrict__ packed, size_t pitch, int stand_method,
+__global__ __launch_bounds__(256) void k_bed_stats(const uint8_t *__restrict__ packed, size_t pitch, uint64_t N, int stand_method,
                                                     double *__restrict__ lut, double *__restrict__ mean_out,
-                                                    double *__restrict__ sd_out, double *__restrict__ sumsq_out)
+                                                    double *__restrict__ sd_out, double *__restrict__ sumsq_out,
+                                                    uint32_t *__restrict__ nmiss_out)
 {
    const uint64_t snp = blockIdx.x;
    const uint4 *row = reinterpret_cast<const uint4 *>(packed + snp * pitch);
@@ -179,18 +180,18 @@ __global__ __launch_bounds__(256) void k_bed_stats(const uint8_t *__restrict__ p
       lp[3] = l[3];
       mean_out[snp] = mean;
       sd_out[snp] = sd;
+      if (nmiss_out) nmiss_out[snp] = (uint32_t)(n01 - (cells - N)); // missing calls among the N samples (padding is "01" too)
       // sum_i X_ij^2 in closed form from the counts (svdwide.cpp:44-45 sums the dense block)
       sumsq_out[snp] = (double)n00 * l[0] * l[0] + (double)n10 * l[2] * l[2] + (double)n11 * l[3] * l[3];
    }
 }
 
 void bed_stats(const uint8_t *packed, size_t pitch, uint64_t N, uint64_t P_g, int stand_method, double *lut,
-               double *mean, double *sd, double *sumsq, hipStream_t stream)
+               double *mean, double *sd, double *sumsq, uint32_t *nmiss, hipStream_t stream)
 {
-   (void)N;
    if (P_g == 0) return;
-   hipLaunchKernelGGL(k_bed_stats, dim3((unsigned)P_g), dim3(256), 0, stream, packed, pitch, stand_method, lut, mean,
-                      sd, sumsq);
+   hipLaunchKernelGGL(k_bed_stats, dim3((unsigned)P_g), dim3(256), 0, stream, packed, pitch, N, stand_method, lut, mean,
+                      sd, sumsq, nmiss);
    HIP_CHECK_LAUNCH();
 }
 

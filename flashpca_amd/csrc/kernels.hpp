@@ -17,7 +17,7 @@ void fix_last_byte(uint8_t *packed, size_t pitch, uint64_t np, int valid_in_last
 // K1: per-SNP code counts -> mean, sd, lookup table (by raw PLINK code), sum of squares
 //   lut [P_pad][4], mean/sd/sumsq [P_pad]; rows >= P_g untouched (must be pre-zeroed)
 void bed_stats(const uint8_t *packed, size_t pitch, uint64_t N, uint64_t P_g, int stand_method, double *lut,
-               double *mean, double *sd, double *sumsq, hipStream_t stream);
+               double *mean, double *sd, double *sumsq, uint32_t *nmiss /* per-SNP missing calls, or null */, hipStream_t stream);
 // lookup table from preloaded mean/sd (projection path, data.cpp:293-320)
 void lut_from_meansd(const double *mean, const double *sd, uint64_t P_g, double *lut, hipStream_t stream);
 
@@ -97,6 +97,7 @@ size_t gemm_i8_workspace_doubles(uint64_t rows_pad, uint64_t k_pad, int S, int b
 // out[rows_pad][b] = recombined ( (G.M) Qg' , M Qm' ); mean/sd non-null: K2 flavour (per-row standardisation)
 void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, const double *wg, const double *wm,
              const long long *colsum_m, const double *mean, const double *sd, double *out, double *ws, uint64_t rows_pad, uint64_t k_pad,
+             uint64_t rows_valid, int mode /* 0 full, 1 skip E blocks without a missing genotype, 2 shard without missing genotypes */,
              int b, int S, const SliceOp *next_ops, hipStream_t stream);
 void i8_rowscales(const double *mean, const double *sd, uint64_t P_g, uint64_t P_pad, double *inv_sd, double *mu_inv_sd,
                   hipStream_t stream);

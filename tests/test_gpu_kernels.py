@@ -344,3 +344,43 @@ def test_overlapped_allreduce_row_chunks(fp, monkeypatch, nch):
             assert np.max(np.abs(Z - Z0)) <= 1e-13 * np.max(np.abs(Z0))
         r = c.pca(ndim=5)
         assert r["info"]["converged"] == 1
+
+
+@pytest.mark.parametrize("N,P,b", [(3001, 1999, 32), (2050, 700, 64), (517, 300, 16)])
+def test_i8_shard_without_missing_genotypes(N, P, b, fp, orc):
+    """No missing call in the shard (imputed / 1000-Genomes-like data): E = 0, only G.M is multiplied and M'Q = 1'Q comes
+    from the column sums; the padding rows / samples (all "missing") must still come out exactly zero."""
+    rng = np.random.default_rng(N)
+    with fp.Context.synthetic(N, P, n_pop=6, missing_rate=0.0, accum="i8") as c:
+        packed = c.download_packed().reshape(P, -1)
+        od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+        X = od.dense()
+        codes = np.stack([(packed >> (2 * s)) & 3 for s in range(4)], axis=-1).reshape(P, -1)[:, :N]
+        assert not (codes == 1).any()
+        B = rng.standard_normal((N, b))
+        T_ref = X.T @ B
+        assert np.max(np.abs(c.apply_xt(B) - T_ref) / np.max(np.abs(T_ref), axis=0)) <= 1e-11
+        Tin = rng.standard_normal((P, b))
+        Y_ref = X @ Tin
+        assert np.max(np.abs(c.apply_x(Tin) - Y_ref) / np.max(np.abs(Y_ref), axis=0)) <= 1e-11
+        Z_ref = X @ T_ref
+        assert np.max(np.abs(c.apply_xxt(B) - Z_ref) / np.max(np.abs(Z_ref), axis=0)) <= 1e-11
+        r = c.pca(ndim=5)
+        w = np.linalg.eigvalsh(X @ X.T)[::-1][:5] / P
+        assert np.max(np.abs(r["d"] - w) / w) < 1e-8
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_i8_forced_missing_modes(golden_dir, fp, orc, monkeypatch, mode):
+    """I8_FULL and I8_SKIP_EMPTY (blocks of the missing indicator without a missing genotype are skipped) give the same
+    operator on data WITH missing calls, whatever the automatic choice would be."""
+    monkeypatch.setenv("FPCA_I8_MODE", mode)
+    N = fp.count_fam_rows(os.path.join(golden_dir, "hapmap3_data.fam"))
+    bed = os.path.join(golden_dir, "hapmap3_data.bed")
+    ctx = fp.Context.from_bed(bed, N, accum="i8")
+    od = orc.OracleData(bed, N, "binom2")
+    X = od.dense()
+    B = np.random.default_rng(3).standard_normal((N, 32))
+    Z_ref = X @ (X.T @ B)
+    assert np.max(np.abs(ctx.apply_xxt(B) - Z_ref) / np.max(np.abs(Z_ref), axis=0)) <= 1e-11
+    ctx.close()
