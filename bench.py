@@ -215,7 +215,7 @@ def main():
                                "agrees with the f64 kernels to ~3e-15, see fp64_mode)"),
                data="synthetic",
                config=dict(workload=args.workload + ": " + w["desc"], samples=N, snps_total=P_total, snps_per_gpu=P_rank,
-                           k=k, blockvec=b, parallelism="snp-shard x%d + all-reduce(N x b) [%s]" % (world, transport),
+                           k=k, blockvec=b, missing_call_rate=0.001, parallelism="snp-shard x%d + all-reduce(N x b) [%s]" % (world, transport),
                            iters_per_step=b, generate_s=round(t_gen, 3)),
                roofline=roofline)
 

@@ -295,7 +295,7 @@ struct I8Cfg {
    static constexpr int MT = MT_, NT = NT_, WR = WR_, WC = WC_, KC = KC_, G = G_, NQ = TWO ? 2 : 1, MODE = MODE_;
    static constexpr int MATS = MODE == I8_NO_MISSING ? 1 : 2;
    static_assert(!(TWO && MATS == 1), "without E there is only one operand");
-   static_assert(WR * WC == 4 && 2 * MT * NT <= 16 && (MT == 1 || G == 1) && G <= NT, "shape");
+   static_assert(WR * WC == 4 && MATS * MT * NT <= 16 && (MT == 1 || G == 1) && G <= NT, "shape");
    static constexpr int ROWS = WR * MT * 32;            // workgroup rows
    static constexpr int COLS = WC * NT * 32;            // workgroup columns of each operand
    static constexpr int LDQ = KC + 16;                  // operand tile row stride (bytes)
@@ -653,13 +653,14 @@ struct I8Shape {
    int nt, zb, rows, cols, kc;
 };
 
-static I8Shape i8_shape(int S, int b, bool two)
+static I8Shape i8_shape(int S, int b, bool two, int mode = I8_FULL)
 {
    const int tiles = (S * b + 31) / 32, cap = two ? 4 : 8, lo = two ? 3 : 4; // largest / smallest instantiated block
    I8Shape sh;
    sh.zb = (tiles + cap - 1) / cap;
    sh.nt = std::max(lo, (tiles + sh.zb - 1) / sh.zb);
-   sh.rows = two ? 256 : 128;
+   // one matrix only (I8_NO_MISSING): the freed accumulators go into a second row tile per wave (64 rows x NT tiles)
+   sh.rows = (two || mode == I8_NO_MISSING) ? 256 : 128;
    sh.cols = 32 * sh.nt;
    sh.kc = 256;
    return sh;
@@ -742,9 +743,14 @@ static int i8_bw(int b) // lcm(32, b) for b in {16, 32, 48, 64}
 
 size_t gemm_i8_workspace_doubles(uint64_t rows_pad, uint64_t k_pad, int S, int b, bool two)
 {
-   const I8Shape sh = i8_shape(S, b, two);
-   const I8Plan p = i8_plan(rows_pad, k_pad, sh, i8_bw(b));
-   return ((size_t)rows_pad + (size_t)(p.sB - 1) * p.rowsB) * sh.zb * 2 * (size_t)i8_bw(b);
+   size_t need = 0;
+   for (int mode : {(int)I8_FULL, (int)I8_NO_MISSING}) {
+      if (two && mode == I8_NO_MISSING) continue;
+      const I8Shape sh = i8_shape(S, b, two, mode);
+      const I8Plan p = i8_plan(rows_pad, k_pad, sh, i8_bw(b));
+      need = std::max(need, ((size_t)rows_pad + (size_t)(p.sB - 1) * p.rowsB) * sh.zb * 2 * (size_t)i8_bw(b));
+   }
+   return need;
 }
 
 template <class C>
@@ -766,14 +772,14 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
              const SliceOp *next_ops /* null, or the two operands whose column maxima the combine should leave */, hipStream_t stream)
 {
    const bool two = (Qg != Qm);
-   const I8Shape sh = i8_shape(S, b, two);
+   const I8Shape sh = i8_shape(S, b, two, mode);
    const int bw = i8_bw(b); // Q holds gemm_i8_nsc_pad(S, b) rows; rows >= S*b are zero and carry zero weights
    const I8Plan pl = i8_plan(rows_pad, k_pad, sh, bw);
    const int chunks_total = (int)(k_pad / sh.kc);
 #define FPCA_I8_ARGS pl, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws, rows_pad, chunks_total, sh.zb
    if (two && mode == I8_NO_MISSING) throw Error(-1, "gemm_i8: without missing genotypes both matrices share one operand (pass Qm == Qg)");
 #define FPCA_I8_K3(NT_, MODE_) launch_i8<I8Cfg<true, 2, NT_, 4, 1, 256, 1, MODE_>>(FPCA_I8_ARGS)
-#define FPCA_I8_K2(NT_, MODE_) launch_i8<I8Cfg<false, 1, NT_, 4, 1, 256, 2, MODE_>>(FPCA_I8_ARGS)
+#define FPCA_I8_K2(NT_, MODE_) launch_i8<I8Cfg<false, (MODE_ == I8_NO_MISSING ? 2 : 1), NT_, 4, 1, 256, (MODE_ == I8_NO_MISSING ? 1 : 2), MODE_>>(FPCA_I8_ARGS)
 #define FPCA_I8_K2_NT(MODE_)                                                                                 \
    switch (sh.nt) {                                                                                           \
    case 4: FPCA_I8_K2(4, MODE_); break;                                                                       \
