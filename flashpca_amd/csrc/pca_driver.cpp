@@ -3,6 +3,9 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -38,6 +41,14 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
    so.seed = o.seed ? o.seed : 1;
    so.verbose = o.verbose;
    SolverResult r = block_krylov_schur(be, so);
+   const bool timing = std::getenv("FPCA_TIMING") != nullptr;
+   auto lap = [&, last = std::chrono::steady_clock::now()](const char *what) mutable {
+      const auto now = std::chrono::steady_clock::now();
+      if (timing) std::fprintf(stderr, "[fpca] %-28s %8.3f ms\n", what, std::chrono::duration<double>(now - last).count() * 1e3);
+      last = now;
+   };
+   if (timing) std::fprintf(stderr, "[fpca] %-28s %8.3f ms\n", "solver", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
+   lap("-");
 
    double div = 1; // randompca.cpp:180-184
    if (o.divisor == FPCA_DIVISOR_N1)
@@ -59,12 +70,27 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
          tmp.resize((size_t)N * k);
          U = tmp.data();
       }
+      lap("trace, eigenvalues");
       be.download(r.ritz_block, k, U, (int64_t)N);
-      if (out.Px)
-         for (int j = 0; j < k; j++) { // :207  Px = U diag(sqrt(d))
+      lap("download U");
+      if (out.Px) { // :207  Px = U diag(sqrt(d)); a memory-bound N x k pass, one column per thread when it is big
+         auto column = [&](int j) {
             const double sq = std::sqrt(d[j]);
             for (uint64_t i = 0; i < N; i++) out.Px[i + (size_t)j * N] = U[i + (size_t)j * N] * sq;
+         };
+         if ((uint64_t)N * k < (1u << 20)) {
+            for (int j = 0; j < k; j++) column(j);
+         } else {
+            const int nt = std::min(k, 8);
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++)
+               th.emplace_back([&, t] {
+                  for (int j = t; j < k; j += nt) column(j);
+               });
+            for (auto &x : th) x.join();
          }
+      }
+      lap("Px = U sqrt(d)");
    }
    if (ritz_block)
       *ritz_block = r.ritz_block;
