@@ -183,8 +183,12 @@ def main():
                     packed_gbs=((N + 3) // 4) * P_rank / (ms_dom * 1e-3) / 1e9)
     if args.accum.startswith("i8"):
         S = int(args.accum[3:]) if len(args.accum) > 2 else 8
-        ops_launch = 2.0 * flops_launch * S  # two integer matrices (G.M and 1-M) x S slices of every operand column
+        mm = ctx.missing_mode(b)  # 0/1: two integer matrices on the matrix cores; 2/3: G.M alone (+ sparse gathers for E)
+        nmat = 1 if mm in (2, 3) else 2
+        ops_launch = nmat * flops_launch * S  # integer matrices x S slices of every operand column
         roofline.update(achieved=ops_launch / (ms_dom * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s", slices=S,
+                        integer_matrices_on_mfma=nmat,
+                        missing_call_path={0: "dense (MFMA)", 1: "dense, empty blocks skipped", 2: "none missing", 3: "sparse fp64 gathers"}[mm],
                         ops_per_launch=ops_launch, fp64_equivalent_tflops=flops_launch / (ms_dom * 1e-3) / 1e12,
                         peak_measured_pure_mfma_stream=3576.0)  # profiles/r01_mfma_i8_microbench.txt (random operands; power-limited)
         del roofline["flops_per_launch"]
@@ -254,7 +258,7 @@ def main():
             diff = float(torch.max(torch.abs(Y2 - Y)).item())
             ms2 = max(p2["ms_xt"], p2["ms_x"])
             if other == "i8":
-                ops = 2.0 * flops_launch * 8
+                ops = (1 if c2.missing_mode(b) in (2, 3) else 2) * flops_launch * 8
                 rf = dict(bound="mfma", achieved=ops / (ms2 * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s",
                           frac=ops / (ms2 * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, peak_measured_pure_mfma_stream=3576.0)
             else:

@@ -77,6 +77,7 @@ SIGNATURES = {
     "fpca_nsamples": (_U64, [_P]),
     "fpca_nsnps": (_U64, [_P]),
     "fpca_accum": (_I, [_P]),
+    "fpca_missing_mode": (_I, [_P, _I]),
     "fpca_download_packed": (_I, [_P, _P]),
     "fpca_stats": (_I, [_P, _P, C.POINTER(_D)]),
     "fpca_set_meansd": (_I, [_P, _P]),

@@ -38,6 +38,11 @@ class Context:
         self.P_total = self.P
         self._keep = []
 
+    def missing_mode(self, b=32):
+        """How the exact-integer path treats the missing-call indicator (fpca_missing_mode): 0 full, 1 skip empty blocks,
+        2 nothing missing, 3 sparse gathers; -1 for the fp64 / fp32 kernels."""
+        return int(lib().fpca_missing_mode(self.h, b))
+
     @property
     def accum(self):
         """The arithmetic mode in effect: 'fp64', 'fp32' or 'i8xS' ("auto" resolved)."""

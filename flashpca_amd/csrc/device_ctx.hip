@@ -116,6 +116,12 @@ struct fpca_ctx {
    double *d_i8ws = nullptr;
    size_t i8ws_cap = 0;
    bool i8_scales_done = false, i8_transposed = false;
+   // sparse missing indicator: index lists of the missing calls per SNP (sample indices) and per sample (SNP indices)
+   std::vector<uint32_t> h_nmiss; // per-SNP counts from K1
+   uint32_t *d_snp_ptr = nullptr, *d_snp_idx = nullptr, *d_smp_ptr = nullptr, *d_smp_idx = nullptr;
+   double *d_eplane = nullptr; // E'Q of the current stage, [max(N_pad, P_pad)][b]
+   size_t eplane_cap = 0;
+   bool sparse_ready = false;
    // communication
    ncclComm_t comm = nullptr;
    int nranks = 1, rank = 0;
@@ -224,7 +230,7 @@ void ctx_free(fpca_ctx *c)
    }
    void *ptrs[] = {c->d_Xd, c->d_packed, c->d_lut, c->d_mean, c->d_sd,   c->d_sumsq, c->d_T,
                    c->d_part,   c->d_stage, c->d_io_a, c->d_io_b, c->d_small, c->d_packedT, c->d_inv_sd, c->d_mu_inv_sd,
-                   c->d_i8w, c->d_Qb, c->d_Qg, c->d_Qm, c->d_i8ws};
+                   c->d_i8w, c->d_Qb, c->d_Qg, c->d_Qm, c->d_i8ws, c->d_snp_ptr, c->d_snp_idx, c->d_smp_ptr, c->d_smp_idx, c->d_eplane};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -252,6 +258,7 @@ void ensure_stats(fpca_ctx *c)
    c->n_missing = 0;
    for (uint32_t v : nm) c->n_missing += v;
    c->missing_known = true;
+   c->h_nmiss.swap(nm);
    // pairwise-ish (blocked) summation for a reproducible, accurate trace
    double tot = 0;
    for (size_t i0 = 0; i0 < ss.size(); i0 += 1024) {
@@ -359,14 +366,59 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
 }
 
 // how the int8 GEMMs treat the missing-indicator matrix (kernels_i8.hip: I8_FULL / I8_SKIP_EMPTY / I8_NO_MISSING)
-int i8_mode(const fpca_ctx *c)
+// 0 both matrices on the matrix cores; 1 the same, skipping blocks of E without a missing call; 2 no missing call in the
+// shard: G.M alone; 3 G.M alone on the matrix cores + the missing-indicator products as sparse fp64 gathers
+constexpr int I8M_FULL = 0, I8M_SKIP = 1, I8M_NONE = 2, I8M_SPARSE = 3;
+int i8_mode(const fpca_ctx *c, int b)
 {
-   static const char *env = getenv("FPCA_I8_MODE"); // 0 / 1 / 2: force (tests; 2 is wrong unless nothing is missing)
-   if (env) return atoi(env);
-   if (!c->missing_known) return 0;
-   if (c->n_missing == 0) return 2;
+   static const char *env = getenv("FPCA_I8_MODE"); // force (tests; 2 is wrong unless nothing is missing)
+   const bool sparse_ok = c->missing_known && c->n_missing < (1ull << 31) && (b == 16 || b == 32 || b == 64);
+   if (env) return (atoi(env) == I8M_SPARSE && !sparse_ok) ? I8M_FULL : atoi(env);
+   if (!c->missing_known) return I8M_FULL;
+   if (c->n_missing == 0) return I8M_NONE;
    const double rate = (double)c->n_missing / ((double)c->N * (double)std::max<uint64_t>(c->P_g, 1));
-   return rate < 3e-4 ? 1 : 0; // break-even of the block-skipping variant, measured at N x P = 500k x 100k
+   // a gathered fp64 row costs 8 b bytes per missing call (1.9-2.2 ms per 0.1 % at N x P = 500k x 100k, b = 32); the E half
+   // of the int8 GEMMs costs 7.5-9 ms there whatever the rate: break-even measured near 0.4 %
+   if (sparse_ok && rate <= 0.003) return I8M_SPARSE;
+   return rate < 3e-4 ? I8M_SKIP : I8M_FULL; // (block skipping: only where the sparse path does not apply)
+}
+
+// index lists of the missing calls, built once (by SNP from the SNP-major stream, by sample from the sample-major copy)
+void ensure_sparse(fpca_ctx *c, int b)
+{
+   hipStream_t s = c->stream;
+   const size_t need = (size_t)std::max(c->N_pad, c->P_pad) * b;
+   if (need > c->eplane_cap) {
+      if (c->d_eplane) HIP_CHECK(hipFree(c->d_eplane));
+      c->d_eplane = nullptr;
+      HIP_CHECK(hipMalloc(&c->d_eplane, need * sizeof(double)));
+      c->eplane_cap = need;
+   }
+   if (c->sparse_ready) return;
+   const uint64_t nnz = c->n_missing;
+   std::vector<uint32_t> ptr(c->P_g + 1, 0);
+   for (uint64_t j = 0; j < c->P_g; j++) ptr[j + 1] = ptr[j] + c->h_nmiss[j];
+   HIP_CHECK(hipMalloc(&c->d_snp_ptr, (c->P_g + 1) * sizeof(uint32_t)));
+   HIP_CHECK(hipMalloc(&c->d_snp_idx, std::max<uint64_t>(nnz, 1) * sizeof(uint32_t)));
+   HIP_CHECK(hipMemcpyAsync(c->d_snp_ptr, ptr.data(), (c->P_g + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+   kern::fill_missing(c->d_packed, c->pitch, c->N, c->P_g, c->d_snp_ptr, c->d_snp_idx, s);
+   HIP_CHECK(hipStreamSynchronize(s)); // ptr is reused below
+   uint32_t *d_cnt = nullptr;
+   HIP_CHECK(hipMalloc(&d_cnt, c->N * sizeof(uint32_t)));
+   kern::count_missing(c->d_packedT, c->pitchT, c->P_g, c->N, d_cnt, s);
+   std::vector<uint32_t> cnt(c->N);
+   HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, c->N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   (void)hipFree(d_cnt);
+   ptr.assign(c->N + 1, 0);
+   for (uint64_t i = 0; i < c->N; i++) ptr[i + 1] = ptr[i] + cnt[i];
+   if (ptr[c->N] != nnz) throw Error(FPCA_EHIP, "missing-call counts by sample and by SNP disagree");
+   HIP_CHECK(hipMalloc(&c->d_smp_ptr, (c->N + 1) * sizeof(uint32_t)));
+   HIP_CHECK(hipMalloc(&c->d_smp_idx, std::max<uint64_t>(nnz, 1) * sizeof(uint32_t)));
+   HIP_CHECK(hipMemcpyAsync(c->d_smp_ptr, ptr.data(), (c->N + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+   kern::fill_missing(c->d_packedT, c->pitchT, c->P_g, c->N, c->d_smp_ptr, c->d_smp_idx, s);
+   HIP_CHECK(hipStreamSynchronize(s));
+   c->sparse_ready = true;
 }
 
 kern::SliceOp i8_op_b(fpca_ctx *c)
@@ -393,8 +445,16 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain)
    i8_ops_t(c, ot);
    kern::i8_colmax(dB, c->N, b, 1, &ob, s);
    kern::i8_slice(dB, c->N_pad, c->N, b, c->i8_S, 1, &ob, s);
+   int mode = i8_mode(c, b);
+   const double *eplane = nullptr;
+   if (mode == I8M_SPARSE) { // E'B: for every SNP the sum of the B rows of its missing samples
+      ensure_sparse(c, b);
+      kern::sparse_rows_sum(c->d_snp_ptr, c->d_snp_idx, dB, nullptr, b, c->P_g, c->P_pad, c->d_eplane, s);
+      eplane = c->d_eplane;
+      mode = I8M_NONE;
+   }
    kern::gemm_i8(c->d_packed, c->pitch, c->d_Qb, c->d_Qb, ob.colw, ob.colw, ob.colsum, c->d_mean, c->d_sd, c->d_T, c->d_i8ws, c->P_pad,
-                 c->N_pad, c->P_g, i8_mode(c), b, c->i8_S, chain ? ot : nullptr, s);
+                 c->N_pad, c->P_g, mode, eplane, b, c->i8_S, chain ? ot : nullptr, s);
 }
 
 // Row chunks of Y for the overlapped all-reduce (built-in communicator only): the all-reduce of chunk i runs on the
@@ -422,17 +482,26 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_
 {
    kern::SliceOp ot[2];
    i8_ops_t(c, ot);
+   int mode = i8_mode(c, b);
    if (do_slice) {
       if (!have_max) kern::i8_colmax(c->d_T, c->P_g, b, 2, ot, s);
       kern::i8_slice(c->d_T, c->P_pad, c->P_g, b, c->i8_S, 2, ot, s);
+      if (mode == I8M_SPARSE) { // E (mean T / sd): for every sample the sum of the scaled T rows of its missing SNPs
+         ensure_sparse(c, b);
+         kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, c->d_T, c->d_mu_inv_sd, b, c->N, c->N_pad, c->d_eplane, s);
+      }
    }
    if (r1 == 0) r1 = c->N_pad;
    if (r1 <= r0) return;
-   const int mode = i8_mode(c);
-   // without missing genotypes only G.M is multiplied: one operand (Qm is still sliced: its column sums are 1'Qm = M'Qm)
-   kern::gemm_i8(c->d_packedT + r0 * c->pitchT, c->pitchT, c->d_Qg, mode == 2 ? c->d_Qg : c->d_Qm, ot[0].colw, ot[1].colw, ot[1].colsum,
-                 nullptr, nullptr, dY + r0 * b, c->d_i8ws, r1 - r0, c->P_pad, c->N > r0 ? std::min(c->N - r0, r1 - r0) : 0, mode, b, c->i8_S,
-                 nullptr, s);
+   const double *eplane = nullptr;
+   if (mode == I8M_SPARSE) {
+      eplane = c->d_eplane + r0 * b;
+      mode = I8M_NONE;
+   }
+   // G.M alone: one operand (Qm is still sliced: its column sums are 1'Qm, and M'Qm = 1'Qm - E'Qm)
+   kern::gemm_i8(c->d_packedT + r0 * c->pitchT, c->pitchT, c->d_Qg, mode == I8M_NONE ? c->d_Qg : c->d_Qm, ot[0].colw, ot[1].colw,
+                 ot[1].colsum, nullptr, nullptr, dY + r0 * b, c->d_i8ws, r1 - r0, c->P_pad, c->N > r0 ? std::min(c->N - r0, r1 - r0) : 0, mode,
+                 eplane, b, c->i8_S, nullptr, s);
 }
 
 // the operator on device-resident blocks: dY = X_g X_g' dB (+ all-reduce).  ev (optional): 4 events recorded
@@ -950,6 +1019,18 @@ int fpca_set_meansd(fpca_ctx *ctx, const double *mean_sd)
 }
 
 int fpca_accum(const fpca_ctx *ctx) { return ctx ? ctx->accum : FPCA_EINVAL; }
+
+int fpca_missing_mode(fpca_ctx *ctx, int b)
+{
+   int mode = -1;
+   int rc = guarded([&] {
+      if (!ctx || b < 1 || b > MAX_BLOCKVEC) throw Error(FPCA_EINVAL, "bad argument to fpca_missing_mode");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      ensure_stats(ctx);
+      mode = ctx->i8_S ? i8_mode(ctx, (int)round_up((uint64_t)b, 16)) : -1;
+   });
+   return rc == FPCA_OK ? mode : rc;
+}
 
 // ---- operator, host pointers -------------------------------------------------------------------------
 int fpca_apply_xxt(fpca_ctx *ctx, const double *B, int64_t ldb, int b, double *Y, int64_t ldy)

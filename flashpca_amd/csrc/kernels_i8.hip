@@ -584,7 +584,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
 // The K2 flavour can also leave the column maxima of out * rs0 and out * rs1 behind (the two K3 operands), which saves
 // the next stage a pass over T.
 __global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ part, int zb, int rows_tile, int nA, int sB, uint64_t rowB0,
-                                                     uint64_t rowsB, uint64_t rows_pad, uint64_t rows_valid, int mats, int b, int bw, int S,
+                                                     uint64_t rowsB, uint64_t rows_pad, uint64_t rows_valid, int mats,
+                                                     const double *__restrict__ eplane /* [rows_pad][b]: E'Q from the sparse path */,
+                                                     int b, int bw, int S,
                                                      const double *__restrict__ wm, const long long *__restrict__ colsum_m /* 1'Qm */,
                                                      const double *__restrict__ mean, const double *__restrict__ sd,
                                                      double *__restrict__ out, const double *__restrict__ rs0,
@@ -620,8 +622,9 @@ __global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ p
                }
             }
          }
-         // (mats == 1: no missing genotype in the shard, E = 0; but the padding rows are all "missing" and must stay zero)
-         if (mats == 1 && row >= rows_valid) accg = 0.0, acce = ones;
+         // (mats == 1: E is not in the partials -- it is zero, or comes from the sparse path; the padding rows are all
+         // "missing" and must stay zero)
+         if (mats == 1) acce = row >= rows_valid ? ones : (eplane ? eplane[row * b + c] : 0.0);
          const double accm = ones - acce;
          double v;
          if (mean) {
@@ -768,8 +771,9 @@ static void launch_i8(const I8Plan &pl, hipStream_t stream, const uint8_t *packe
 
 void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, const double *wg, const double *wm,
              const long long *colsum_m, const double *mean, const double *sd, double *out, double *ws, uint64_t rows_pad, uint64_t k_pad,
-             uint64_t rows_valid, int mode, int b, int S,
-             const SliceOp *next_ops /* null, or the two operands whose column maxima the combine should leave */, hipStream_t stream)
+             uint64_t rows_valid, int mode, const double *eplane /* I8_NO_MISSING kernel + E'Q computed elsewhere, or null */, int b,
+             int S, const SliceOp *next_ops /* null, or the two operands whose column maxima the combine should leave */,
+             hipStream_t stream)
 {
    const bool two = (Qg != Qm);
    const I8Shape sh = i8_shape(S, b, two, mode);
@@ -813,8 +817,8 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
 #undef FPCA_I8_ARGS
    HIP_CHECK_LAUNCH();
    const unsigned blocks = (unsigned)std::min<uint64_t>(1024, (rows_pad + (256 / b) - 1) / (256 / b));
-   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, sh.zb, sh.rows, pl.nA, pl.sB, pl.rowB0, pl.rowsB, rows_pad, rows_valid, mode == I8_NO_MISSING ? 1 : 2, b, bw, S, wm, colsum_m, mean,
-                      sd, out,
+   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, sh.zb, sh.rows, pl.nA, pl.sB, pl.rowB0, pl.rowsB, rows_pad, rows_valid, mode == I8_NO_MISSING ? 1 : 2, eplane, b, bw, S, wm, colsum_m,
+                      mean, sd, out,
                       next_ops ? next_ops[0].rowscale : nullptr, next_ops ? next_ops[0].maxbits : nullptr,
                       next_ops ? next_ops[1].rowscale : nullptr, next_ops ? next_ops[1].maxbits : nullptr);
    HIP_CHECK_LAUNCH();
@@ -840,6 +844,143 @@ void i8_rowscales(const double *mean, const double *sd, uint64_t P_g, uint64_t P
                   hipStream_t stream)
 {
    hipLaunchKernelGGL(k_i8_rowscales, dim3((unsigned)((P_pad + 255) / 256)), dim3(256), 0, stream, mean, sd, P_g, P_pad, inv_sd, mu_inv_sd);
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sparse missing indicator.  With a typical array-data missing rate (0.1 %) the E half of the int8 work multiplies a
+// matrix that is 99.9 % zeros.  Instead: index lists of the missing calls (per SNP for K2, per sample for K3), built
+// once, and  E'B  /  E (mean T / sd)  as gathers of fp64 rows -- 256 bytes per missing call, a few ms where the MFMA
+// route took 8-9 -- while the int8 GEMM multiplies G.M alone with the one-matrix kernel.
+
+// missing calls of each 2-bit record among its first `ncols` codes
+__global__ __launch_bounds__(256) void k_count_missing(const uint8_t *__restrict__ packed, size_t pitch, uint64_t ncols,
+                                                        uint32_t *__restrict__ cnt)
+{
+   const uint8_t *row = packed + (uint64_t)blockIdx.x * pitch;
+   const uint64_t nbytes = (ncols + 3) / 4, nw = nbytes / 4;
+   uint32_t n = 0;
+   for (uint64_t i = threadIdx.x; i < nw; i += 256) {
+      const uint32_t w = reinterpret_cast<const uint32_t *>(row)[i];
+      n += __popc(w & ~(w >> 1) & 0x55555555u);
+   }
+   for (uint64_t i = nw * 4 + threadIdx.x; i < nbytes; i += 256) {
+      const uint32_t w = row[i];
+      n += __popc(w & ~(w >> 1) & 0x55u);
+   }
+   // codes beyond ncols in the last byte
+   if (threadIdx.x == 0 && (ncols & 3)) {
+      const uint32_t w = row[nbytes - 1] >> (2 * (ncols & 3));
+      n -= __popc(w & ~(w >> 1) & 0x55u);
+   }
+   __shared__ uint32_t red[256];
+   red[threadIdx.x] = n;
+   __syncthreads();
+   for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) cnt[blockIdx.x] = red[0];
+}
+
+// idx[ptr[r] ..] = ascending positions (< ncols) of the missing calls of record r; thread t scans a contiguous segment
+__global__ __launch_bounds__(256) void k_fill_missing(const uint8_t *__restrict__ packed, size_t pitch, uint64_t ncols,
+                                                       const uint32_t *__restrict__ ptr, uint32_t *__restrict__ idx)
+{
+   const uint8_t *row = packed + (uint64_t)blockIdx.x * pitch;
+   const uint64_t nbytes = (ncols + 3) / 4;
+   const uint64_t seg = (nbytes + 255) / 256, b0 = threadIdx.x * seg, b1 = b0 + seg < nbytes ? b0 + seg : nbytes;
+   uint32_t n = 0;
+   for (uint64_t i = b0; i < b1; i++) {
+      const uint32_t w = row[i];
+      uint32_t m = w & ~(w >> 1) & 0x55u;
+      if (i == nbytes - 1 && (ncols & 3)) m &= (1u << (2 * (ncols & 3))) - 1u;
+      n += __popc(m);
+   }
+   __shared__ uint32_t scan[256];
+   scan[threadIdx.x] = n;
+   __syncthreads();
+   for (int o = 1; o < 256; o <<= 1) { // Hillis-Steele inclusive scan
+      const uint32_t v = (int)threadIdx.x >= o ? scan[threadIdx.x - o] : 0;
+      __syncthreads();
+      scan[threadIdx.x] += v;
+      __syncthreads();
+   }
+   uint32_t pos = ptr[blockIdx.x] + scan[threadIdx.x] - n;
+   for (uint64_t i = b0; i < b1; i++) {
+      const uint32_t w = row[i];
+      uint32_t m = w & ~(w >> 1) & 0x55u;
+      if (i == nbytes - 1 && (ncols & 3)) m &= (1u << (2 * (ncols & 3))) - 1u;
+      while (m) {
+         const int bit = __ffs(m) - 1;
+         idx[pos++] = (uint32_t)(i * 4 + bit / 2);
+         m &= m - 1;
+      }
+   }
+}
+
+void count_missing(const uint8_t *packed, size_t pitch, uint64_t ncols, uint64_t nrec, uint32_t *cnt, hipStream_t stream)
+{
+   if (!nrec) return;
+   hipLaunchKernelGGL(k_count_missing, dim3((unsigned)nrec), dim3(256), 0, stream, packed, pitch, ncols, cnt);
+   HIP_CHECK_LAUNCH();
+}
+
+void fill_missing(const uint8_t *packed, size_t pitch, uint64_t ncols, uint64_t nrec, const uint32_t *ptr, uint32_t *idx, hipStream_t stream)
+{
+   if (!nrec) return;
+   hipLaunchKernelGGL(k_fill_missing, dim3((unsigned)nrec), dim3(256), 0, stream, packed, pitch, ncols, ptr, idx);
+   HIP_CHECK_LAUNCH();
+}
+
+// out[r][c] = sum over s in list(r) of V[s][c] * (rowscale ? rowscale[s] : 1)   (fp64, list order = ascending s);
+// rows r >= nrec are zeroed.  One wave per output row; EPW = 64 / b list entries per step, 4 steps in flight.
+template <int B>
+__global__ __launch_bounds__(256) void k_sparse_rows_sum(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
+                                                          const double *__restrict__ V, const double *__restrict__ rowscale, uint64_t nrec,
+                                                          uint64_t rows_out, double *__restrict__ out)
+{
+   constexpr int EPW = 64 / B;
+   const int lane = threadIdx.x & 63, c = lane % B, e0 = lane / B;
+   for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows_out; r += (uint64_t)gridDim.x * 4) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      if (r < nrec) {
+         const uint32_t p0 = ptr[r], p1 = ptr[r + 1];
+         for (uint32_t t = p0 + e0; t < p1; t += 4 * EPW) {
+            const uint32_t t1 = t + EPW, t2 = t + 2 * EPW, t3 = t + 3 * EPW;
+            const uint32_t s0 = idx[t], s1 = t1 < p1 ? idx[t1] : 0, s2 = t2 < p1 ? idx[t2] : 0, s3 = t3 < p1 ? idx[t3] : 0;
+            double v0 = V[(uint64_t)s0 * B + c], v1 = t1 < p1 ? V[(uint64_t)s1 * B + c] : 0.0, v2 = t2 < p1 ? V[(uint64_t)s2 * B + c] : 0.0,
+                   v3 = t3 < p1 ? V[(uint64_t)s3 * B + c] : 0.0;
+            if (rowscale) {
+               v0 *= rowscale[s0];
+               v1 *= t1 < p1 ? rowscale[s1] : 0.0;
+               v2 *= t2 < p1 ? rowscale[s2] : 0.0;
+               v3 *= t3 < p1 ? rowscale[s3] : 0.0;
+            }
+            a0 += v0;
+            a1 += v1;
+            a2 += v2;
+            a3 += v3;
+         }
+      }
+      double a = (a0 + a1) + (a2 + a3);
+#pragma unroll
+      for (int o = 32; o >= B; o >>= 1) a += __shfl_down(a, o);
+      if (lane < B) out[r * B + c] = a;
+   }
+}
+
+void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, const double *rowscale, int b, uint64_t nrec,
+                     uint64_t rows_out, double *out, hipStream_t stream)
+{
+   if (!rows_out) return;
+   const unsigned blocks = (unsigned)std::min<uint64_t>(65536, (rows_out + 3) / 4);
+   switch (b) {
+   case 16: hipLaunchKernelGGL(k_sparse_rows_sum<16>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out); break;
+   case 32: hipLaunchKernelGGL(k_sparse_rows_sum<32>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out); break;
+   case 64: hipLaunchKernelGGL(k_sparse_rows_sum<64>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out); break;
+   default: throw Error(-1, "sparse_rows_sum: block width must be 16, 32 or 64");
+   }
    HIP_CHECK_LAUNCH();
 }
 

@@ -105,6 +105,11 @@ void fpca_destroy(fpca_ctx *ctx);
 uint64_t fpca_nsamples(const fpca_ctx *ctx);   /* Data::N */
 uint64_t fpca_nsnps(const fpca_ctx *ctx);      /* shard's P_g (Data::nsnps for a 1-shard run) */
 int fpca_accum(const fpca_ctx *ctx);           /* the FPCA_ACCUM_* mode in effect (AUTO resolved; may drop to FP64 at the first apply) */
+/* how the exact-integer path treats the missing-call indicator for blocks of b columns (chosen from K1's counts of this
+ * shard): 0 = both integer matrices on the matrix cores, 1 = the same, skipping blocks without a missing call, 2 = the
+ * shard has no missing call (one matrix), 3 = one matrix on the matrix cores + the missing-call products as sparse fp64
+ * gathers; -1 = not the exact-integer path.  Negative FPCA_E* on error. */
+int fpca_missing_mode(fpca_ctx *ctx, int b);
 /* copy the shard's packed stream back (P_g * ceil(N/4) bytes, .bed body layout) -- used by the tests to feed
  * the CPU oracle the exact matrix a synthetic context holds */
 int fpca_download_packed(fpca_ctx *ctx, uint8_t *out);

@@ -370,9 +370,10 @@ def test_i8_shard_without_missing_genotypes(N, P, b, fp, orc):
         assert np.max(np.abs(r["d"] - w) / w) < 1e-8
 
 
-@pytest.mark.parametrize("mode", ["0", "1"])
+@pytest.mark.parametrize("mode", ["0", "1", "3"])
 def test_i8_forced_missing_modes(golden_dir, fp, orc, monkeypatch, mode):
-    """I8_FULL and I8_SKIP_EMPTY (blocks of the missing indicator without a missing genotype are skipped) give the same
+    """Both matrices on the matrix cores (0), the same skipping blocks of the missing indicator without a missing
+    genotype (1), and G.M on the matrix cores + the missing-indicator products as sparse fp64 gathers (3) give the same
     operator on data WITH missing calls, whatever the automatic choice would be."""
     monkeypatch.setenv("FPCA_I8_MODE", mode)
     N = fp.count_fam_rows(os.path.join(golden_dir, "hapmap3_data.fam"))
@@ -380,7 +381,13 @@ def test_i8_forced_missing_modes(golden_dir, fp, orc, monkeypatch, mode):
     ctx = fp.Context.from_bed(bed, N, accum="i8")
     od = orc.OracleData(bed, N, "binom2")
     X = od.dense()
-    B = np.random.default_rng(3).standard_normal((N, 32))
-    Z_ref = X @ (X.T @ B)
-    assert np.max(np.abs(ctx.apply_xxt(B) - Z_ref) / np.max(np.abs(Z_ref), axis=0)) <= 1e-11
+    for b in (32, 64, 16, 5):
+        B = np.random.default_rng(3).standard_normal((N, b))
+        T_ref = X.T @ B
+        assert np.max(np.abs(ctx.apply_xt(B) - T_ref) / np.max(np.abs(T_ref), axis=0)) <= 1e-11
+        Z_ref = X @ T_ref
+        assert np.max(np.abs(ctx.apply_xxt(B) - Z_ref) / np.max(np.abs(Z_ref), axis=0)) <= 1e-11
+    Tin = np.random.default_rng(4).standard_normal((ctx.P, 32))
+    Y_ref = X @ Tin
+    assert np.max(np.abs(ctx.apply_x(Tin) - Y_ref) / np.max(np.abs(Y_ref), axis=0)) <= 1e-11
     ctx.close()
