@@ -59,6 +59,8 @@ class BenchResult(C.Structure):
         ("ms_allreduce", C.c_double),
         ("flops_per_step", C.c_double),
         ("packed_bytes_per_step", C.c_double),
+        ("ms_gemm_xt", C.c_double),
+        ("ms_gemm_x", C.c_double),
     ]
 
 

@@ -439,7 +439,7 @@ void i8_zero_meta(fpca_ctx *c, hipStream_t s)
 
 // T = X' B : slices of B against the SNP-major stream, per-SNP mean / sd applied in the combine; with `chain` the
 // combine also leaves the column maxima of the two K3 operands (the meta region must have been zeroed by the caller)
-void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain)
+void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipEvent_t *gev = nullptr)
 {
    kern::SliceOp ob = i8_op_b(c), ot[2];
    i8_ops_t(c, ot);
@@ -454,7 +454,7 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain)
       mode = I8M_NONE;
    }
    kern::gemm_i8(c->d_packed, c->pitch, c->d_Qb, c->d_Qb, ob.colw, ob.colw, ob.colsum, c->d_mean, c->d_sd, c->d_T, c->d_i8ws, c->P_pad,
-                 c->N_pad, c->P_g, mode, eplane, b, c->i8_S, chain ? ot : nullptr, s);
+                 c->N_pad, c->P_g, mode, eplane, b, c->i8_S, chain ? ot : nullptr, s, gev);
 }
 
 // Row chunks of Y for the overlapped all-reduce (built-in communicator only): the all-reduce of chunk i runs on the
@@ -478,7 +478,8 @@ uint64_t ar_chunk_begin(const fpca_ctx *c, int nchunks, int i) // multiples of 5
 }
 
 // Y = X T : slices of T/sd and mean T/sd (one pass over T) against the sample-major copy, rows [r0, r1) of Y
-void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_slice = true, uint64_t r0 = 0, uint64_t r1 = 0)
+void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_slice = true, uint64_t r0 = 0, uint64_t r1 = 0,
+          hipEvent_t *gev = nullptr)
 {
    kern::SliceOp ot[2];
    i8_ops_t(c, ot);
@@ -501,7 +502,7 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_
    // G.M alone: one operand (Qm is still sliced: its column sums are 1'Qm, and M'Qm = 1'Qm - E'Qm)
    kern::gemm_i8(c->d_packedT + r0 * c->pitchT, c->pitchT, c->d_Qg, mode == I8M_NONE ? c->d_Qg : c->d_Qm, ot[0].colw, ot[1].colw,
                  ot[1].colsum, nullptr, nullptr, dY + r0 * b, c->d_i8ws, r1 - r0, c->P_pad, c->N > r0 ? std::min(c->N - r0, r1 - r0) : 0, mode,
-                 eplane, b, c->i8_S, nullptr, s);
+                 eplane, b, c->i8_S, nullptr, s, gev);
 }
 
 // the operator on device-resident blocks: dY = X_g X_g' dB (+ all-reduce).  ev (optional): 4 events recorded
@@ -513,10 +514,11 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
       c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
       if (ev) HIP_CHECK(hipEventRecord(ev[0], s));
       i8_zero_meta(c, s);
-      xt_i8(c, dB, b, s, true);
+      xt_i8(c, dB, b, s, true, ev ? ev + 4 : nullptr);
       if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
       const int nch = ar_chunks(c);
       if (nch > 1) {
+         if (ev) HIP_CHECK(hipEventRecord(ev[6], s)); // (chunked: the "GEMM kernel" interval spans all chunks, slicing included)
          for (int i = 0; i < nch; i++) {
             const uint64_t r0 = ar_chunk_begin(c, nch, i), r1 = ar_chunk_begin(c, nch, i + 1);
             x_i8(c, b, dY, s, true, i == 0, r0, r1);
@@ -525,13 +527,14 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
             HIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_chunk[i], 0));
             RCCL_CHECK(rccl().AllReduce(dY + r0 * b, dY + r0 * b, (r1 - r0) * b, ncclDouble, ncclSum, c->comm, c->comm_stream));
          }
+         if (ev) HIP_CHECK(hipEventRecord(ev[7], s));
          if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
          HIP_CHECK(hipEventRecord(c->ev_comm_done, c->comm_stream));
          HIP_CHECK(hipStreamWaitEvent(s, c->ev_comm_done, 0));
          if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
          return;
       }
-      x_i8(c, b, dY, s, true);
+      x_i8(c, b, dY, s, true, true, 0, 0, ev ? ev + 6 : nullptr);
       if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
       if (c->multi()) c->allreduce(dY, (uint64_t)c->N_pad * b, s);
       if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
@@ -545,16 +548,20 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
    if (s3 > 1) need = std::max(need, (size_t)s3 * c->N_pad * b);
    if (need) c->ensure(c->d_part, c->part_cap, need);
    if (ev) HIP_CHECK(hipEventRecord(ev[0], s));
+   if (ev) HIP_CHECK(hipEventRecord(ev[4], s));
    if (c->dense)
       kern::xt_b_dense(c->d_Xd, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, s);
    else
       kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, c->accum == FPCA_ACCUM_FP32, s);
+   if (ev) HIP_CHECK(hipEventRecord(ev[5], s));
    if (s2 > 1) kern::reduce_sum(c->d_part, c->d_T, (uint64_t)c->P_pad * b, s2, s);
    if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
+   if (ev) HIP_CHECK(hipEventRecord(ev[6], s));
    if (c->dense)
       kern::x_t_dense(c->d_Xd, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, s);
    else
       kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, c->accum == FPCA_ACCUM_FP32, s);
+   if (ev) HIP_CHECK(hipEventRecord(ev[7], s));
    if (s3 > 1) kern::reduce_sum(c->d_part, dY, (uint64_t)c->N_pad * b, s3, s);
    if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
    if (c->multi()) c->allreduce(dY, (uint64_t)c->N_pad * b, s);
@@ -1104,7 +1111,7 @@ int fpca_apply_xxt_dev(fpca_ctx *ctx, const double *dB, int b, double *dY, void 
       if (b != 16 && b != 32 && b != 48 && b != 64) throw Error(FPCA_EINVAL, "device blocks must be 16, 32, 48 or 64 wide");
       HIP_CHECK(hipSetDevice(ctx->device));
       hipEvent_t *ev = nullptr;
-      if (ctx->prof_on && (size_t)(ctx->prof_used + 1) * 4 <= ctx->prof_ev.size()) ev = &ctx->prof_ev[(size_t)ctx->prof_used++ * 4];
+      if (ctx->prof_on && (size_t)(ctx->prof_used + 1) * 8 <= ctx->prof_ev.size()) ev = &ctx->prof_ev[(size_t)ctx->prof_used++ * 8];
       apply_xxt_dev(ctx, dB, b, dY, stream ? (hipStream_t)stream : ctx->stream, ev);
    });
 }
@@ -1264,27 +1271,33 @@ int fpca_bench_apply(fpca_ctx *ctx, int b, int steps, int warmup, fpca_bench_res
       HIP_CHECK(hipMalloc(&dB, (size_t)ctx->N_pad * b * sizeof(double)));
       HIP_CHECK(hipMalloc(&dY, (size_t)ctx->N_pad * b * sizeof(double)));
       kern::fill_random(dB, ctx->N, ctx->N_pad, b, 12345, ctx->stream);
-      std::vector<hipEvent_t> ev((size_t)steps * 4);
+      std::vector<hipEvent_t> ev((size_t)steps * 8); // per step: stage boundaries [0..3], K2 / K3 GEMM kernel [4,5] / [6,7]
       for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));
       for (int i = 0; i < warmup; i++) apply_xxt_dev(ctx, dB, b, dY, ctx->stream, nullptr);
       HIP_CHECK(hipStreamSynchronize(ctx->stream));
-      for (int i = 0; i < steps; i++) apply_xxt_dev(ctx, dB, b, dY, ctx->stream, &ev[(size_t)i * 4]);
+      for (int i = 0; i < steps; i++) apply_xxt_dev(ctx, dB, b, dY, ctx->stream, &ev[(size_t)i * 8]);
       HIP_CHECK(hipStreamSynchronize(ctx->stream));
-      double t2 = 0, t3 = 0, ta = 0;
+      double t2 = 0, t3 = 0, ta = 0, g2 = 0, g3 = 0;
       float ms = 0;
       for (int i = 0; i < steps; i++) {
-         HIP_CHECK(hipEventElapsedTime(&ms, ev[i * 4 + 0], ev[i * 4 + 1]));
+         HIP_CHECK(hipEventElapsedTime(&ms, ev[i * 8 + 0], ev[i * 8 + 1]));
          t2 += ms;
-         HIP_CHECK(hipEventElapsedTime(&ms, ev[i * 4 + 1], ev[i * 4 + 2]));
+         HIP_CHECK(hipEventElapsedTime(&ms, ev[i * 8 + 1], ev[i * 8 + 2]));
          t3 += ms;
-         HIP_CHECK(hipEventElapsedTime(&ms, ev[i * 4 + 2], ev[i * 4 + 3]));
+         HIP_CHECK(hipEventElapsedTime(&ms, ev[i * 8 + 2], ev[i * 8 + 3]));
          ta += ms;
+         HIP_CHECK(hipEventElapsedTime(&ms, ev[i * 8 + 4], ev[i * 8 + 5]));
+         g2 += ms;
+         HIP_CHECK(hipEventElapsedTime(&ms, ev[i * 8 + 6], ev[i * 8 + 7]));
+         g3 += ms;
       }
-      HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[(size_t)steps * 4 - 1]));
+      HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[(size_t)(steps - 1) * 8 + 3]));
       res->ms_total = ms;
       res->ms_xt = t2 / steps;
       res->ms_x = t3 / steps;
       res->ms_allreduce = ta / steps;
+      res->ms_gemm_xt = g2 / steps;
+      res->ms_gemm_x = g3 / steps;
       res->flops_per_step = 4.0 * (double)ctx->N * (double)ctx->P_g * b;
       res->packed_bytes_per_step = 2.0 * (double)ctx->np * (double)ctx->P_g;
       for (auto &e : ev) (void)hipEventDestroy(e);
@@ -1298,7 +1311,7 @@ int fpca_profile_begin(fpca_ctx *ctx, int max_steps)
    return guarded([&] {
       if (!ctx || max_steps < 1) throw Error(FPCA_EINVAL, "bad argument to fpca_profile_begin");
       HIP_CHECK(hipSetDevice(ctx->device));
-      while (ctx->prof_ev.size() < (size_t)max_steps * 4) {
+      while (ctx->prof_ev.size() < (size_t)max_steps * 8) {
          hipEvent_t e;
          HIP_CHECK(hipEventCreate(&e));
          ctx->prof_ev.push_back(e);
@@ -1316,10 +1329,14 @@ int fpca_profile_end(fpca_ctx *ctx, int b, fpca_bench_result *res, int *nsteps)
       ctx->prof_on = false;
       HIP_CHECK(hipDeviceSynchronize());
       const int n = ctx->prof_used;
-      double t2 = 0, t3 = 0, ta = 0, tt = 0;
+      double t2 = 0, t3 = 0, ta = 0, tt = 0, g2 = 0, g3 = 0;
       float ms = 0;
       for (int i = 0; i < n; i++) {
-         hipEvent_t *e = &ctx->prof_ev[(size_t)i * 4];
+         hipEvent_t *e = &ctx->prof_ev[(size_t)i * 8];
+         HIP_CHECK(hipEventElapsedTime(&ms, e[4], e[5]));
+         g2 += ms;
+         HIP_CHECK(hipEventElapsedTime(&ms, e[6], e[7]));
+         g3 += ms;
          HIP_CHECK(hipEventElapsedTime(&ms, e[0], e[1]));
          t2 += ms;
          HIP_CHECK(hipEventElapsedTime(&ms, e[1], e[2]));
@@ -1335,6 +1352,8 @@ int fpca_profile_end(fpca_ctx *ctx, int b, fpca_bench_result *res, int *nsteps)
          res->ms_xt = t2 / n;
          res->ms_x = t3 / n;
          res->ms_allreduce = ta / n;
+         res->ms_gemm_xt = g2 / n;
+         res->ms_gemm_x = g3 / n;
       }
       res->flops_per_step = 4.0 * (double)ctx->N * (double)ctx->P_g * b;
       res->packed_bytes_per_step = 2.0 * (double)ctx->np * (double)ctx->P_g;

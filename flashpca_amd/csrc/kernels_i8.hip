@@ -773,7 +773,7 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
              const long long *colsum_m, const double *mean, const double *sd, double *out, double *ws, uint64_t rows_pad, uint64_t k_pad,
              uint64_t rows_valid, int mode, const double *eplane /* I8_NO_MISSING kernel + E'Q computed elsewhere, or null */, int b,
              int S, const SliceOp *next_ops /* null, or the two operands whose column maxima the combine should leave */,
-             hipStream_t stream)
+             hipStream_t stream, hipEvent_t *gemm_events /* null, or 2 events recorded around the GEMM kernel itself */)
 {
    const bool two = (Qg != Qm);
    const I8Shape sh = i8_shape(S, b, two, mode);
@@ -781,6 +781,7 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
    const I8Plan pl = i8_plan(rows_pad, k_pad, sh, bw);
    const int chunks_total = (int)(k_pad / sh.kc);
 #define FPCA_I8_ARGS pl, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws, rows_pad, chunks_total, sh.zb
+   if (gemm_events) (void)hipEventRecord(gemm_events[0], stream);
    if (two && mode == I8_NO_MISSING) throw Error(-1, "gemm_i8: without missing genotypes both matrices share one operand (pass Qm == Qg)");
 #define FPCA_I8_K3(NT_, MODE_) launch_i8<I8Cfg<true, 2, NT_, 4, 1, 256, 1, MODE_>>(FPCA_I8_ARGS)
 #define FPCA_I8_K2(NT_, MODE_) launch_i8<I8Cfg<false, (MODE_ == I8_NO_MISSING ? 2 : 1), NT_, 4, 1, 256, (MODE_ == I8_NO_MISSING ? 1 : 2), MODE_>>(FPCA_I8_ARGS)
@@ -816,6 +817,7 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
 #undef FPCA_I8_K3
 #undef FPCA_I8_ARGS
    HIP_CHECK_LAUNCH();
+   if (gemm_events) (void)hipEventRecord(gemm_events[1], stream);
    const unsigned blocks = (unsigned)std::min<uint64_t>(1024, (rows_pad + (256 / b) - 1) / (256 / b));
    hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, sh.zb, sh.rows, pl.nA, pl.sB, pl.rowB0, pl.rowsB, rows_pad, rows_valid, mode == I8_NO_MISSING ? 1 : 2, eplane, b, bw, S, wm, colsum_m,
                       mean, sd, out,

@@ -214,6 +214,8 @@ typedef struct fpca_bench_result {
    double ms_allreduce;  /* average per step in the all-reduce (0 for one rank) */
    double flops_per_step;           /* 4 N P_g b */
    double packed_bytes_per_step;    /* 2 ceil(N/4) P_g */
+   double ms_gemm_xt;    /* average per step of the K2 GEMM kernel launch alone */
+   double ms_gemm_x;     /* average per step of the K3 GEMM kernel launch alone */
 } fpca_bench_result;
 int fpca_bench_apply(fpca_ctx *ctx, int b, int steps, int warmup, fpca_bench_result *res);
 /* Live profiling of caller-driven applies: between fpca_profile_begin and fpca_profile_end every

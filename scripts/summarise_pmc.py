@@ -18,12 +18,15 @@ for wl in ("cfg2", "cfg3"):
             continue
         agg = collections.defaultdict(list)
         dur = collections.defaultdict(list)
-        for r in csv.DictReader(open(fs[0])):
+        rows = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Dispatch_Id"]))
+        gemm_ids = sorted({int(r["Dispatch_Id"]) for r in rows if "k_gemm_i8" in r["Kernel_Name"]})
+        gemm_rank = {d: i for i, d in enumerate(gemm_ids)}  # the int8 GEMM launches alternate K2, K3, K2, ... (one template)
+        for r in rows:
             name = r["Kernel_Name"]
             key = ("xt_b" if "k_xt_b" in name else "x_t" if "k_x_t" in name else "bed_stats" if "k_bed_stats" in name
                    else "reduce_sum" if "k_reduce_sum" in name
-                   else "gemm_i8_xt_b" if "k_gemm_i8" in name and "I8Cfg<false" in name
-                   else "gemm_i8_x_t" if "k_gemm_i8" in name and "I8Cfg<true" in name
+                   else ("gemm_i8_xt_b" if gemm_rank[int(r["Dispatch_Id"])] % 2 == 0 else "gemm_i8_x_t") if "k_gemm_i8" in name
+                   else "i8_sparse_rows_sum" if "k_sparse_rows_sum" in name
                    else "i8_combine" if "k_i8_combine" in name else "i8_slice" if "k_slice" in name else None)
             if key is None:
                 continue
