@@ -885,39 +885,47 @@ __global__ __launch_bounds__(256) void k_count_missing(const uint8_t *__restrict
    if (threadIdx.x == 0) cnt[blockIdx.x] = red[0];
 }
 
-// idx[ptr[r] ..] = ascending positions (< ncols) of the missing calls of record r; thread t scans a contiguous segment
+// idx[ptr[r] ..] = ascending positions (< ncols) of the missing calls of record r.  The record is walked in tiles of 256
+// dwords (coalesced), every thread owns one dword = 16 codes; a wave scan + 4 wave totals place each thread's hits.
 __global__ __launch_bounds__(256) void k_fill_missing(const uint8_t *__restrict__ packed, size_t pitch, uint64_t ncols,
                                                        const uint32_t *__restrict__ ptr, uint32_t *__restrict__ idx)
 {
-   const uint8_t *row = packed + (uint64_t)blockIdx.x * pitch;
-   const uint64_t nbytes = (ncols + 3) / 4;
-   const uint64_t seg = (nbytes + 255) / 256, b0 = threadIdx.x * seg, b1 = b0 + seg < nbytes ? b0 + seg : nbytes;
-   uint32_t n = 0;
-   for (uint64_t i = b0; i < b1; i++) {
-      const uint32_t w = row[i];
-      uint32_t m = w & ~(w >> 1) & 0x55u;
-      if (i == nbytes - 1 && (ncols & 3)) m &= (1u << (2 * (ncols & 3))) - 1u;
-      n += __popc(m);
-   }
-   __shared__ uint32_t scan[256];
-   scan[threadIdx.x] = n;
-   __syncthreads();
-   for (int o = 1; o < 256; o <<= 1) { // Hillis-Steele inclusive scan
-      const uint32_t v = (int)threadIdx.x >= o ? scan[threadIdx.x - o] : 0;
+   const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (uint64_t)blockIdx.x * pitch);
+   const uint64_t nw = (ncols + 15) / 16;
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   __shared__ uint32_t wsum[4];
+   uint32_t base = ptr[blockIdx.x];
+   for (uint64_t w0 = 0; w0 < nw; w0 += 256) {
+      const uint64_t w = w0 + threadIdx.x;
+      uint32_t m = 0;
+      if (w < nw) {
+         const uint32_t x = row[w];
+         m = x & ~(x >> 1) & 0x55555555u;
+         if (w == nw - 1 && (ncols & 15)) m &= (1u << (2 * (ncols & 15))) - 1u;
+      }
+      const uint32_t c = __popc(m);
+      uint32_t v = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+         const uint32_t t = __shfl_up(v, o);
+         if (lane >= o) v += t;
+      }
+      if (lane == 63) wsum[wave] = v;
       __syncthreads();
-      scan[threadIdx.x] += v;
-      __syncthreads();
-   }
-   uint32_t pos = ptr[blockIdx.x] + scan[threadIdx.x] - n;
-   for (uint64_t i = b0; i < b1; i++) {
-      const uint32_t w = row[i];
-      uint32_t m = w & ~(w >> 1) & 0x55u;
-      if (i == nbytes - 1 && (ncols & 3)) m &= (1u << (2 * (ncols & 3))) - 1u;
+      uint32_t woff = 0, total = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+         if (k < wave) woff += wsum[k];
+         total += wsum[k];
+      }
+      uint32_t pos = base + woff + v - c;
       while (m) {
          const int bit = __ffs(m) - 1;
-         idx[pos++] = (uint32_t)(i * 4 + bit / 2);
+         idx[pos++] = (uint32_t)(w * 16 + bit / 2);
          m &= m - 1;
       }
+      base += total;
+      __syncthreads();
    }
 }
 
