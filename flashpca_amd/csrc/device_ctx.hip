@@ -122,6 +122,8 @@ struct fpca_ctx {
    double *d_eplane = nullptr; // E'Q of the current stage, [max(N_pad, P_pad)][b]
    size_t eplane_cap = 0;
    bool sparse_ready = false;
+   hipStream_t aux_stream = nullptr; // the gather-sums run here, under the (MFMA-bound) GEMM of the same stage
+   hipEvent_t ev_aux_go = nullptr, ev_aux_done = nullptr;
    // communication
    ncclComm_t comm = nullptr;
    int nranks = 1, rank = 0;
@@ -237,6 +239,9 @@ void ctx_free(fpca_ctx *c)
    for (hipEvent_t e : c->ev_chunk)
       if (e) (void)hipEventDestroy(e);
    if (c->ev_comm_done) (void)hipEventDestroy(c->ev_comm_done);
+   if (c->ev_aux_go) (void)hipEventDestroy(c->ev_aux_go);
+   if (c->ev_aux_done) (void)hipEventDestroy(c->ev_aux_done);
+   if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
    if (c->stream) (void)hipStreamDestroy(c->stream);
    delete c;
@@ -383,6 +388,11 @@ int i8_mode(const fpca_ctx *c, int b)
    return rate < 3e-4 ? I8M_SKIP : I8M_FULL; // (block skipping: only where the sparse path does not apply)
 }
 
+// The gather-sum runs on the low-priority side stream, released together with the GEMM of its stage, when it is big enough
+// to be worth two event hand-offs (~30 us): measured 11.0 / 11.9 ms vs 11.9 / 12.2 ms at cfg3, but 0.338 / 0.360 vs
+// 0.306 / 0.334 ms at cfg2, where it stays inline.
+bool sparse_on_side_stream(const fpca_ctx *c, int b) { return (double)c->n_missing * b * 8.0 > 2e9; }
+
 // index lists of the missing calls, built once (by SNP from the SNP-major stream, by sample from the sample-major copy)
 void ensure_sparse(fpca_ctx *c, int b)
 {
@@ -395,6 +405,13 @@ void ensure_sparse(fpca_ctx *c, int b)
       c->eplane_cap = need;
    }
    if (c->sparse_ready) return;
+   {
+      int lo = 0, hi = 0; // lowest priority: the gather-sums should only fill what the GEMM's workgroups leave free
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      HIP_CHECK(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, lo));
+   }
+   HIP_CHECK(hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming));
+   HIP_CHECK(hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming));
    const uint64_t nnz = c->n_missing;
    std::vector<uint32_t> ptr(c->P_g + 1, 0);
    for (uint64_t j = 0; j < c->P_g; j++) ptr[j + 1] = ptr[j] + c->h_nmiss[j];
@@ -443,18 +460,26 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipE
 {
    kern::SliceOp ob = i8_op_b(c), ot[2];
    i8_ops_t(c, ot);
-   kern::i8_colmax(dB, c->N, b, 1, &ob, s);
-   kern::i8_slice(dB, c->N_pad, c->N, b, c->i8_S, 1, &ob, s);
    int mode = i8_mode(c, b);
    const double *eplane = nullptr;
-   if (mode == I8M_SPARSE) { // E'B: for every SNP the sum of the B rows of its missing samples
-      ensure_sparse(c, b);
-      kern::sparse_rows_sum(c->d_snp_ptr, c->d_snp_idx, dB, nullptr, b, c->P_g, c->P_pad, c->d_eplane, s);
+   hipEvent_t wait = nullptr;
+   kern::i8_colmax(dB, c->N, b, 1, &ob, s);
+   kern::i8_slice(dB, c->N_pad, c->N, b, c->i8_S, 1, &ob, s);
+   if (mode == I8M_SPARSE) { // E'B: for every SNP the sum of the B rows of its missing samples, on the (low-priority) side
+      ensure_sparse(c, b);  // stream, released together with the GEMM
+      if (sparse_on_side_stream(c, b)) {
+         HIP_CHECK(hipEventRecord(c->ev_aux_go, s));
+         HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_aux_go, 0));
+         kern::sparse_rows_sum(c->d_snp_ptr, c->d_snp_idx, dB, nullptr, b, c->P_g, c->P_pad, c->d_eplane, c->aux_stream);
+         HIP_CHECK(hipEventRecord(c->ev_aux_done, c->aux_stream));
+         wait = c->ev_aux_done;
+      } else
+         kern::sparse_rows_sum(c->d_snp_ptr, c->d_snp_idx, dB, nullptr, b, c->P_g, c->P_pad, c->d_eplane, s);
       eplane = c->d_eplane;
       mode = I8M_NONE;
    }
    kern::gemm_i8(c->d_packed, c->pitch, c->d_Qb, c->d_Qb, ob.colw, ob.colw, ob.colsum, c->d_mean, c->d_sd, c->d_T, c->d_i8ws, c->P_pad,
-                 c->N_pad, c->P_g, mode, eplane, b, c->i8_S, chain ? ot : nullptr, s, gev);
+                 c->N_pad, c->P_g, mode, eplane, b, c->i8_S, chain ? ot : nullptr, s, gev, wait);
 }
 
 // Row chunks of Y for the overlapped all-reduce (built-in communicator only): the all-reduce of chunk i runs on the
@@ -489,20 +514,28 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_
       kern::i8_slice(c->d_T, c->P_pad, c->P_g, b, c->i8_S, 2, ot, s);
       if (mode == I8M_SPARSE) { // E (mean T / sd): for every sample the sum of the scaled T rows of its missing SNPs
          ensure_sparse(c, b);
-         kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, c->d_T, c->d_mu_inv_sd, b, c->N, c->N_pad, c->d_eplane, s);
+         if (sparse_on_side_stream(c, b)) {
+            HIP_CHECK(hipEventRecord(c->ev_aux_go, s)); // T is complete on s here (and the K2 combine has consumed the plane)
+            HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_aux_go, 0));
+            kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, c->d_T, c->d_mu_inv_sd, b, c->N, c->N_pad, c->d_eplane, c->aux_stream);
+            HIP_CHECK(hipEventRecord(c->ev_aux_done, c->aux_stream));
+         } else
+            kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, c->d_T, c->d_mu_inv_sd, b, c->N, c->N_pad, c->d_eplane, s);
       }
    }
    if (r1 == 0) r1 = c->N_pad;
    if (r1 <= r0) return;
    const double *eplane = nullptr;
+   hipEvent_t wait = nullptr;
    if (mode == I8M_SPARSE) {
       eplane = c->d_eplane + r0 * b;
+      if (sparse_on_side_stream(c, b)) wait = c->ev_aux_done;
       mode = I8M_NONE;
    }
    // G.M alone: one operand (Qm is still sliced: its column sums are 1'Qm, and M'Qm = 1'Qm - E'Qm)
    kern::gemm_i8(c->d_packedT + r0 * c->pitchT, c->pitchT, c->d_Qg, mode == I8M_NONE ? c->d_Qg : c->d_Qm, ot[0].colw, ot[1].colw,
                  ot[1].colsum, nullptr, nullptr, dY + r0 * b, c->d_i8ws, r1 - r0, c->P_pad, c->N > r0 ? std::min(c->N - r0, r1 - r0) : 0, mode,
-                 eplane, b, c->i8_S, nullptr, s, gev);
+                 eplane, b, c->i8_S, nullptr, s, gev, wait);
 }
 
 // the operator on device-resident blocks: dY = X_g X_g' dB (+ all-reduce).  ev (optional): 4 events recorded

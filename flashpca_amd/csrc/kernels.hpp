@@ -99,7 +99,7 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
              const long long *colsum_m, const double *mean, const double *sd, double *out, double *ws, uint64_t rows_pad, uint64_t k_pad,
              uint64_t rows_valid, int mode /* 0 full, 1 skip E blocks without a missing genotype, 2 G.M alone */,
              const double *eplane /* with mode 2: E'Q [rows_pad][b] from sparse_rows_sum, or null if nothing is missing */, int b, int S,
-             const SliceOp *next_ops, hipStream_t stream, hipEvent_t *gemm_events = nullptr);
+             const SliceOp *next_ops, hipStream_t stream, hipEvent_t *gemm_events = nullptr, hipEvent_t before_combine = nullptr);
 // index lists of the missing calls of 2-bit records (positions < ncols), and the gather-sum over them
 void count_missing(const uint8_t *packed, size_t pitch, uint64_t ncols, uint64_t nrec, uint32_t *cnt, hipStream_t stream);
 void fill_missing(const uint8_t *packed, size_t pitch, uint64_t ncols, uint64_t nrec, const uint32_t *ptr, uint32_t *idx, hipStream_t stream);

@@ -773,7 +773,8 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
              const long long *colsum_m, const double *mean, const double *sd, double *out, double *ws, uint64_t rows_pad, uint64_t k_pad,
              uint64_t rows_valid, int mode, const double *eplane /* I8_NO_MISSING kernel + E'Q computed elsewhere, or null */, int b,
              int S, const SliceOp *next_ops /* null, or the two operands whose column maxima the combine should leave */,
-             hipStream_t stream, hipEvent_t *gemm_events /* null, or 2 events recorded around the GEMM kernel itself */)
+             hipStream_t stream, hipEvent_t *gemm_events /* null, or 2 events recorded around the GEMM kernel itself */,
+             hipEvent_t before_combine /* null, or an event the combine must wait for (eplane produced on another stream) */)
 {
    const bool two = (Qg != Qm);
    const I8Shape sh = i8_shape(S, b, two, mode);
@@ -818,6 +819,7 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
 #undef FPCA_I8_ARGS
    HIP_CHECK_LAUNCH();
    if (gemm_events) (void)hipEventRecord(gemm_events[1], stream);
+   if (before_combine) (void)hipStreamWaitEvent(stream, before_combine, 0);
    const unsigned blocks = (unsigned)std::min<uint64_t>(1024, (rows_pad + (256 / b) - 1) / (256 / b));
    hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, sh.zb, sh.rows, pl.nA, pl.sB, pl.rowB0, pl.rowsB, rows_pad, rows_valid, mode == I8_NO_MISSING ? 1 : 2, eplane, b, bw, S, wm, colsum_m,
                       mean, sd, out,
