@@ -652,18 +652,22 @@ class HipBackend : public BlockBackend {
    {
       HIP_CHECK(hipSetDevice(c->device));
       ensure_stats(c);
-      nsplit_gram_ = kern::gram_splits(c->N_pad);
       HIP_CHECK(hipMalloc(&d_ptrs_, 1024 * sizeof(double *)));
       HIP_CHECK(hipEventCreate(&e0_));
       HIP_CHECK(hipEventCreate(&e1_));
+      HIP_CHECK(hipEventCreateWithFlags(&ev_pin_, hipEventDisableTiming));
+      (void)pin_coeff((size_t)16 * b * b);
    }
    ~HipBackend() override
    {
+      (void)hipStreamSynchronize(c_->stream);
       for (double *p : blocks_)
          if (p) (void)hipFree(p);
       if (d_ptrs_) (void)hipFree(d_ptrs_);
       if (d_C_) (void)hipFree(d_C_);
       if (d_gpart_) (void)hipFree(d_gpart_);
+      if (h_pin_) (void)hipHostFree(h_pin_);
+      (void)hipEventDestroy(ev_pin_);
       (void)hipEventDestroy(e0_);
       (void)hipEventDestroy(e1_);
    }
@@ -695,25 +699,46 @@ class HipBackend : public BlockBackend {
       HIP_CHECK(hipEventElapsedTime(&ms, e0_, e1_));
       sec_apply_ += ms * 1e-3;
    }
+   // Host <-> device traffic of the small matrices goes through one pinned buffer ([1024 pointers][coefficients]); the
+   // event marks the last asynchronous read of it, so a call never overwrites what an earlier copy has not picked up.
+   void pin_wait()
+   {
+      if (pin_busy_) HIP_CHECK(hipEventSynchronize(ev_pin_));
+      pin_busy_ = false;
+   }
+   double *pin_coeff(size_t cnt)
+   {
+      pin_wait();
+      if (cnt > pin_cap_) {
+         if (h_pin_) HIP_CHECK(hipHostFree(h_pin_));
+         h_pin_ = nullptr;
+         pin_cap_ = std::max(cnt, 2 * pin_cap_);
+         HIP_CHECK(hipHostMalloc(&h_pin_, 1024 * sizeof(double *) + pin_cap_ * sizeof(double), hipHostMallocDefault));
+      }
+      return reinterpret_cast<double *>(static_cast<char *>(h_pin_) + 1024 * sizeof(double *));
+   }
    void push_ptrs(const int *a, int nq)
    {
       if (nq > 1024) throw Error(FPCA_EINVAL, "too many basis blocks");
-      std::vector<const double *> hp(nq);
+      const double **hp = static_cast<const double **>(h_pin_);
       for (int q = 0; q < nq; q++) hp[q] = blocks_[a[q]];
-      HIP_CHECK(hipMemcpyAsync(d_ptrs_, hp.data(), nq * sizeof(double *), hipMemcpyHostToDevice, c_->stream));
+      HIP_CHECK(hipMemcpyAsync(d_ptrs_, hp, nq * sizeof(double *), hipMemcpyHostToDevice, c_->stream));
    }
    void gram(const int *a, int nq, int w, double *C) override
    {
       auto t0 = std::chrono::steady_clock::now();
       const size_t cnt = (size_t)nq * b_ * b_;
-      const int ns = nsplit_gram_ * 4;
+      const int rows = kern::gram_rows(c_->N_pad, nq);
+      const int ns = kern::gram_splits(c_->N_pad, rows) * 4;
       grow(d_gpart_, gpart_cap_, cnt * ns);
       grow(d_C_, C_cap_, std::max(cnt, (size_t)1024 * b_ * 4));
+      double *hc = pin_coeff(cnt);
       push_ptrs(a, nq);
-      kern::gram(d_ptrs_, nq, blocks_[w], d_gpart_, c_->N_pad, b_, nsplit_gram_, c_->stream);
+      kern::gram(d_ptrs_, nq, blocks_[w], d_gpart_, c_->N_pad, b_, rows, c_->stream);
       kern::reduce_sum(d_gpart_, d_C_, cnt, ns, c_->stream);
-      HIP_CHECK(hipMemcpyAsync(C, d_C_, cnt * sizeof(double), hipMemcpyDeviceToHost, c_->stream));
+      HIP_CHECK(hipMemcpyAsync(hc, d_C_, cnt * sizeof(double), hipMemcpyDeviceToHost, c_->stream));
       HIP_CHECK(hipStreamSynchronize(c_->stream));
+      std::memcpy(C, hc, cnt * sizeof(double));
       sec_other_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
    }
    void gemm(const int *a, int nq, const double *C, int init, int out) override
@@ -721,11 +746,14 @@ class HipBackend : public BlockBackend {
       auto t0 = std::chrono::steady_clock::now();
       const size_t cnt = (size_t)nq * b_ * b_;
       grow(d_C_, C_cap_, std::max(cnt, (size_t)1024 * b_ * 4));
+      double *hc = pin_coeff(cnt);
+      std::memcpy(hc, C, cnt * sizeof(double));
       push_ptrs(a, nq);
-      HIP_CHECK(hipMemcpyAsync(d_C_, C, cnt * sizeof(double), hipMemcpyHostToDevice, c_->stream));
+      HIP_CHECK(hipMemcpyAsync(d_C_, hc, cnt * sizeof(double), hipMemcpyHostToDevice, c_->stream));
+      HIP_CHECK(hipEventRecord(ev_pin_, c_->stream));
+      pin_busy_ = true;
+      // not drained: d_C_ / d_ptrs_ are only rewritten by later copies on this same stream, i.e. after the kernel
       kern::block_gemm(d_ptrs_, nq, d_C_, init >= 0 ? blocks_[init] : nullptr, blocks_[out], c_->N_pad, b_, c_->stream);
-      // d_C_/d_ptrs_ are reused by the next call: keep it simple and drain here (the kernel is HBM-bound, short)
-      HIP_CHECK(hipStreamSynchronize(c_->stream));
       sec_other_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
    }
    void download(int h, int ncols, double *host, int64_t ld) override
@@ -762,20 +790,24 @@ class HipBackend : public BlockBackend {
    void grow(double *&p, size_t &cap, size_t need)
    {
       if (need <= cap) return;
+      HIP_CHECK(hipStreamSynchronize(c_->stream));
       if (p) HIP_CHECK(hipFree(p));
       p = nullptr;
+      need = std::max(need, 2 * cap); // geometric: the basis grows by one block per step
       HIP_CHECK(hipMalloc(&p, need * sizeof(double)));
       cap = need;
    }
    fpca_ctx *c_;
    int b_;
-   int nsplit_gram_ = 1;
    std::vector<double *> blocks_;
    std::vector<unsigned char> used_;
    const double **d_ptrs_ = nullptr;
    double *d_C_ = nullptr, *d_gpart_ = nullptr;
    size_t C_cap_ = 0, gpart_cap_ = 0;
-   hipEvent_t e0_, e1_;
+   void *h_pin_ = nullptr;
+   size_t pin_cap_ = 0;
+   bool pin_busy_ = false;
+   hipEvent_t e0_, e1_, ev_pin_;
    double sec_apply_ = 0, sec_other_ = 0;
 };
 

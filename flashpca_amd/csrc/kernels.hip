@@ -666,10 +666,47 @@ __global__ __launch_bounds__(256) void k_reduce_sum(const d2 *__restrict__ part,
    }
 }
 
+// Tall stacks of small planes (the Gram partials: hundreds of planes of a few b x b blocks): a block owns 8 consecutive
+// 16-byte elements, 32 thread groups stride over the planes with four loads in flight each, and the groups are folded
+// in a fixed order through LDS (deterministic for a given nsplit).
+__global__ __launch_bounds__(256) void k_reduce_tall(const d2 *__restrict__ part, d2 *__restrict__ out, uint64_t count2, int nsplit)
+{
+   __shared__ d2 sh[32][8];
+   const int e = threadIdx.x & 7, g = threadIdx.x >> 3;
+   const uint64_t i = (uint64_t)blockIdx.x * 8 + e;
+   d2 s0 = (d2){0.0, 0.0}, s1 = s0, s2 = s0, s3 = s0;
+   if (i < count2) {
+      int k = g;
+      for (; k + 96 < nsplit; k += 128) {
+         const d2 a0 = part[(uint64_t)k * count2 + i], a1 = part[(uint64_t)(k + 32) * count2 + i];
+         const d2 a2 = part[(uint64_t)(k + 64) * count2 + i], a3 = part[(uint64_t)(k + 96) * count2 + i];
+         s0 += a0;
+         s1 += a1;
+         s2 += a2;
+         s3 += a3;
+      }
+      for (; k < nsplit; k += 32) s0 += part[(uint64_t)k * count2 + i];
+   }
+   sh[g][e] = (s0 + s1) + (s2 + s3);
+   __syncthreads();
+   if (g == 0 && i < count2) {
+      d2 t = sh[0][e];
+#pragma unroll
+      for (int j = 1; j < 32; j++) t += sh[j][e];
+      out[i] = t;
+   }
+}
+
 void reduce_sum(const double *part, double *out, uint64_t count, int nsplit, hipStream_t stream)
 {
    if (count == 0) return;
    const uint64_t count2 = count / 2; // all our buffers have even element counts
+   if (nsplit >= 64 && count2 <= (1u << 16)) {
+      hipLaunchKernelGGL(k_reduce_tall, dim3((unsigned)((count2 + 7) / 8)), dim3(256), 0, stream, reinterpret_cast<const d2 *>(part),
+                         reinterpret_cast<d2 *>(out), count2, nsplit);
+      HIP_CHECK_LAUNCH();
+      return;
+   }
    uint64_t blocks = (count2 + 511) / 512;
    if (blocks > 2048) blocks = 2048;
    if (blocks == 0) blocks = 1;
@@ -991,19 +1028,26 @@ __global__ __launch_bounds__(256) void k_gram(const double *const *__restrict__ 
          for (int r = 0; r < 4; r++) out[(size_t)(pt * 16 + kq + 4 * r) * b + nt * 16 + li] = acc[pt][nt][r];
 }
 
-static constexpr int GRAM_ROWS = 2048;
-int gram_splits(uint64_t N_pad) { return (int)((N_pad + GRAM_ROWS - 1) / GRAM_ROWS); }
+// Rows per workgroup: enough workgroups to fill the chip several times over (nq blocks x splits >= ~1024) without making
+// the stack of partial planes (4 per workgroup) taller than it has to be.
+int gram_rows(uint64_t N_pad, int nq)
+{
+   uint64_t rows = 8192;
+   while (rows > 256 && (N_pad + rows - 1) / rows * (uint64_t)(nq > 0 ? nq : 1) < 1024) rows /= 2;
+   return (int)rows;
+}
 
-void gram(const double *const *blocks, int nq, const double *W, double *part, uint64_t N_pad, int b, int nsplit,
-          hipStream_t stream)
+int gram_splits(uint64_t N_pad, int rows) { return (int)((N_pad + rows - 1) / rows); }
+
+void gram(const double *const *blocks, int nq, const double *W, double *part, uint64_t N_pad, int b, int rows, hipStream_t stream)
 {
    if (nq <= 0) return;
-   dim3 grid((unsigned)nsplit, (unsigned)nq);
+   dim3 grid((unsigned)gram_splits(N_pad, rows), (unsigned)nq);
    switch (b) {
-   case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<1>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, GRAM_ROWS, nq); break;
-   case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<2>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, GRAM_ROWS, nq); break;
-   case 48: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<3>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, GRAM_ROWS, nq); break;
-   case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<4>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, GRAM_ROWS, nq); break;
+   case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<1>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, rows, nq); break;
+   case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<2>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, rows, nq); break;
+   case 48: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<3>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, rows, nq); break;
+   case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<4>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, rows, nq); break;
    default: throw Error(-1, "gram: block width must be 16, 32, 48 or 64");
    }
    HIP_CHECK_LAUNCH();

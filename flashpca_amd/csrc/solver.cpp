@@ -148,7 +148,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    V.push_back(v0);
    int W = be.alloc_block();
    double scale = 0; // running estimate of ||A|| (largest Ritz value)
-   std::vector<double> S; // eigenvectors of T (n x n, ld n)
+   std::vector<double> S, Srow; // eigenvectors of T (n x n, ld n; only when needed) / their last b rows (b x n)
    int n = 0;
    uint64_t reseed = o.seed * 7919 + 13;
 
@@ -254,8 +254,11 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
             Tat((m - 1) * b + p, (m - 1) * b + c) = h;
          }
       for (int j = 0; j < n; j++) std::memcpy(&Tw[(size_t)j * n], &T[(size_t)j * nmax], sizeof(double) * n);
-      if (symeig_desc(n, Tw.data(), n, theta.data()) != 0) throw Error(-3, "solver: projected eigensolver failed");
-      S.assign(Tw.begin(), Tw.begin() + (size_t)n * n);
+      // eigenvalues + the last block of rows of the eigenvectors (all the residual test needs); the full
+      // eigenvector matrix is formed only when it is used: convergence, thick restart, last step
+      Srow.resize((size_t)b * n);
+      if (symeig_desc_rows(n, Tw.data(), n, theta.data(), (m - 1) * b, b, Srow.data()) != 0)
+         throw Error(-3, "solver: projected eigensolver failed");
       scale = std::max(scale, std::fabs(theta[0]));
       // residual estimates: || R * S[(m-1)b : mb, i] ||
       res.residuals.assign(k, 0.0);
@@ -263,7 +266,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       bool all_conv = true;
       double worst = 0;
       for (int i = 0; i < k; i++) {
-         const double *s = &S[(size_t)(m - 1) * b + (size_t)i * n];
+         const double *s = &Srow[(size_t)i * b];
          double r2 = 0;
          for (int r = 0; r < b; r++) {
             double acc = 0;
@@ -277,6 +280,11 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          if (!(rn < thr)) all_conv = false;
       }
       res.max_rel_residual = worst;
+      if (all_conv || res.block_applies >= o.max_applies || m + 1 > mcap) {
+         for (int j = 0; j < n; j++) std::memcpy(&Tw[(size_t)j * n], &T[(size_t)j * nmax], sizeof(double) * n);
+         if (symeig_desc(n, Tw.data(), n, theta.data()) != 0) throw Error(-3, "solver: projected eigensolver failed");
+         S.assign(Tw.begin(), Tw.begin() + (size_t)n * n);
+      }
       host_s += since(t0);
       if (o.verbose)
          std::fprintf(stderr, "[fpca] apply %3d  basis %4d  theta1 %.6g  theta_k %.6g  max rel resid %.3e\n",

@@ -14,7 +14,8 @@ namespace fpca {
 namespace {
 
 // A = Q T Q', T tridiagonal (d, e).  On return A holds Q (column-major).
-void tridiagonalise(int n, double *A, int lda, double *d, double *e)
+// With rows != nullptr Q is not formed: rows (nrows x n, ld nrows) receives rows row0..row0+nrows-1 of Q instead.
+void tridiagonalise(int n, double *A, int lda, double *d, double *e, int row0 = 0, int nrows = 0, double *rows = nullptr)
 {
 #define AA(i, j) A[(size_t)(i) + (size_t)(j) * lda]
    std::vector<double> v(n), p(n), beta(n, 0.0);
@@ -67,6 +68,29 @@ void tridiagonalise(int n, double *A, int lda, double *d, double *e)
       e[n - 2] = AA(n - 1, n - 2);
    }
    d[n - 1] = AA(n - 1, n - 1);
+   if (rows) {
+      // e_r' Q = e_r' H_0 H_1 ... H_{n-3}: the reflectors applied to unit rows, front to back
+      for (int j = 0; j < n; j++)
+         for (int r = 0; r < nrows; r++) rows[(size_t)r + (size_t)j * nrows] = (j == row0 + r) ? 1.0 : 0.0;
+      std::vector<double> s(nrows);
+      for (int k = 0; k < n - 2; k++) {
+         if (beta[k] == 0.0) continue;
+         const int m = n - k - 1;
+         v[0] = 1.0;
+         for (int i = 1; i < m; i++) v[i] = AA(k + 1 + i, k);
+         std::fill(s.begin(), s.end(), 0.0);
+         for (int i = 0; i < m; i++) {
+            const double *col = &rows[(size_t)(k + 1 + i) * nrows];
+            for (int r = 0; r < nrows; r++) s[r] += col[r] * v[i];
+         }
+         for (int i = 0; i < m; i++) {
+            double *col = &rows[(size_t)(k + 1 + i) * nrows];
+            const double bv = beta[k] * v[i];
+            for (int r = 0; r < nrows; r++) col[r] -= s[r] * bv;
+         }
+      }
+      return;
+   }
    // accumulate Q = H_0 H_1 ... H_{n-3} into A (overwriting the reduced matrix), back to front
    std::vector<double> Q((size_t)n * n, 0.0);
    for (int i = 0; i < n; i++) Q[(size_t)i + (size_t)i * n] = 1.0;
@@ -88,8 +112,27 @@ void tridiagonalise(int n, double *A, int lda, double *d, double *e)
 #undef AA
 }
 
+// sqrt(a^2 + b^2) without the cost of std::hypot's correct rounding (called once per rotation); the operands are
+// entries of a tridiagonal matrix, scaled through the larger one so that tiny couplings do not underflow
+static inline double pythag(double a, double b)
+{
+   const double x = std::fabs(a), y = std::fabs(b);
+   const double hi = x > y ? x : y, lo = x > y ? y : x;
+   if (hi == 0.0) return 0.0;
+   const double r = lo / hi;
+   return hi * std::sqrt(1.0 + r * r);
+}
+
+// the same on the rotation chain of the QL sweep, where its latency is what the sweep costs: the plain formula whenever
+// the squares are safely inside the double range
+static inline double pythag_fast(double a, double b)
+{
+   const double h = a * a + b * b;
+   return (h > 1e-280 && h < 1e280) ? std::sqrt(h) : pythag(a, b);
+}
+
 // implicit-shift QL on (d, e) accumulating the rotations into the columns of Z (n x n, ld ldz)
-int tridiag_ql(int n, double *d, double *e_in, double *Z, int ldz)
+int tridiag_ql(int n, double *d, double *e_in, double *Z, int ldz, int zrows)
 {
    std::vector<double> e(n + 1, 0.0);
    for (int i = 0; i < n - 1; i++) e[i] = e_in[i];
@@ -103,29 +146,30 @@ int tridiag_ql(int n, double *d, double *e_in, double *Z, int ldz)
          if (m != l) {
             if (iter++ == 300) return 1;
             double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-            double r = std::hypot(g, 1.0);
+            double r = pythag(g, 1.0);
             g = d[m] - d[l] + e[l] / (g + std::copysign(r, g));
             double s = 1.0, c = 1.0, p = 0.0;
             int i;
             for (i = m - 1; i >= l; i--) {
                double f = s * e[i];
                const double bb = c * e[i];
-               r = std::hypot(f, g);
+               r = pythag_fast(f, g);
                e[i + 1] = r;
                if (r == 0.0) {
                   d[i + 1] -= p;
                   e[m] = 0.0;
                   break;
                }
-               s = f / r;
-               c = g / r;
+               const double rinv = 1.0 / r;
+               s = f * rinv;
+               c = g * rinv;
                g = d[i + 1] - p;
                r = (d[i] - g) * s + 2.0 * c * bb;
                p = s * r;
                d[i + 1] = g + p;
                g = c * r - bb;
                double *z0 = Z + (size_t)i * ldz, *z1 = Z + (size_t)(i + 1) * ldz;
-               for (int k = 0; k < n; k++) {
+               for (int k = 0; k < zrows; k++) {
                   f = z1[k];
                   z1[k] = s * z0[k] + c * f;
                   z0[k] = c * z0[k] - s * f;
@@ -153,7 +197,7 @@ int symeig_desc(int n, double *A, int lda, double *w)
    }
    std::vector<double> d(n), e(n, 0.0);
    tridiagonalise(n, A, lda, d.data(), e.data());
-   int rc = tridiag_ql(n, d.data(), e.data(), A, lda);
+   int rc = tridiag_ql(n, d.data(), e.data(), A, lda, n);
    if (rc) return rc;
    std::vector<int> idx(n);
    std::iota(idx.begin(), idx.end(), 0);
@@ -164,6 +208,28 @@ int symeig_desc(int n, double *A, int lda, double *w)
       std::memcpy(&Z[(size_t)j * n], A + (size_t)idx[j] * lda, sizeof(double) * n);
    }
    for (int j = 0; j < n; j++) std::memcpy(A + (size_t)j * lda, &Z[(size_t)j * n], sizeof(double) * n);
+   return 0;
+}
+
+int symeig_desc_rows(int n, double *A, int lda, double *w, int row0, int nrows, double *Zr)
+{
+   if (n <= 0) return 0;
+   if (n == 1) {
+      w[0] = A[0];
+      if (nrows > 0) Zr[0] = 1.0;
+      return 0;
+   }
+   std::vector<double> d(n), e(n, 0.0), rows((size_t)nrows * n);
+   tridiagonalise(n, A, lda, d.data(), e.data(), row0, nrows, rows.data());
+   int rc = tridiag_ql(n, d.data(), e.data(), rows.data(), nrows, nrows);
+   if (rc) return rc;
+   std::vector<int> idx(n);
+   std::iota(idx.begin(), idx.end(), 0);
+   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return d[a] > d[b]; });
+   for (int j = 0; j < n; j++) {
+      w[j] = d[idx[j]];
+      std::memcpy(Zr + (size_t)j * nrows, &rows[(size_t)idx[j] * nrows], sizeof(double) * nrows);
+   }
    return 0;
 }
 

@@ -11,6 +11,11 @@ namespace fpca {
 // Returns 0 on success, nonzero if the QL iteration failed to converge.
 int symeig_desc(int n, double *A, int lda, double *w);
 
+// Same eigenvalues, but only rows row0..row0+nrows-1 of the eigenvector matrix: Zr (nrows x n, ld nrows), column j
+// belonging to w[j].  A is destroyed.  O(4/3 n^3) instead of O(6 n^3): the Krylov residual test needs only the last
+// block of rows.
+int symeig_desc_rows(int n, double *A, int lda, double *w, int row0, int nrows, double *Zr);
+
 // Upper Cholesky factor: G = R' R, R overwrites the upper triangle of G (strict lower part zeroed).
 // Returns 0 on success, j+1 if the pivot of column j is not sufficiently positive (relative to rel_tol *
 // the largest original diagonal entry).

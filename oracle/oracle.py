@@ -21,10 +21,8 @@ _dpc = C.POINTER(C.c_double)
 
 
 def build(force=False):
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(
-        os.path.join(HERE, "fpca_oracle.c")
-    ):
-        subprocess.check_call(["make", "-C", HERE, "-s"])
+    """make decides what is stale (the host-simulation library also depends on the product's solver sources)."""
+    subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))
     return LIB_PATH
 
 
