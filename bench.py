@@ -14,7 +14,7 @@ every rank holds its own 20,000-SNP shard of a (20,000 * N)-SNP matrix, generate
 `--workload cfg3` selects the 500,000 x 100,000 paper-headline matrix (configs[2]/[3], SNP-sharded = strong).
 
 Arithmetic: `--accum i8` (default; the product's default FPCA_ACCUM_AUTO resolves to it) runs the two GEMMs on the int8 matrix
-cores -- integer genotype matrices x 7-bit slices of the fp64 operand, exact int32 accumulation, fp64 recombination
+cores -- integer genotype matrices x byte slices of the fp64 operand, exact int32 accumulation, fp64 recombination
 -- with results equal to the fp64 MFMA kernels (`--accum fp64`) to ~3e-15; the line carries the other mode's timing and the
 measured difference between the two as `fp64_mode` / `exact_int8_mode`.
 
@@ -54,8 +54,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--accum", default="i8", choices=["fp64", "fp32", "i8"] + ["i8x%d" % s for s in range(4, 10)],
-                    help="i8[xS] (default: the product's default mode) = exact-integer int8 MFMA on S (default 8) 7-bit slices of the "
+    ap.add_argument("--accum", default="i8", choices=["fp64", "fp32", "i8"] + ["i8x%d" % s for s in range(4, 9)],
+                    help="i8[xS] (default: the product's default mode) = exact-integer int8 MFMA on S (default 7) byte slices of the "
                          "fp64 operand, results equal to the fp64 path; fp64 = v_mfma_f64; fp32 = v_mfma_f32 products, fp64 long "
                          "accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,7 +186,7 @@ def main():
                     flops_per_launch=flops_launch,
                     packed_gbs=((N + 3) // 4) * P_rank / (ms_dom * 1e-3) / 1e9)
     if args.accum.startswith("i8"):
-        S = int(args.accum[3:]) if len(args.accum) > 2 else 8
+        S = int(args.accum[3:]) if len(args.accum) > 2 else 7
         mm = ctx.missing_mode(b)  # 0/1: two integer matrices on the matrix cores; 2/3: G.M alone (+ sparse gathers for E)
         nmat = 1 if mm in (2, 3) else 2
         ops_launch = nmat * flops_launch * S  # integer matrices x S slices of every operand column
@@ -219,7 +219,7 @@ def main():
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
                scaling=w["scaling"], vs_baseline=None,
                dtype={"fp64": "f64", "fp32": "f32 (fp64 long accumulation)"}.get(
-                   args.accum, "i8 (integer genotypes x 7-bit slices of the f64 operand; exact i32 accumulation, f64 recombination; "
+                   args.accum, "i8 (integer genotypes x 7 byte slices of the f64 operand; exact i32 accumulation, f64 recombination; "
                                "agrees with the f64 kernels to ~3e-15, see fp64_mode)"),
                data="synthetic",
                config=dict(workload=args.workload + ": " + w["desc"], samples=N, snps_total=P_total, snps_per_gpu=P_rank,
@@ -262,7 +262,7 @@ def main():
             diff = float(torch.max(torch.abs(Y2 - Y)).item())
             ms2 = max(p2["ms_gemm_xt"], p2["ms_gemm_x"])
             if other == "i8":
-                ops = (1 if c2.missing_mode(b) in (2, 3) else 2) * flops_launch * 8
+                ops = (1 if c2.missing_mode(b) in (2, 3) else 2) * flops_launch * 7
                 rf = dict(bound="mfma", achieved=ops / (ms2 * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s",
                           frac=ops / (ms2 * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, peak_measured_pure_mfma_stream=3576.0)
             else:

@@ -13,9 +13,9 @@ from . import _lib
 from ._lib import DIVISOR, STANDARDISE, BenchResult, FpcaError, PcaInfo, PcaOpts, check, lib  # noqa: F401
 
 
-ACCUM = {"auto": 0, 0: 0, "fp64": 64, "fp32": 32, 64: 64, 32: 32, "i8": 808}
-ACCUM.update({"i8x%d" % s: 800 + s for s in range(2, 10)})
-ACCUM.update({800 + s: 800 + s for s in range(2, 10)})
+ACCUM = {"auto": 0, 0: 0, "fp64": 64, "fp32": 32, 64: 64, 32: 32, "i8": 807}
+ACCUM.update({"i8x%d" % s: 800 + s for s in range(2, 9)})
+ACCUM.update({800 + s: 800 + s for s in range(2, 9)})
 
 
 def _p(a):

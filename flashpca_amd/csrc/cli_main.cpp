@@ -83,7 +83,7 @@ const OptSpec OPTS[] = {
    {"device", 0, true, "HIP device index [0]"},
    {"blockvec", 0, true, "block width of the eigensolver: 16, 32, 48 or 64 [smallest multiple of 16 >= ndim+4]"},
    {"maxblocks", 0, true, "basis cap (in blocks) before a thick restart [automatic]"},
-   {"accum", 0, true, "arithmetic of the two genotype GEMMs [auto | fp64 | fp32 | i8 | i8xS]: i8 = exact-integer int8 MFMA on S = 8 (i8xS: S = 2..9) 7-bit slices of the fp64 operand, results equal to fp64; fp32 = fp32 MFMA products, fp64 long accumulation; auto (default) = i8, or fp64 if the int8 buffers do not fit"},
+   {"accum", 0, true, "arithmetic of the two genotype GEMMs [auto | fp64 | fp32 | i8 | i8xS]: i8 = exact-integer int8 MFMA on S = 7 (i8xS: S = 2..8) byte slices of the fp64 operand, results equal to fp64; fp32 = fp32 MFMA products, fp64 long accumulation; auto (default) = i8, or fp64 if the int8 buffers do not fit"},
 };
 
 const OptSpec *find_long(const std::string &n)
@@ -369,8 +369,8 @@ int main(int argc, char *argv[])
          if (m == "auto") accum = FPCA_ACCUM_AUTO;
          else if (m == "fp64") accum = FPCA_ACCUM_FP64;
          else if (m == "fp32") accum = FPCA_ACCUM_FP32;
-         else if (m == "i8") accum = FPCA_ACCUM_I8(8);
-         else if (m.size() == 4 && m.compare(0, 3, "i8x") == 0 && m[3] >= '2' && m[3] <= '9') accum = FPCA_ACCUM_I8(m[3] - '0');
+         else if (m == "i8") accum = FPCA_ACCUM_I8(7);
+         else if (m.size() == 4 && m.compare(0, 3, "i8x") == 0 && m[3] >= '2' && m[3] <= '8') accum = FPCA_ACCUM_I8(m[3] - '0');
          else {
             std::cerr << "Error: unknown accumulate mode (--accum): " << m << std::endl;
             return EXIT_FAILURE;

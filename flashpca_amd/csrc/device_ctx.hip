@@ -166,13 +166,13 @@ void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int devi
       throw Error(FPCA_EINVAL, "unknown standardization method"); // util.cpp:183
    if (accum == FPCA_ACCUM_AUTO) {
       // the exact-integer path when it applies (2-bit input, int32-safe sizes), else the fp64 MFMA path
-      const bool fits = !dense && std::max<uint64_t>(N, P_g) <= (uint64_t)15000000;
-      accum = fits ? FPCA_ACCUM_I8(8) : FPCA_ACCUM_FP64;
+      const bool fits = !dense && std::max<uint64_t>(N, P_g) <= (uint64_t)8000000;
+      accum = fits ? FPCA_ACCUM_I8(7) : FPCA_ACCUM_FP64;
       c->i8_auto = fits;
    }
-   const bool i8 = accum >= FPCA_ACCUM_I8(2) && accum <= FPCA_ACCUM_I8(9);
+   const bool i8 = accum >= FPCA_ACCUM_I8(2) && accum <= FPCA_ACCUM_I8(8);
    if (accum != FPCA_ACCUM_FP64 && accum != FPCA_ACCUM_FP32 && !i8)
-      throw Error(FPCA_EINVAL, "accum must be FPCA_ACCUM_AUTO, FPCA_ACCUM_FP64, FPCA_ACCUM_FP32 or FPCA_ACCUM_I8(2..9)");
+      throw Error(FPCA_EINVAL, "accum must be FPCA_ACCUM_AUTO, FPCA_ACCUM_FP64, FPCA_ACCUM_FP32 or FPCA_ACCUM_I8(2..8)");
    if (i8 && dense) throw Error(FPCA_EINVAL, "the int8-sliced mode needs 2-bit genotype input");
    int ndev = 0;
    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -316,9 +316,9 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
 {
    hipStream_t s = c->stream;
    if (getenv("FPCA_DEBUG_I8_NOMEM")) throw Error(FPCA_ENOMEM, "FPCA_DEBUG_I8_NOMEM is set"); // exercises the fallback in the tests
-   // exact int32 accumulation: |sum| <= 2 * 64 * K must stay below 2^31
-   if (std::max(c->N_pad, c->P_pad) > (uint64_t)16000000)
-      throw Error(FPCA_EINVAL, "the int8-sliced mode supports up to 16,000,000 samples and SNPs per GPU (int32 accumulation)");
+   // exact int32 accumulation: |sum| <= 2 * 128 * K must stay below 2^31
+   if (std::max(c->N_pad, c->P_pad) > (uint64_t)8380000)
+      throw Error(FPCA_EINVAL, "the int8-sliced mode supports up to 8,380,000 samples and SNPs per GPU (int32 accumulation)");
    if (!c->i8_transposed) {
       c->pitchT = (size_t)c->P_pad / 4;
       if (!c->d_inv_sd) HIP_CHECK(hipMalloc(&c->d_inv_sd, c->P_pad * sizeof(double)));

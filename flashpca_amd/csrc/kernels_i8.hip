@@ -4,12 +4,13 @@
 // "not missing" flag, so
 //     T = X' B = diag(1/sigma) [ (G.M)' B  -  diag(mu) M' B ]           (K2)
 //     Y = X T  = (G.M) (T / sigma)  -  M (mu T / sigma)                  (K3)
-// where G.M and M are tiny integers.  The fp64 operand (B, resp. T/sigma and mu T/sigma) is split per column into S
-// signed 7-bit slices sharing one power-of-two scale (q = d_0/64 + d_1/(64*128) + ..., |d_s| <= 64, remainder
-// < 2^-7S dropped), and the products run on v_mfma_i32_32x32x32_i8 with EXACT int32 accumulation (|sum| <= 128 N).
-// The only rounding of the whole product is the 2^-7S truncation of the fp64 operand and the fp64 recombination of the
-// S exact slice sums (once per split-K part) -- nothing accumulates along K -- so S = 8 (56 bits) is fp64-equivalent
-// while the int8 MFMA issues 64x the multiply-adds per cycle of the fp64 one for 16x as many of them.
+// where G.M and M are tiny integers.  The fp64 operand (B, resp. T/sigma and mu T/sigma) is rounded per column to a
+// (8S-2)-bit fixed-point number sharing one power-of-two scale (m = rint(v 2^(8S-2-e)), 2^e > max|column|) and cut into
+// its S two's-complement bytes (m = sum_i d_i 256^i, d_i in [-128, 127], the top one within +-65): full 8-bit digits,
+// so S = 7 keeps 54 bits below the column maximum.  The products run on v_mfma_i32_32x32x32_i8 with EXACT int32
+// accumulation (|sum| <= 256 K).  The only rounding of the whole product is the 2^-(8S-2) rounding of the fp64 operand
+// and the fp64 recombination of the S exact slice sums (once per split-K part) -- nothing accumulates along K -- so
+// S = 7 is fp64-equivalent while the int8 MFMA issues 64x the multiply-adds per cycle of the fp64 one for 14x as many.
 //
 // MFMA operand maps (32x32x32 i8): lane l holds 16 int8 of A row i = l&31 and of B column j = l&31 for the K-half
 // l>>5; A and B use the same (half, byte) -> k assignment, so the dot products do not depend on it.  C/D register r of
@@ -125,7 +126,8 @@ __device__ __forceinline__ int slice_exponent(unsigned long long bits)
 }
 
 // one thread = one 16-row group of one column: 16 strided fp64 in, one 16-byte store per slice and operand out; block 0
-// also writes the weights colw[s*b + c] = 2^e_c / 64 / 128^s (0 for the padding slice-columns); optionally the exact
+// also writes the weights colw[s*b + c] = 2^(e_c - (8S-2)) 256^(S-1-s) (slice 0 = top byte; 0 for the padding
+// slice-columns); optionally the exact
 // integer column sums of every slice (for  M'Q = 1'Q - E'Q, see k_gemm_i8) -- block-reduced, one atomic per
 // slice-column per block
 template <int NOPS>
@@ -136,19 +138,15 @@ __global__ __launch_bounds__(256) void k_slice(const double *__restrict__ V, uin
    const uint64_t groups = rows_pad / 16;
    const int c = threadIdx.x % b, gl = threadIdx.x / b, gpb = 256 / b; // column, local group, groups per block
    const SliceOp *ops[2] = {&o0, &o1};
-   double sc[NOPS];
+   const int F = 8 * S - 2; // fractional bits below 2^e; |m| < 2^F <= 2^62
+   int sh[NOPS];
 #pragma unroll
    for (int o = 0; o < NOPS; o++) {
       const int e = slice_exponent(maxbits_fold(ops[o]->maxbits, c));
-      sc[o] = ldexp(1.0, 6 - e);
+      sh[o] = F - e;
       if (blockIdx.x == 0) {
-         if (gl == 0) {
-            double w = ldexp(1.0, e - 6);
-            for (int s = 0; s < S; s++) {
-               ops[o]->colw[s * b + c] = w;
-               w *= 1.0 / 128.0;
-            }
-         }
+         if (gl == 0)
+            for (int s = 0; s < S; s++) ops[o]->colw[s * b + c] = ldexp(1.0, e - F + 8 * (S - 1 - s));
          for (int t = S * b + threadIdx.x; t < nsc_pad; t += 256) ops[o]->colw[t] = 0.0;
       }
    }
@@ -164,23 +162,23 @@ __global__ __launch_bounds__(256) void k_slice(const double *__restrict__ V, uin
       }
 #pragma unroll
       for (int o = 0; o < NOPS; o++) {
-         double q[16];
+         long long m[16];
 #pragma unroll
          for (int j = 0; j < 16; j++) {
             const uint64_t r = r0 + j;
             double x = v[j];
             if (ops[o]->rowscale && act && r < rows) x *= ops[o]->rowscale[r];
-            q[j] = x * sc[o]; // |q| < 64; exact (power-of-two scaling)
+            m[j] = __double2ll_rn(ldexp(x, sh[o])); // power-of-two scaling is exact; |m| < 2^F
          }
-         for (int s = 0; s < S; s++) {
+         for (int s = S - 1; s >= 0; s--) { // bytes from the low end, carries into the next one
             u4 word = {0u, 0u, 0u, 0u};
             int tot = 0;
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-               const double d = rint(q[j]);
-               q[j] = (q[j] - d) * 128.0; // exact
-               tot += (int)d;
-               word[j & 3] |= ((uint32_t)(int)d & 0xFFu) << (8 * (j >> 2)); // position 4 (j&3) + (j>>2)
+               const int d = (int)(signed char)(m[j] & 0xFF);
+               m[j] = (m[j] - d) >> 8;
+               tot += d;
+               word[j & 3] |= ((uint32_t)d & 0xFFu) << (8 * (j >> 2)); // position 4 (j&3) + (j>>2)
             }
             if (act) *reinterpret_cast<u4 *>(ops[o]->Q + ((uint64_t)(s * b + c)) * rows_pad + r0) = word;
             ssum[o][s][threadIdx.x] = tot;
@@ -219,7 +217,7 @@ void i8_colmax(const double *V, uint64_t rows, int b, int nops, const SliceOp *o
 
 void i8_slice(const double *V, uint64_t rows_pad, uint64_t rows, int b, int S, int nops, const SliceOp *ops, hipStream_t stream)
 {
-   if (S > 9 || b > 64 || nops < 1 || nops > 2) throw Error(-1, "i8_slice: S <= 9, b <= 64, 1 or 2 operands");
+   if (S > 8 || b > 64 || nops < 1 || nops > 2) throw Error(-1, "i8_slice: S <= 8, b <= 64, 1 or 2 operands");
    const unsigned blocks = (unsigned)std::min<uint64_t>(4096, (rows_pad / 16 + (256 / b) - 1) / (256 / b));
    const int nsc = gemm_i8_nsc_pad(S, b);
    if (nops == 2)

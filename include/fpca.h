@@ -45,14 +45,15 @@ extern "C" {
 #define FPCA_DIVISOR_NONE 0
 #define FPCA_DIVISOR_N1 1
 #define FPCA_DIVISOR_P 2
-/* arithmetic of the two genotype GEMMs.  AUTO = the exact-integer path FPCA_ACCUM_I8(8) for 2-bit input (falling back to
+/* arithmetic of the two genotype GEMMs.  AUTO = the exact-integer path FPCA_ACCUM_I8(7) for 2-bit input (falling back to
  * FP64 if its extra buffers -- a second, sample-major 2-bit copy and the int8 operands -- do not fit), FP64 for dense input */
 #define FPCA_ACCUM_AUTO 0
 #define FPCA_ACCUM_FP64 64
 #define FPCA_ACCUM_FP32 32
-/* exact-integer mode: the fp64 operand is cut into S signed 7-bit slices (shared power-of-two scale per column) and
- * multiplied with the integer genotype matrices on the int8 matrix cores with exact int32 accumulation; S = 8 keeps
- * 56 bits (fp64-equivalent), S = 4..5 roughly single precision but still without accumulation error. */
+/* exact-integer mode: the fp64 operand is rounded to (8S-2)-bit fixed point (shared power-of-two scale per column), cut
+ * into its S bytes and multiplied with the integer genotype matrices on the int8 matrix cores with exact int32
+ * accumulation; S = 7 keeps 54 bits below the column maximum (fp64-equivalent, the default), S = 4 (30 bits) roughly
+ * single precision but still without accumulation error.  S = 2..8. */
 #define FPCA_ACCUM_I8(S) (800 + (S))
 
 #define FPCA_OK 0

@@ -18,7 +18,7 @@ for name, N, P, b, steps in configs:
     Z64 = ref.apply_xxt(B)
     r64 = ref.bench_apply(b=b, steps=steps, warmup=2)
     ref.close()
-    for mode in ("i8", "i8x7", "i8x6", "i8x5", "i8x4"):
+    for mode in ("i8x8", "i8", "i8x6", "i8x5", "i8x4"):
         if mode == "i8x4" and b != 64:
             pass
         ctx = fp.Context.synthetic(N, P, n_pop=40, accum=mode)

@@ -214,13 +214,14 @@ def test_mfma_i8_operand_mapping(fp):
     assert np.array_equal(D, A.astype(np.int32) @ Bt.astype(np.int32).T)
 
 
-@pytest.mark.parametrize("name,b,S,tol", [("data_chr1", 32, 8, 1e-12), ("hapmap3_data", 32, 8, 1e-12), ("hapmap3_data", 64, 8, 1e-12),
+@pytest.mark.parametrize("name,b,S,tol", [("data_chr1", 32, 7, 1e-12), ("hapmap3_data", 32, 7, 1e-12), ("hapmap3_data", 64, 7, 1e-12),
+                                          ("data_chr1", 32, 8, 1e-12), ("hapmap3_data", 64, 8, 1e-12), ("hapmap3_data", 16, 7, 1e-12),
                                           ("hapmap3_data", 16, 8, 1e-12), ("hapmap3_data", 48, 7, 1e-11), ("data_chr1", 5, 8, 1e-12),
                                           ("hapmap3_data", 64, 4, 3e-6), ("hapmap3_data", 32, 6, 1e-9)])
 def test_i8_mode_operator_parity(golden_dir, name, b, S, tol, fp, orc):
-    """FPCA_ACCUM_I8(S): integer genotype matrices x 7-bit slices of the fp64 operand with exact int32 accumulation.
-    S = 8 keeps 56 bits per column scale, so the result meets the fp64 tolerance; smaller S only truncates the operand
-    (error <= 2^-7S of the column maximum per element, no accumulation error)."""
+    """FPCA_ACCUM_I8(S): integer genotype matrices x byte slices of the fp64 operand with exact int32 accumulation.
+    S = 7 keeps 54 bits per column scale, so the result meets the fp64 tolerance; smaller S only truncates the operand
+    (error <= 2^-(8S-1) of the column maximum per element, no accumulation error)."""
     N = fp.count_fam_rows(os.path.join(golden_dir, name + ".fam"))
     bed = os.path.join(golden_dir, name + ".bed")
     ctx = fp.Context.from_bed(bed, N, accum="i8x%d" % S)
@@ -265,7 +266,7 @@ def test_auto_mode_resolution(golden_dir, fp):
     N = fp.count_fam_rows(os.path.join(golden_dir, "data_chr1.fam"))
     bed = os.path.join(golden_dir, "data_chr1.bed")
     with fp.Context.from_bed(bed, N, accum="auto") as c:
-        assert c.accum == "i8x8"
+        assert c.accum == "i8x7"
     with fp.Context.from_bed(bed, N, accum="fp64") as c:
         assert c.accum == "fp64"
     with fp.Context.from_bed(bed, N, accum="i8x6") as c:
@@ -320,7 +321,7 @@ def test_auto_mode_falls_back_to_fp64_when_buffers_do_not_fit(fp, monkeypatch):
         Z0 = ref.apply_xxt(B)
     monkeypatch.setenv("FPCA_DEBUG_I8_NOMEM", "1")
     with fp.Context.synthetic(N, P, n_pop=6, accum="auto") as c:
-        assert c.accum == "i8x8"
+        assert c.accum == "i8x7"
         Z = c.apply_xxt(B)
         assert c.accum == "fp64"
         assert np.array_equal(Z, Z0)
