@@ -29,4 +29,6 @@ python scripts/summarise_pmc.py gpurun_out/$R _fp64 > gpurun_out/$R/pmc_summary.
 python scripts/summarise_pmc.py gpurun_out/$R _i8 > gpurun_out/$R/pmc_summary_i8.json
 python scripts/mfma_i8_peak.py > gpurun_out/$R/mfma_i8_microbench.txt 2>&1
 python scripts/mfma_peak.py > gpurun_out/$R/mfma_f64_microbench.txt 2>&1
+[ -x flashpca_amd/_build/mx_probe ] && timeout 300 flashpca_amd/_build/mx_probe > gpurun_out/$R/mx_fp4_fp6_probe.txt 2>&1
+python bench.py --workload cfg5 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/$R/bench_cfg5_n1.json 2>/dev/null
 cat gpurun_out/$R/pmc_summary_i8.json | head -60; cat gpurun_out/$R/bench_cfg2_n1.json

@@ -242,6 +242,51 @@ def test_i8_mode_operator_parity(golden_dir, name, b, S, tol, fp, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("S", [7, 4])
+def test_i8_slicing_extreme_columns(golden_dir, S, fp, orc):
+    """The per-column fixed-point slicing at its corners: columns scaled to the ends of the double range, a zero column,
+    a single-entry column, a constant column (every element = the column maximum, top byte at its bound), all-negative
+    and alternating +-max columns (carries into the top byte), and denormals.  Each column of the result must carry its
+    own relative accuracy, untouched by its neighbours."""
+    name = "data_chr1"
+    N = fp.count_fam_rows(os.path.join(golden_dir, name + ".fam"))
+    bed = os.path.join(golden_dir, name + ".bed")
+    od = orc.OracleData(bed, N, "binom2")
+    X = od.dense()
+    rng = np.random.default_rng(S)
+    b = 16
+    B = rng.standard_normal((N, b))
+    B[:, 0] *= 1e-290
+    B[:, 1] *= 1e290
+    B[:, 2] = 0.0
+    B[:, 3] = 0.0
+    B[N // 2, 3] = -3.75
+    B[:, 4] = 0.999999999999
+    B[:, 5] = -np.abs(B[:, 5]) - 1.0
+    B[:, 6] = np.where(np.arange(N) % 2 == 0, 1.0, -1.0) * (2.0 - 2.0 ** -52)
+    B[:, 7] *= 5e-324 * 2 ** 20  # denormals
+    B[:, 8] = 2.0 ** -1030  # a constant denormal column
+    with fp.Context.from_bed(bed, N, accum="i8x%d" % S) as ctx:
+        T = ctx.apply_xt(B)
+    T_ref = X.T @ B
+    # the integer path is exact up to the 2^-(8S-1) rounding of each operand entry relative to its column maximum; the
+    # numpy reference itself carries ~N eps of the absolute sums -- so the bound is on |X|' |B| (several columns cancel
+    # almost completely: a constant column against centred genotypes), column by column
+    with np.errstate(over="ignore", invalid="ignore"):
+        A = np.abs(X).T @ np.maximum(np.abs(B), np.max(np.abs(B), axis=0, keepdims=True) * 2.0 ** -(8 * S - 2))
+    for c in range(b):
+        err = np.abs(T[:, c] - T_ref[:, c])
+        if not np.any(B[:, c]):
+            assert np.all(T[:, c] == 0.0), c
+        elif c == 1:
+            assert np.all(err <= 2.0 ** -(8 * S - 4) * np.max(np.abs(T_ref[:, c]))), c  # |X|'|B| overflows here
+        elif c in (7, 8):
+            assert np.all(err <= 1e-9 * A[:, c] + 5e-324 * N * 4096), c  # the denormal grid is the limit
+        else:
+            assert np.all(err <= (2.0 ** -(8 * S - 3) + 1e-13) * A[:, c]), (c, np.max(err / A[:, c]))
+    assert np.all(np.isfinite(T))
+
+
 @pytest.mark.parametrize("N,P", [(1, 3), (5, 7), (257, 300), (2051, 129)])
 def test_i8_mode_ragged_shapes(N, P, fp, orc):
     rng = np.random.default_rng(N * 1000 + P)
