@@ -287,10 +287,14 @@ __device__ __forceinline__ void static_for(F &&f)
 //                 multiplied, M'Q = 1'Q comes from the column sums alone -- half the MFMAs
 enum { I8_FULL = 0, I8_SKIP_EMPTY = 1, I8_NO_MISSING = 2 };
 
-template <bool TWO_, int MT_, int NT_, int WR_, int WC_, int KC_, int G_, int MODE_ = I8_FULL>
+// ABL (builds with -DFPCA_I8_ABLATION only; results are wrong by construction): bit 0 drops the operand staging of the
+// main loop, bit 1 the genotype decode, bit 2 the LDS fragment reads, bit 3 the packed-word loads -- what each costs
+// (scripts/i8_ablation.py)
+template <bool TWO_, int MT_, int NT_, int WR_, int WC_, int KC_, int G_, int MODE_ = I8_FULL, int ABL_ = 0>
 struct I8Cfg {
    static constexpr bool TWO = TWO_;
    static constexpr int MT = MT_, NT = NT_, WR = WR_, WC = WC_, KC = KC_, G = G_, NQ = TWO ? 2 : 1, MODE = MODE_;
+   static constexpr int ABL = ABL_;
    static constexpr int MATS = MODE == I8_NO_MISSING ? 1 : 2;
    static_assert(!(TWO && MATS == 1), "without E there is only one operand");
    static_assert(WR * WC == 4 && MATS * MT * NT <= 16 && (MT == 1 || G == 1) && G <= NT, "shape");
@@ -458,6 +462,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
       read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       enz[0] = i8_decode<MODE>(pk[0][0][0], ag[0], am[0]);
       wait_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      if constexpr ((C::ABL & 4) != 0) {
+         read_b(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+         wait_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+      }
+      if constexpr ((C::ABL & 2) != 0) enz[1] = i8_decode<MODE>(pk[0][0][1], ag[1], am[1]);
       __builtin_amdgcn_sched_barrier(0);
 
       static_for<NSTEP>([&](auto ss) {
@@ -469,19 +478,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
          constexpr int ks1 = s1 / (MT * G), m1 = (G == 1) ? s1 % MT : 0, g1 = (G == 1) ? 0 : s1 % G;
          constexpr int bkey1 = ks1 * G + g1, akey1 = ks1 * MT + m1;
          // --- staging of chunk cn: loads in the first half, packed words at the half-way mark, LDS stores in the second
-         if constexpr (s < H) {
+         if constexpr (s < H && !(C::ABL & 1)) {
             static_for<(s + 1) * NP / H - s * NP / H>([&](auto jj) {
                issue_q(std::integral_constant<int, s * NP / H + decltype(jj)::value>{}, cn);
             });
          }
-         if constexpr (s == H - 1) issue_p(pkn, cn);
-         if constexpr (s >= H) {
+         if constexpr (s == H - 1 && !(C::ABL & 8)) issue_p(pkn, cn);
+         if constexpr (s >= H && !(C::ABL & 1)) {
             static_for<(s - H + 1) * NP / H - (s - H) * NP / H>([&](auto jj) {
                store_q(std::integral_constant<int, (s - H) * NP / H + decltype(jj)::value>{}, wst);
             });
          }
          // --- operand fragments of the next micro-step
-         if constexpr (bkey1 != bkey)
+         if constexpr (bkey1 != bkey && !(C::ABL & 4))
             read_b(std::integral_constant<int, ks1>{}, std::integral_constant<int, g1>{}, std::integral_constant<int, (bkey1 & 1)>{});
          // --- this micro-step's MFMAs, the next micro-step's decode in their shadow
          static_for<NG>([&](auto jj) {
@@ -491,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
                if constexpr (MODE == I8_FULL)
                   acc[1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(am[akey & 1], bq[bkey & 1][NQ - 1][j], acc[1][m][n], 0, 0, 0);
             }
-            if constexpr (j == 0 && akey1 != akey)
+            if constexpr (j == 0 && akey1 != akey && !(C::ABL & 2))
                enz[akey1 & 1] = i8_decode<MODE>(pk[m1][ks1 >> 2][ks1 & 3], ag[akey1 & 1], am[akey1 & 1]);
          });
          if constexpr (MODE == I8_SKIP_EMPTY) {
@@ -504,18 +513,20 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
             }
          }
          __builtin_amdgcn_sched_barrier(0);
-         if constexpr (bkey1 != bkey) {
+         if constexpr (bkey1 != bkey && !(C::ABL & 4)) {
             wait_b(std::integral_constant<int, g1>{}, std::integral_constant<int, (bkey1 & 1)>{});
             __builtin_amdgcn_sched_barrier(0);
          }
       });
+      if constexpr (!(C::ABL & 8)) {
 #pragma unroll
-      for (int m = 0; m < MT; m++)
+         for (int m = 0; m < MT; m++)
 #pragma unroll
-         for (int h = 0; h < PW; h++) {
-            vm_wait<0>(pkn[m][h]);
-            pk[m][h] = pkn[m][h];
-         }
+            for (int h = 0; h < PW; h++) {
+               vm_wait<0>(pkn[m][h]);
+               pk[m][h] = pkn[m][h];
+            }
+      }
       __syncthreads();
    }
 
@@ -805,6 +816,22 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
             FPCA_I8_K3(4, I8_FULL);
       }
    } else if (mode == I8_NO_MISSING) {
+#ifdef FPCA_I8_ABLATION
+      static const char *abl = getenv("FPCA_I8_ABL");
+      const int ab = abl ? atoi(abl) : 0;
+#define FPCA_I8_AB(A_) launch_i8<I8Cfg<false, 2, 7, 4, 1, 256, 1, I8_NO_MISSING, A_>>(FPCA_I8_ARGS)
+      if (ab && sh.nt == 7) {
+         switch (ab) {
+         case 1: FPCA_I8_AB(1); break;
+         case 2: FPCA_I8_AB(2); break;
+         case 4: FPCA_I8_AB(4); break;
+         case 8: FPCA_I8_AB(8); break;
+         case 9: FPCA_I8_AB(9); break;
+         case 6: FPCA_I8_AB(6); break;
+         default: FPCA_I8_AB(15); break;
+         }
+      } else
+#endif
       FPCA_I8_K2_NT(I8_NO_MISSING)
    } else if (mode == I8_SKIP_EMPTY) {
       FPCA_I8_K2_NT(I8_SKIP_EMPTY)

@@ -272,14 +272,12 @@ def test_i8_slicing_extreme_columns(golden_dir, S, fp, orc):
     # the integer path is exact up to the 2^-(8S-1) rounding of each operand entry relative to its column maximum; the
     # numpy reference itself carries ~N eps of the absolute sums -- so the bound is on |X|' |B| (several columns cancel
     # almost completely: a constant column against centred genotypes), column by column
-    with np.errstate(over="ignore", invalid="ignore"):
+    with np.errstate(under="ignore"):
         A = np.abs(X).T @ np.maximum(np.abs(B), np.max(np.abs(B), axis=0, keepdims=True) * 2.0 ** -(8 * S - 2))
     for c in range(b):
         err = np.abs(T[:, c] - T_ref[:, c])
         if not np.any(B[:, c]):
             assert np.all(T[:, c] == 0.0), c
-        elif c == 1:
-            assert np.all(err <= 2.0 ** -(8 * S - 4) * np.max(np.abs(T_ref[:, c]))), c  # |X|'|B| overflows here
         elif c in (7, 8):
             assert np.all(err <= 1e-9 * A[:, c] + 5e-324 * N * 4096), c  # the denormal grid is the limit
         else:
