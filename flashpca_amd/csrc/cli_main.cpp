@@ -7,6 +7,7 @@
 // New, MI355X-specific flags: --device, --blockvec, --maxblocks, --accum.  --memory/--blocksize/--batch/--numthreads are
 // accepted for compatibility; the packed matrix is always fully resident in HBM so they have no effect.
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -381,6 +382,13 @@ int main(int argc, char *argv[])
       std::cout << timestamp() << "Start flashpca (version " << FLASHPCA_VERSION << ")" << std::endl;
       verbose && std::cout << timestamp() << "seed: " << seed << std::endl;
 
+      // FPCA_TIMING=1: wall-clock of each phase on stderr
+      const bool phase_timing = std::getenv("FPCA_TIMING") != nullptr;
+      auto phase = [&, last = std::chrono::steady_clock::now()](const char *what) mutable {
+         const auto now = std::chrono::steady_clock::now();
+         if (phase_timing) std::fprintf(stderr, "[fpca-cli] %-32s %8.3f ms\n", what, std::chrono::duration<double>(now - last).count() * 1e3);
+         last = now;
+      };
       // N = number of rows of the .fam whose 6th column parses as a number (flashpca.cpp:589 -> data.cpp:408-413)
       fpca::TextMatrix pheno = fpca::read_text(fam_file, 6);
       const uint64_t N = pheno.rows;
@@ -388,10 +396,12 @@ int main(int argc, char *argv[])
       fpca::read_plink_bim(bim_file, snp_ids, ref_alleles, alt_alleles);
       fpca::read_plink_fam(fam_file, fam_ids, indiv_ids);
       if (N == 0) throw std::runtime_error("no samples found in " + fam_file);
+      phase(".fam / .bim");
 
       fpca_ctx *ctx = nullptr;
       uint64_t nsnps = 0;
       fpca_ok(fpca_create_from_bed(&ctx, geno_file.c_str(), N, 0, 0, stand_method_x, device, accum, &nsnps));
+      phase("device init + .bed upload");
       verbose && std::cout << timestamp() << "Detected BED file: " << geno_file << " with " << N << " samples, " << nsnps << " SNPs." << std::endl;
       if (verbose) {
          char name[256];
@@ -485,6 +495,7 @@ int main(int argc, char *argv[])
          const double s = std::sqrt(div);
          for (auto &x : Px) x /= s; // randompca.cpp:818
       }
+      phase("compute");
 
       // ---- write out results (flashpca.cpp:755-878) --------------------------------------------------------
       const std::vector<std::string> none;
@@ -536,7 +547,9 @@ int main(int argc, char *argv[])
          if (rn.size() != nsnps) throw std::runtime_error("the .bim file has a different number of SNPs than the .bed");
          fpca::save_text(meansd.data(), nsnps, 2, cn, rn, meansdfile, precision);
       }
+      phase("output files");
       fpca_destroy(ctx);
+      phase("teardown");
       std::cout << timestamp() << "Goodbye!" << std::endl;
    } catch (std::exception &e) {
       std::cerr << timestamp() << "Exception: " << e.what() << std::endl;

@@ -171,13 +171,18 @@ def test_parallel_writer_is_byte_identical_to_iostream_format(tmp_path):
     M[5, 3] = 0.0
     M[6, 3] = -0.0
     M[7, 3] = 123456789012.0
+    # values where %g switches notation or rounds up a digit, the ends of the double range, non-finite values
+    M[8, :] = [0.0001, 0.00001, 999999.5, 9999999.5, 1e7, 0.5, 1.0]
+    M[9, :] = [5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, -1e-5, 1e21, 1e22, 123456.7]
+    M[10, :] = [np.nan, np.inf, -np.inf, 0.1, 0.2, 0.3, 1.0 / 3.0]
+    M[11, :] = [2.5, 3.5, 0.125, 0.0625, 1e15 + 0.5, 1e16, 99999995.0]
     names = "|".join("f%d\ti%d" % (i, i) for i in range(rows)).encode()
     f = str(tmp_path / "big.txt")
-    for prec in (7, 20, 3):
+    for prec in (7, 20, 3, 1, 17, 10):
         assert L.hostsim_save_text(M.ctypes.data, rows, cols, b"FID\tIID|" + b"|".join(b"U%d" % i for i in range(cols)), names, f.encode(), prec) == 0
         lines = open(f).read().split("\n")
         assert len(lines) == rows + 2 and lines[-1] == ""
-        for i in (0, 1, 4095, 4096, 4097, 8191, 8192, 20010, 5, 6, 7):
+        for i in range(rows):  # every row: Python's % operator is the C library's printf conversion
             expect = "f%d\ti%d\t" % (i, i) + "\t".join("%.*g" % (prec, v) for v in M[i])
             assert lines[i + 1] == expect, (i, prec)
 
