@@ -124,6 +124,15 @@ struct fpca_ctx {
    bool sparse_ready = false;
    hipStream_t aux_stream = nullptr; // the gather-sums run here, under the (MFMA-bound) GEMM of the same stage
    hipEvent_t ev_aux_go = nullptr, ev_aux_done = nullptr;
+   // Krylov basis blocks of finished solves, kept for the next one (bytes, pointer): allocating and freeing a dozen
+   // 128 MB blocks costs ~15 ms per fpca_pca at 500,000 samples; released by fpca_destroy
+   std::vector<std::pair<size_t, double *>> block_pool;
+   // the backend's small-matrix scratch lives here for the same reason (freeing a 100 MB partial stack and a pinned
+   // buffer at the end of every solve costs ~10 ms)
+   const double **be_ptrs = nullptr;
+   double *be_C = nullptr, *be_gpart = nullptr;
+   size_t be_C_cap = 0, be_gpart_cap = 0, be_pin_cap = 0;
+   void *be_pin = nullptr;
    // communication
    ncclComm_t comm = nullptr;
    int nranks = 1, rank = 0;
@@ -235,6 +244,11 @@ void ctx_free(fpca_ctx *c)
                    c->d_i8w, c->d_Qb, c->d_Qg, c->d_Qm, c->d_i8ws, c->d_snp_ptr, c->d_snp_idx, c->d_smp_ptr, c->d_smp_idx, c->d_eplane};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
+   for (auto &pb : c->block_pool) (void)hipFree(pb.second);
+   if (c->be_ptrs) (void)hipFree(c->be_ptrs);
+   if (c->be_C) (void)hipFree(c->be_C);
+   if (c->be_gpart) (void)hipFree(c->be_gpart);
+   if (c->be_pin) (void)hipHostFree(c->be_pin);
    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
    for (hipEvent_t e : c->ev_chunk)
       if (e) (void)hipEventDestroy(e);
@@ -648,11 +662,13 @@ void ensure_io(fpca_ctx *c)
 // ---- HIP backend for the eigensolver ---------------------------------------------------------------
 class HipBackend : public BlockBackend {
  public:
-   HipBackend(fpca_ctx *c, int b) : c_(c), b_(b)
+   HipBackend(fpca_ctx *c, int b)
+      : c_(c), b_(b), d_ptrs_(c->be_ptrs), d_C_(c->be_C), d_gpart_(c->be_gpart), C_cap_(c->be_C_cap), gpart_cap_(c->be_gpart_cap),
+        h_pin_(c->be_pin), pin_cap_(c->be_pin_cap)
    {
       HIP_CHECK(hipSetDevice(c->device));
       ensure_stats(c);
-      HIP_CHECK(hipMalloc(&d_ptrs_, 1024 * sizeof(double *)));
+      if (!d_ptrs_) HIP_CHECK(hipMalloc(&d_ptrs_, 1024 * sizeof(double *)));
       HIP_CHECK(hipEventCreate(&e0_));
       HIP_CHECK(hipEventCreate(&e1_));
       HIP_CHECK(hipEventCreateWithFlags(&ev_pin_, hipEventDisableTiming));
@@ -662,17 +678,14 @@ class HipBackend : public BlockBackend {
    {
       (void)hipStreamSynchronize(c_->stream);
       for (double *p : blocks_)
-         if (p) (void)hipFree(p);
-      if (d_ptrs_) (void)hipFree(d_ptrs_);
-      if (d_C_) (void)hipFree(d_C_);
-      if (d_gpart_) (void)hipFree(d_gpart_);
-      if (h_pin_) (void)hipHostFree(h_pin_);
+         if (p) c_->block_pool.emplace_back(block_bytes(), p);
       (void)hipEventDestroy(ev_pin_);
       (void)hipEventDestroy(e0_);
       (void)hipEventDestroy(e1_);
    }
    uint64_t nrows() const override { return c_->N; }
    int width() const override { return b_; }
+   size_t block_bytes() const { return (size_t)c_->N_pad * b_ * sizeof(double); }
    int alloc_block() override
    {
       for (size_t i = 0; i < used_.size(); i++)
@@ -681,7 +694,13 @@ class HipBackend : public BlockBackend {
             return (int)i;
          }
       double *p = nullptr;
-      HIP_CHECK(hipMalloc(&p, (size_t)c_->N_pad * b_ * sizeof(double)));
+      for (size_t i = 0; i < c_->block_pool.size(); i++)
+         if (c_->block_pool[i].first == block_bytes()) {
+            p = c_->block_pool[i].second;
+            c_->block_pool.erase(c_->block_pool.begin() + (long)i);
+            break;
+         }
+      if (!p) HIP_CHECK(hipMalloc(&p, block_bytes()));
       blocks_.push_back(p);
       used_.push_back(1);
       return (int)blocks_.size() - 1;
@@ -801,11 +820,11 @@ class HipBackend : public BlockBackend {
    int b_;
    std::vector<double *> blocks_;
    std::vector<unsigned char> used_;
-   const double **d_ptrs_ = nullptr;
-   double *d_C_ = nullptr, *d_gpart_ = nullptr;
-   size_t C_cap_ = 0, gpart_cap_ = 0;
-   void *h_pin_ = nullptr;
-   size_t pin_cap_ = 0;
+   const double **&d_ptrs_; // scratch owned by the context (kept across solves)
+   double *&d_C_, *&d_gpart_;
+   size_t &C_cap_, &gpart_cap_;
+   void *&h_pin_;
+   size_t &pin_cap_;
    bool pin_busy_ = false;
    hipEvent_t e0_, e1_, ev_pin_;
    double sec_apply_ = 0, sec_other_ = 0;
@@ -1261,7 +1280,15 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
       if (k < 1 || (uint64_t)k > max_dim)
          throw Error(FPCA_EINVAL, "You asked for " + std::to_string(k) + " dimensions, but only " + std::to_string(max_dim) + " allowed");
       const int b = choose_blockvec(k, opts->blockvec);
+      const bool timing = std::getenv("FPCA_TIMING") != nullptr;
+      auto tp0 = std::chrono::steady_clock::now();
+      auto lap = [&](const char *what) {
+         const auto now = std::chrono::steady_clock::now();
+         if (timing) std::fprintf(stderr, "[fpca] %-28s %8.3f ms\n", what, std::chrono::duration<double>(now - tp0).count() * 1e3);
+         tp0 = now;
+      };
       HipBackend be(ctx, b);
+      lap("backend setup");
       PcaOutputs out;
       out.U = U;
       out.d = d;
@@ -1272,6 +1299,7 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
       std::vector<double> dloc(k);
       if (!out.d) out.d = dloc.data();
       solver_rc = run_pca(be, *opts, ctx->P_total, out, info, &ritz, &div);
+      lap("run_pca");
       if (opts->do_loadings && V) {
          // randompca.cpp:191-204: V[:, j] = X' u_j / sqrt(d_j) / sqrt(div); one K2 pass for all k columns
          xt_dev(ctx, be.ptr(ritz), b, ctx->stream);
@@ -1288,7 +1316,9 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
          HIP_CHECK(hipMemcpy(mean_sd, ctx->d_mean, ctx->P_g * sizeof(double), hipMemcpyDeviceToHost));
          HIP_CHECK(hipMemcpy(mean_sd + ctx->P_g, ctx->d_sd, ctx->P_g * sizeof(double), hipMemcpyDeviceToHost));
       }
+      lap("loadings, mean/sd");
    });
+   if (std::getenv("FPCA_TIMING")) std::fprintf(stderr, "[fpca] %-28s (backend teardown follows)\n", "fpca_pca body done");
    if (rc != FPCA_OK) return rc;
    if (solver_rc == FPCA_ENOTCONVERGED) set_last_error("eigen-decomposition was not successful (not converged within maxiter)");
    return solver_rc;
