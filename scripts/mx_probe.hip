@@ -106,6 +106,37 @@ __global__ __launch_bounds__(256, 1) void k_rate_i8(int *out, int iters, uint32_
    if (s == 123456789) out[0] = s;
 }
 
+typedef int v4iacc __attribute__((ext_vector_type(4)));
+// the 16x16x64 shape of the same int8 MFMA: a quarter of the accumulator traffic per instruction, half per op
+__global__ __launch_bounds__(256, 1) void k_rate_i8_16(int *out, int iters, uint32_t seed, int realistic)
+{
+   uint32_t x = (threadIdx.x + 1) * 2654435761u ^ seed;
+   auto rnd = [&]() {
+      x ^= x << 13;
+      x ^= x >> 17;
+      x ^= x << 5;
+      return x;
+   };
+   v4i a[4], b[4];
+   for (int j = 0; j < 4; j++)
+      for (int i = 0; i < 4; i++) {
+         uint32_t w = rnd();
+         if (realistic) w = (w & (w >> 1) & 0x01010101u) | ((w >> 2) & ~w & 0x02020202u);
+         a[j][i] = (int)w;
+         b[j][i] = (int)(rnd() & 0x7F7F7F7Fu) - 0x40404040;
+      }
+   v4iacc acc[16];
+   for (int j = 0; j < 16; j++) acc[j] = (v4iacc){0, 0, 0, 0};
+   for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j & 3], b[j >> 2], acc[j], 0, 0, 0);
+   }
+   int s = 0;
+   for (int j = 0; j < 16; j++)
+      for (int r = 0; r < 4; r++) s += acc[j][r];
+   if (s == 123456789) out[0] = s;
+}
+
 template <typename K, typename... Args> static double time_ms(K kern, int blocks, Args... args)
 {
    hipEvent_t e0, e1;
@@ -194,10 +225,12 @@ int main()
       const double m66 = time_ms(k_rate<FMT_FP6, FMT_FP6>, blocks, d, iters, 1u, realistic);
       const double m48 = time_ms(k_rate<FMT_FP4, 0>, blocks, d, iters, 1u, realistic);
       const double mi8 = time_ms(k_rate_i8, blocks, (int *)d, iters, 1u, realistic);
+      const double mi16 = time_ms(k_rate_i8_16, blocks, (int *)d, iters, 1u, realistic);
       const double ops = (double)blocks * 4 * iters * 8 * 2.0 * 32 * 32 * 64;
       std::printf("%s A operand: fp4 x fp6 %.0f TOP/s | fp4 x fp4 %.0f | fp6 x fp6 %.0f | fp4 x fp8 %.0f | i8 32x32x32 %.0f TOP/s\n",
                   realistic ? "genotype-like" : "random", ops / (m46 * 1e-3) / 1e12, ops / (m44 * 1e-3) / 1e12, ops / (m66 * 1e-3) / 1e12,
                   ops / (m48 * 1e-3) / 1e12, ops / 2 / (mi8 * 1e-3) / 1e12);
+      std::printf("   i8 16x16x64 %.0f TOP/s\n", (double)blocks * 4 * iters * 16 * 2.0 * 16 * 16 * 64 / (mi16 * 1e-3) / 1e12);
    }
    return 0;
 }
