@@ -100,6 +100,11 @@ def test_restart_path_and_blockvec(golden_dir, fp):
             assert np.max(np.abs(r["d"] - ev) / ev) < 1e-9
         r = ctx.pca(ndim=10, tol=1e-8, max_blocks=4)
         assert r["info"]["restarts"] >= 1
+        # solves reuse the basis blocks of earlier ones (pool in the context, other widths in between): same bits
+        a = ctx.pca(ndim=10, blockvec=32)
+        ctx.pca(ndim=5, blockvec=16)
+        b2 = ctx.pca(ndim=10, blockvec=32)
+        assert np.array_equal(a["d"], b2["d"]) and np.array_equal(a["U"], b2["U"])
 
 
 def test_ndim_limit_and_errors(golden_dir, fp):
