@@ -1023,34 +1023,49 @@ void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, 
 
 // ------------------------------------------------------------------------------------------------
 // sample-major copy of the packed stream for K3i: out[sample][snp/4] from in[snp][sample/4]  (2-bit transpose)
-//   tile = 64 SNPs x 64 samples through LDS as bytes-per-code
+//   tile = 256 SNPs x 256 samples.  A thread loads the 16 x 16 block (16 SNP rows, one dword = 16 samples each; the 16
+//   lanes of a sample-word run read 64 contiguous bytes of a row), transposes it in registers with the four
+//   butterfly stages of a bit-matrix transpose on 2-bit elements, and the 256 blocks are regrouped through LDS so that
+//   every thread stores 64 contiguous bytes (256 SNPs) of one sample row.
 __global__ __launch_bounds__(256) void k_transpose_packed(const uint8_t *__restrict__ in, size_t pitch_in, uint8_t *__restrict__ out,
                                                            size_t pitch_out)
 {
-   __shared__ uint8_t tile[64][65];
-   const uint64_t snp0 = (uint64_t)blockIdx.x * 64, smp0 = (uint64_t)blockIdx.y * 64;
-   // read: 64 SNP rows x 16 bytes; thread t -> row t/4, 4 bytes
-   {
-      const int r = threadIdx.x >> 2, seg = threadIdx.x & 3;
-      const uint32_t w = *reinterpret_cast<const uint32_t *>(in + (snp0 + r) * pitch_in + smp0 / 4 + seg * 4);
+   __shared__ uint32_t tile[256][17];
+   const uint64_t snp0 = (uint64_t)blockIdx.x * 256, smp0 = (uint64_t)blockIdx.y * 256;
+   const int bs = threadIdx.x & 15, bp = threadIdx.x >> 4;
+   uint32_t w[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) tile[r][seg * 16 + k] = (uint8_t)((w >> (2 * k)) & 3u);
+   for (int i = 0; i < 16; i++) w[i] = *reinterpret_cast<const uint32_t *>(in + (snp0 + 16 * bp + i) * pitch_in + smp0 / 4 + 4 * bs);
+   // w[i] holds (SNP i, samples 0..15); swap the off-diagonal sub-blocks at element distances 8, 4, 2, 1
+#define FPCA_T2_STAGE(S_, MASK_)                                                    \
+   _Pragma("unroll") for (int r = 0; r < 16; r++) if (!(r & S_))                    \
+   {                                                                                \
+      const uint32_t t = ((w[r] >> (2 * S_)) ^ w[r + S_]) & MASK_;                  \
+      w[r + S_] ^= t;                                                               \
+      w[r] ^= t << (2 * S_);                                                        \
    }
-   __syncthreads();
-   // write: 64 sample rows x 16 bytes (64 SNPs)
-   {
-      const int r = threadIdx.x >> 2, seg = threadIdx.x & 3;
-      uint32_t w = 0;
+   FPCA_T2_STAGE(8, 0x0000FFFFu)
+   FPCA_T2_STAGE(4, 0x00FF00FFu)
+   FPCA_T2_STAGE(2, 0x0F0F0F0Fu)
+   FPCA_T2_STAGE(1, 0x33333333u)
+#undef FPCA_T2_STAGE
+   // now w[j] holds (sample j, SNPs 0..15) of the block
 #pragma unroll
-      for (int k = 0; k < 16; k++) w |= (uint32_t)tile[seg * 16 + k][r] << (2 * k);
-      *reinterpret_cast<uint32_t *>(out + (smp0 + r) * pitch_out + snp0 / 4 + seg * 4) = w;
+   for (int j = 0; j < 16; j++) tile[16 * bs + j][bp] = w[j];
+   __syncthreads();
+   {
+      const int r = threadIdx.x;
+      u4 *dst = reinterpret_cast<u4 *>(out + (smp0 + r) * pitch_out + snp0 / 4);
+#pragma unroll
+      for (int q = 0; q < 4; q++) dst[q] = (u4){tile[r][4 * q], tile[r][4 * q + 1], tile[r][4 * q + 2], tile[r][4 * q + 3]};
    }
 }
 
 void transpose_packed(const uint8_t *in, size_t pitch_in, uint64_t N_pad, uint64_t P_pad, uint8_t *out, size_t pitch_out,
                       hipStream_t stream)
 {
-   dim3 grid((unsigned)(P_pad / 64), (unsigned)(N_pad / 64));
+   if (N_pad % 256 || P_pad % 256) throw Error(-1, "transpose_packed: padded sizes must be multiples of 256");
+   dim3 grid((unsigned)(P_pad / 256), (unsigned)(N_pad / 256));
    hipLaunchKernelGGL(k_transpose_packed, grid, dim3(256), 0, stream, in, pitch_in, out, pitch_out);
    HIP_CHECK_LAUNCH();
 }
