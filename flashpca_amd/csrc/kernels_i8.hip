@@ -912,25 +912,34 @@ __global__ __launch_bounds__(256) void k_count_missing(const uint8_t *__restrict
    if (threadIdx.x == 0) cnt[blockIdx.x] = red[0];
 }
 
-// idx[ptr[r] ..] = ascending positions (< ncols) of the missing calls of record r.  The record is walked in tiles of 256
-// dwords (coalesced), every thread owns one dword = 16 codes; a wave scan + 4 wave totals place each thread's hits.
+// idx[ptr[r] ..] = ascending positions (< ncols) of the missing calls of record r.  The record is walked in tiles of 1024
+// dwords (coalesced 16-byte loads), every thread owns four consecutive dwords = 64 codes; a wave scan + 4 wave totals
+// place each thread's hits.  (Rows are 128-byte aligned and padded with "missing" codes up to the pitch, so whole
+// 16-byte pieces can be read; positions >= ncols are masked off.)
 __global__ __launch_bounds__(256) void k_fill_missing(const uint8_t *__restrict__ packed, size_t pitch, uint64_t ncols,
                                                        const uint32_t *__restrict__ ptr, uint32_t *__restrict__ idx)
 {
-   const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (uint64_t)blockIdx.x * pitch);
-   const uint64_t nw = (ncols + 15) / 16;
+   const u4 *row = reinterpret_cast<const u4 *>(packed + (uint64_t)blockIdx.x * pitch);
+   const uint64_t nq = (ncols + 63) / 64; // 16-byte pieces holding valid codes
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    __shared__ uint32_t wsum[4];
    uint32_t base = ptr[blockIdx.x];
-   for (uint64_t w0 = 0; w0 < nw; w0 += 256) {
-      const uint64_t w = w0 + threadIdx.x;
-      uint32_t m = 0;
-      if (w < nw) {
-         const uint32_t x = row[w];
-         m = x & ~(x >> 1) & 0x55555555u;
-         if (w == nw - 1 && (ncols & 15)) m &= (1u << (2 * (ncols & 15))) - 1u;
+   for (uint64_t q0 = 0; q0 < nq; q0 += 256) {
+      const uint64_t q = q0 + threadIdx.x;
+      uint32_t m[4] = {0u, 0u, 0u, 0u};
+      if (q < nq) {
+         const u4 x = row[q];
+#pragma unroll
+         for (int k = 0; k < 4; k++) {
+            m[k] = x[k] & ~(x[k] >> 1) & 0x55555555u;
+            const uint64_t first = q * 64 + 16 * k; // first code of this dword
+            if (first >= ncols)
+               m[k] = 0u;
+            else if (ncols - first < 16)
+               m[k] &= (1u << (2 * (ncols - first))) - 1u;
+         }
       }
-      const uint32_t c = __popc(m);
+      const uint32_t c = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
       uint32_t v = c;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -946,10 +955,14 @@ __global__ __launch_bounds__(256) void k_fill_missing(const uint8_t *__restrict_
          total += wsum[k];
       }
       uint32_t pos = base + woff + v - c;
-      while (m) {
-         const int bit = __ffs(m) - 1;
-         idx[pos++] = (uint32_t)(w * 16 + bit / 2);
-         m &= m - 1;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+         uint32_t mk = m[k];
+         while (mk) {
+            const int bit = __ffs(mk) - 1;
+            idx[pos++] = (uint32_t)(q * 64 + 16 * k + bit / 2);
+            mk &= mk - 1;
+         }
       }
       base += total;
       __syncthreads();
