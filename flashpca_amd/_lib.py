@@ -80,6 +80,7 @@ SIGNATURES = {
     "fpca_nsnps": (_U64, [_P]),
     "fpca_accum": (_I, [_P]),
     "fpca_missing_mode": (_I, [_P, _I]),
+    "fpca_allreduce_chunks": (_I, [_P]),
     "fpca_download_packed": (_I, [_P, _P]),
     "fpca_stats": (_I, [_P, _P, C.POINTER(_D)]),
     "fpca_set_meansd": (_I, [_P, _P]),

@@ -43,6 +43,10 @@ class Context:
         2 nothing missing, 3 sparse gathers; -1 for the fp64 / fp32 kernels."""
         return int(lib().fpca_missing_mode(self.h, b))
 
+    def allreduce_chunks(self):
+        """Row chunks of Y whose all-reduce overlaps the computation of the next chunk (fpca_allreduce_chunks)."""
+        return int(lib().fpca_allreduce_chunks(self.h))
+
     @property
     def accum(self):
         """The arithmetic mode in effect: 'fp64', 'fp32' or 'i8xS' ("auto" resolved)."""

@@ -390,7 +390,7 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
 constexpr int I8M_FULL = 0, I8M_SKIP = 1, I8M_NONE = 2, I8M_SPARSE = 3;
 int i8_mode(const fpca_ctx *c, int b)
 {
-   static const char *env = getenv("FPCA_I8_MODE"); // force (tests; 2 is wrong unless nothing is missing)
+   const char *env = getenv("FPCA_I8_MODE"); // force (tests; 2 is wrong unless nothing is missing); read on every call
    const bool sparse_ok = c->missing_known && c->n_missing < (1ull << 31) && (b == 16 || b == 32 || b == 64);
    if (env) return (atoi(env) == I8M_SPARSE && !sparse_ok) ? I8M_FULL : atoi(env);
    if (!c->missing_known) return I8M_FULL;
@@ -504,7 +504,7 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipE
 int ar_chunks(const fpca_ctx *c)
 {
    if (!c->comm || c->ar_fn || !c->comm_stream) return 1;
-   static const char *env = getenv("FPCA_AR_CHUNKS");
+   const char *env = getenv("FPCA_AR_CHUNKS"); // read on every call: the tests switch it between contexts
    int n = c->N_pad >= 400000 ? 4 : c->N_pad >= 200000 ? 2 : 1;
    if (env && atoi(env) >= 1) n = std::min(atoi(env), 4);
    while (n > 1 && c->N_pad / n < 512) n--;
@@ -1122,6 +1122,8 @@ int fpca_missing_mode(fpca_ctx *ctx, int b)
    });
    return rc == FPCA_OK ? mode : rc;
 }
+
+int fpca_allreduce_chunks(fpca_ctx *ctx) { return ctx ? ar_chunks(ctx) : FPCA_EINVAL; }
 
 // ---- operator, host pointers -------------------------------------------------------------------------
 int fpca_apply_xxt(fpca_ctx *ctx, const double *B, int64_t ldb, int b, double *Y, int64_t ldy)

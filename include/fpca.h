@@ -111,6 +111,9 @@ int fpca_accum(const fpca_ctx *ctx);           /* the FPCA_ACCUM_* mode in effec
  * shard has no missing call (one matrix), 3 = one matrix on the matrix cores + the missing-call products as sparse fp64
  * gathers; -1 = not the exact-integer path.  Negative FPCA_E* on error. */
 int fpca_missing_mode(fpca_ctx *ctx, int b);
+/* row chunks of Y whose all-reduce the built-in communicator overlaps with the computation of the next chunk (1 = one
+ * all-reduce after K3; always 1 without a communicator or with a caller-supplied all-reduce hook) */
+int fpca_allreduce_chunks(fpca_ctx *ctx);
 /* copy the shard's packed stream back (P_g * ceil(N/4) bytes, .bed body layout) -- used by the tests to feed
  * the CPU oracle the exact matrix a synthetic context holds */
 int fpca_download_packed(fpca_ctx *ctx, uint8_t *out);

@@ -383,6 +383,7 @@ def test_overlapped_allreduce_row_chunks(fp, monkeypatch, nch):
     monkeypatch.setenv("FPCA_AR_CHUNKS", str(nch))
     with fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:
         c.comm_init_rank(1, 0, fp.Context.comm_unique_id())
+        assert c.allreduce_chunks() == nch  # the setting reached the library (it is read per call, not cached)
         for _ in range(3):
             Z = c.apply_xxt(B)
             assert np.max(np.abs(Z - Z0)) <= 1e-13 * np.max(np.abs(Z0))
@@ -426,6 +427,7 @@ def test_i8_forced_missing_modes(golden_dir, fp, orc, monkeypatch, mode):
     od = orc.OracleData(bed, N, "binom2")
     X = od.dense()
     for b in (32, 64, 16, 5):
+        assert ctx.missing_mode(b) == int(mode)  # HapMap3 has 0.15 % missing calls: every forced path applies
         B = np.random.default_rng(3).standard_normal((N, b))
         T_ref = X.T @ B
         assert np.max(np.abs(ctx.apply_xt(B) - T_ref) / np.max(np.abs(T_ref), axis=0)) <= 1e-11
