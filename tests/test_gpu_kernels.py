@@ -437,3 +437,17 @@ def test_i8_forced_missing_modes(golden_dir, fp, orc, monkeypatch, mode):
     Y_ref = X @ Tin
     assert np.max(np.abs(ctx.apply_x(Tin) - Y_ref) / np.max(np.abs(Y_ref), axis=0)) <= 1e-11
     ctx.close()
+
+
+def test_randomised_parity_sweep(built_lib):
+    """scripts/fuzz_parity.py: 30 random (N, P, b, S, missing rate, forced missing-indicator path) cases, exact-integer
+    and fp64 kernels against dense numpy (all-missing and monomorphic SNPs mixed in)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "FPCA_I8_MODE"}
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_parity.py"), "30", "7"], capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all 30 cases ok" in r.stdout
