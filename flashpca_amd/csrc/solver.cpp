@@ -100,6 +100,56 @@ int svqb_pass(BlockBackend &be, int w, double zero_scale, std::vector<double> &R
    return ndead;
 }
 
+// Fewer than three blocks of samples (N < 3 b): a block Krylov basis does not fit in N dimensions, but the whole operator
+// is small.  A = X X' is formed column block by column block from applies on the identity and decomposed on the host --
+// the reference handles such inputs through ncv = 2k+1 <= N single vectors (flashpca.cpp:623-633 admits k up to
+// (min(N,P)-1)/2).
+SolverResult dense_small(BlockBackend &be, const SolverOpts &o)
+{
+   const int b = be.width(), k = o.k;
+   const uint64_t N = be.nrows();
+   SolverResult res;
+   auto t0 = clk::now();
+   std::vector<double> A((size_t)N * N), E((size_t)N * b), w(N);
+   const int in = be.alloc_block(), out = be.alloc_block();
+   for (uint64_t j0 = 0; j0 < N; j0 += (uint64_t)b) {
+      const int nc = (int)std::min<uint64_t>((uint64_t)b, N - j0);
+      std::fill(E.begin(), E.end(), 0.0);
+      for (int c = 0; c < nc; c++) E[(j0 + c) + (size_t)c * N] = 1.0;
+      be.upload(in, nc, E.data(), (int64_t)N);
+      be.apply(in, out);
+      be.download(out, nc, &A[(size_t)j0 * N], (int64_t)N);
+      res.block_applies++;
+   }
+   for (uint64_t i = 0; i < N; i++)
+      for (uint64_t j = 0; j < i; j++) {
+         const double a = 0.5 * (A[i + j * N] + A[j + i * N]);
+         A[i + j * N] = A[j + i * N] = a;
+      }
+   const std::vector<double> A0 = A;
+   if (symeig_desc((int)N, A.data(), (int)N, w.data()) != 0) throw Error(-3, "solver: dense eigensolver failed");
+   res.evals.assign(w.begin(), w.begin() + k);
+   res.residuals.assign(k, 0.0);
+   for (int i = 0; i < k; i++) { // || A u - theta u || of the computed pairs
+      double r2 = 0;
+      for (uint64_t r = 0; r < N; r++) {
+         double acc = -w[i] * A[r + (size_t)i * N];
+         for (uint64_t c = 0; c < N; c++) acc += A0[r + c * N] * A[c + (size_t)i * N];
+         r2 += acc * acc;
+      }
+      res.residuals[i] = std::sqrt(r2);
+      res.max_rel_residual = std::max(res.max_rel_residual, res.residuals[i] / std::max(std::pow(DBL_EPSILON, 2.0 / 3.0), std::fabs(w[i])));
+   }
+   be.upload(in, (int)std::min<uint64_t>((uint64_t)b, N), A.data(), (int64_t)N);
+   be.free_block(out);
+   res.ritz_block = in;
+   res.converged = true;
+   res.seconds_host = since(t0);
+   if (o.verbose) std::fprintf(stderr, "[fpca] %llu samples < 3 x block width %d: dense eigendecomposition of X X' (%d applies)\n",
+                               (unsigned long long)N, b, res.block_applies);
+   return res;
+}
+
 } // namespace
 
 SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
@@ -111,7 +161,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    int mcap = o.max_blocks > 0 ? o.max_blocks : std::max(4, 512 / b);
    // the basis [V_0..V_{m-1}, Q] must fit in N dimensions
    const int fit = (int)std::min<uint64_t>(N / (uint64_t)b, 1u << 20) - 1;
-   if (fit < 2) throw Error(-1, "solver: too few samples for this block width (need N >= 3 b)");
+   if (fit < 2) return dense_small(be, o);
    mcap = std::min(mcap, fit);
    if (mcap < 2) mcap = 2;
    const int nmax = mcap * b;

@@ -252,3 +252,16 @@ def test_product_reproduces_survey_known_answers(golden_dir, fp, accum):
         if "pve1" in kat:
             assert abs(r["pve"][0] - kat["pve1"]) < 1e-11
             assert ["%.7g" % v for v in r["values"]] == kat["eigenvalues_txt"]
+
+
+def test_randomised_end_to_end_sweep(built_lib):
+    """scripts/fuzz_pca.py: 40 random small problems (N, P, k up to the reference's limit, standardisation, divisor,
+    arithmetic mode, duplicated samples, fewer samples than three blocks) against numpy's dense eigendecomposition:
+    eigenvalues, orthonormality, per-pair residual, Px, pve, loadings."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_pca.py"), "40", "11"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all 40 cases ok" in r.stdout

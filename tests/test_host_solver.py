@@ -120,6 +120,24 @@ def test_not_converged_is_reported(golden_dir):
     assert rc == -1  # FPCA_EINVAL
 
 
+@pytest.mark.parametrize("N,P,k", [(61, 400, 20), (40, 300, 19), (17, 50, 8), (95, 64, 20), (33, 2000, 16)])
+def test_few_samples_take_the_dense_path(N, P, k):
+    """N < 3 x block width (the reference admits any k <= (min(N,P)-1)/2, flashpca.cpp:623-633): no room for a block
+    Krylov basis, X X' is formed from applies on the identity and decomposed directly."""
+    rng = np.random.default_rng(N)
+    packed = rng.integers(0, 256, size=(P, (N + 3) // 4), dtype=np.uint8)
+    d = O.OracleData(packed=packed, N=N, P=P, stand="binom2")
+    X = d.dense()
+    w, v = np.linalg.eigh(X @ X.T / P)
+    w, v = w[::-1], v[:, ::-1]
+    rc, r = run_pca(d, k)
+    assert rc == 0 and r["converged"] == 1
+    assert r["applies"] == -(-N // r["b"])
+    assert np.max(np.abs(r["d"] - w[:k])) < 1e-10 * w[0]
+    assert np.max(np.abs(r["U"].T @ r["U"] - np.eye(k))) < 1e-10
+    assert np.max(np.abs(X @ (X.T @ r["U"]) / P - r["U"] * r["d"])) < 1e-9 * w[0]
+
+
 def test_low_rank_matrix_deflation():
     """rank(X) < block width: the Krylov space closes after one step; the solver must deflate, not blow up."""
     rng = np.random.default_rng(3)
