@@ -103,3 +103,15 @@ def test_cli_end_to_end(tmp_path, built_lib):
     # ndim limit (flashpca.cpp:623-633)
     r = run(["--bfile", DATA, "--ndim", "500", "--notime"], cwd=tmp_path)
     assert r.returncode == 1 and "You asked for 500 dimensions, but only 478allowed" in r.stderr
+
+
+@pytest.mark.gpu
+def test_randomised_cli_sweep(built_lib):
+    """scripts/fuzz_cli.py: 12 random filesets through the binary (PCA with loadings and mean/sd, --project of the same
+    samples == the PCs, --check), every output file compared with numpy at the written precision."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_cli.py"), "12", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all 12 cases ok" in r.stdout
