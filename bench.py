@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the bounded baseline sample")
     args = ap.parse_args()
 
+    # the host driver of these boxes only supports dmabuf IPC; RCCL across processes needs this (already exported there)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
