@@ -165,7 +165,9 @@ int fpca_set_total_snps(fpca_ctx *ctx, uint64_t P_total);
  * Driver.  Replaces RandomPCA::pca_fast(Data&, block_size, ndim, maxiter, tol, seed, do_loadings)
  * (randompca.cpp:168-218) with a block Krylov-Schur eigensolver whose basis stays in HBM; the projected
  * (m*b x m*b) Rayleigh-Ritz problem is solved on the host.  Convergence rule per Ritz pair is the one the
- * reference's Spectra solver applies: ||A u - theta u|| < tol * max(eps^(2/3), |theta|) for the ndim largest. */
+ * reference's Spectra solver applies: ||A u - theta u|| < tol * max(eps^(2/3), |theta|) for the ndim largest.
+ * With fewer than three block widths of samples (N < 3 b; the reference admits ndim <= (min(N,P)-1)/2, flashpca.cpp:623-633)
+ * X X' is formed from ceil(N/b) applies on the identity and decomposed directly. */
 typedef struct fpca_pca_opts {
    int ndim;        /* --ndim (flashpca.cpp:325 default 10) */
    int blockvec;    /* block width b (multiple of 16, <= 64); 0 = smallest multiple of 16 >= ndim + 4 */
