@@ -15,9 +15,19 @@
 #include <ctime>
 #include <iostream>
 #include <map>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include <atomic>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <hip/hip_runtime_api.h>
 
 #include "../../include/fpca.h"
 #include "plink_io.hpp"
@@ -81,7 +91,8 @@ const OptSpec OPTS[] = {
    {"precision", 0, true, "digits of precision for output"},
    {"notime", 0, false, "don't print timestamp in output"},
    {"version", 0, false, "version"},
-   {"device", 0, true, "HIP device index [0]"},
+   {"device", 0, true, "HIP device index [0] (with --gpus G: the first of G consecutive devices)"},
+   {"gpus", 0, true, "number of GPUs for PCA [1]: the SNPs are split into that many contiguous shards, one process per GPU, partial products summed by an RCCL all-reduce"},
    {"blockvec", 0, true, "block width of the eigensolver: 16, 32, 48 or 64 [smallest multiple of 16 >= ndim+4]"},
    {"maxblocks", 0, true, "basis cap (in blocks) before a thick restart [automatic]"},
    {"accum", 0, true, "arithmetic of the two genotype GEMMs [auto | fp64 | fp32 | i8 | i8xS]: i8 = exact-integer int8 MFMA on S = 7 (i8xS: S = 2..8) byte slices of the fp64 operand, results equal to fp64; fp32 = fp32 MFMA products, fp64 long accumulation; auto (default) = i8, or fp64 if the int8 buffers do not fit"},
@@ -183,6 +194,75 @@ void fpca_ok(int rc)
 }
 
 } // namespace
+
+// ---- --gpus G: one process per GPU -------------------------------------------------------------------------------------
+// The parent parses the command line and the .fam/.bim, maps one shared region, and forks G - 1 children BEFORE anything
+// touches HIP; every process (the parent is rank 0) opens its contiguous SNP shard of the .bed on its own device, joins
+// the RCCL communicator (id made by rank 0, handed over through the shared region) and runs the same fpca_pca -- the host
+// algebra is replicated and deterministic, the only data-path exchange is the all-reduce inside the block apply
+// (DESIGN section 5).  Eigenvectors / eigenvalues are identical on every rank; the loadings and mean/sd rows of each shard
+// are deposited in the shared region and rank 0 writes every file.
+struct MultiShared {
+   std::atomic<int> created, failed, id_ready, bar_count, bar_sense;
+   uint8_t id[FPCA_UNIQUE_ID_BYTES];
+   char msg[512];
+};
+
+struct Multi {
+   int ngpus = 1, rank = 0;
+   MultiShared *sh = nullptr;
+   double *V = nullptr, *meansd = nullptr; // P x k and P x 2, column-major, in the shared region
+   double *slots = nullptr;                // FPCA_CLI_TEST_TRANSPORT=shm only: G x slot_cap doubles
+   size_t slot_cap = 0;
+   std::vector<pid_t> children;
+   bool test_transport = false;
+};
+
+// set in the children of a --gpus run: an exception there must not fall through to rank 0's output code
+static int g_child_rank = 0;
+static MultiShared *g_shared = nullptr;
+
+void multi_fail(Multi &m, const std::string &why)
+{
+   if (!m.sh) return;
+   if (m.sh->failed.fetch_add(1) == 0) std::snprintf(m.sh->msg, sizeof(m.sh->msg), "rank %d: %s", m.rank, why.c_str());
+}
+
+// all ranks arrive, or somebody failed (returns false)
+bool multi_barrier(Multi &m)
+{
+   MultiShared *sh = m.sh;
+   const int sense = sh->bar_sense.load();
+   if (sh->bar_count.fetch_add(1) + 1 == m.ngpus) {
+      sh->bar_count.store(0);
+      sh->bar_sense.store(sense ^ 1);
+      return sh->failed.load() == 0;
+   }
+   while (sh->bar_sense.load() == sense) {
+      if (sh->failed.load()) return false;
+      sched_yield();
+   }
+   return sh->failed.load() == 0;
+}
+
+// Test transport (FPCA_CLI_TEST_TRANSPORT=shm): every rank on the SAME device, the sum staged through host shared
+// memory in rank order -- exercises the launcher, the sharding and the gather of the outputs on a one-GPU box, where RCCL
+// refuses two ranks on one device.  Not a product path.
+int shm_allreduce(void *user, double *dbuf, uint64_t count, void *stream)
+{
+   Multi &m = *static_cast<Multi *>(user);
+   if (count > m.slot_cap) return -1;
+   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+   if (hipMemcpy(m.slots + (size_t)m.rank * m.slot_cap, dbuf, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+   if (!multi_barrier(m)) return -1;
+   std::vector<double> sum(count, 0.0);
+   for (int r = 0; r < m.ngpus; r++) {
+      const double *p = m.slots + (size_t)r * m.slot_cap;
+      for (uint64_t i = 0; i < count; i++) sum[i] += p[i];
+   }
+   if (!multi_barrier(m)) return -1; // nobody overwrites a slot before everyone has read it
+   return hipMemcpy(dbuf, sum.data(), count * sizeof(double), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
 
 int main(int argc, char *argv[])
 {
@@ -362,6 +442,15 @@ int main(int argc, char *argv[])
          }
       }
       const int device = has("device") ? (int)to_long(vm, "device") : 0;
+      const int ngpus = has("gpus") ? (int)to_long(vm, "gpus") : 1;
+      if (ngpus < 1 || ngpus > 64) {
+         std::cerr << "Error: --gpus must be between 1 and 64" << std::endl;
+         return EXIT_FAILURE;
+      }
+      if (ngpus > 1 && mode != MODE_PCA) {
+         std::cerr << "Error: --gpus applies to PCA only (--check and --project run on one GPU)" << std::endl;
+         return EXIT_FAILURE;
+      }
       const int blockvec = has("blockvec") ? (int)to_long(vm, "blockvec") : 0;
       const int maxblocks = has("maxblocks") ? (int)to_long(vm, "maxblocks") : 0;
       int accum = FPCA_ACCUM_AUTO;
@@ -384,9 +473,10 @@ int main(int argc, char *argv[])
 
       // FPCA_TIMING=1: wall-clock of each phase on stderr
       const bool phase_timing = std::getenv("FPCA_TIMING") != nullptr;
+      bool quiet = false; // ranks > 0 of a --gpus run
       auto phase = [&, last = std::chrono::steady_clock::now()](const char *what) mutable {
          const auto now = std::chrono::steady_clock::now();
-         if (phase_timing) std::fprintf(stderr, "[fpca-cli] %-32s %8.3f ms\n", what, std::chrono::duration<double>(now - last).count() * 1e3);
+         if (phase_timing && !quiet) std::fprintf(stderr, "[fpca-cli] %-32s %8.3f ms\n", what, std::chrono::duration<double>(now - last).count() * 1e3);
          last = now;
       };
       // N = number of rows of the .fam whose 6th column parses as a number (flashpca.cpp:589 -> data.cpp:408-413)
@@ -399,13 +489,97 @@ int main(int argc, char *argv[])
       phase(".fam / .bim");
 
       fpca_ctx *ctx = nullptr;
-      uint64_t nsnps = 0;
-      fpca_ok(fpca_create_from_bed(&ctx, geno_file.c_str(), N, 0, 0, stand_method_x, device, accum, &nsnps));
+      uint64_t nsnps = 0; // SNPs in the file (all shards)
+      Multi mg;
+      mg.ngpus = ngpus;
+      uint64_t snp_begin = 0, snp_count = 0; // this rank's shard (0, 0 = the whole file)
+      if (ngpus > 1) {
+         struct stat st;
+         if (stat(geno_file.c_str(), &st) != 0) throw std::runtime_error("[Data::read_bed] Error reading file " + geno_file + ": " + strerror(errno));
+         const uint64_t np = (N + 3) / 4;
+         const uint64_t P_file = (uint64_t)st.st_size > 3 ? ((uint64_t)st.st_size - 3) / np : 0; // data.cpp:165-170
+         if (P_file < (uint64_t)ngpus) throw std::runtime_error("fewer SNPs than GPUs");
+         const char *tt = std::getenv("FPCA_CLI_TEST_TRANSPORT");
+         mg.test_transport = tt && std::string(tt) == "shm";
+         mg.slot_cap = mg.test_transport ? (size_t)(N + 1024) * 64 : 0;
+         const size_t head = (sizeof(MultiShared) + 63) / 64 * 64;
+         const size_t bytes = head + ((size_t)P_file * (n_dim + 2) + (size_t)ngpus * mg.slot_cap) * sizeof(double);
+         void *mem = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+         if (mem == MAP_FAILED) throw std::runtime_error(std::string("mmap of the shared region failed: ") + strerror(errno));
+         mg.sh = new (mem) MultiShared();
+         mg.sh->created = 0;
+         mg.sh->failed = 0;
+         mg.sh->id_ready = 0;
+         mg.sh->bar_count = 0;
+         mg.sh->bar_sense = 0;
+         mg.sh->msg[0] = 0;
+         mg.V = reinterpret_cast<double *>(static_cast<char *>(mem) + head);
+         mg.meansd = mg.V + (size_t)P_file * n_dim;
+         mg.slots = mg.meansd + (size_t)P_file * 2;
+         std::cout.flush();
+         std::fflush(nullptr);
+         for (int r = 1; r < ngpus; r++) { // nothing has touched HIP yet: the children initialise their own runtime
+            const pid_t pid = fork();
+            if (pid < 0) {
+               multi_fail(mg, std::string("fork failed: ") + strerror(errno));
+               break;
+            }
+            if (pid == 0) {
+               mg.rank = r;
+               mg.children.clear();
+               g_child_rank = r;
+               g_shared = mg.sh;
+               quiet = true;
+               std::cout.setstate(std::ios::failbit); // progress lines come from rank 0 only
+               break;
+            }
+            mg.children.push_back(pid);
+         }
+         snp_begin = P_file * (uint64_t)mg.rank / (uint64_t)ngpus;
+         snp_count = P_file * (uint64_t)(mg.rank + 1) / (uint64_t)ngpus - snp_begin;
+      }
+      // a rank that cannot go on says so in the shared region and everybody leaves at the next rendezvous
+      auto multi_abort = [&](void) -> int {
+         if (mg.rank > 0) {
+            if (ctx) fpca_destroy(ctx);
+            _exit(1);
+         }
+         for (pid_t pid : mg.children) (void)waitpid(pid, nullptr, 0);
+         std::cerr << timestamp() << "Exception: " << mg.sh->msg << std::endl << timestamp() << "Terminating" << std::endl;
+         if (ctx) fpca_destroy(ctx);
+         return EXIT_FAILURE;
+      };
+      const int my_device = device + ((ngpus > 1 && !mg.test_transport) ? mg.rank : 0);
+      if (ngpus == 1)
+         fpca_ok(fpca_create_from_bed(&ctx, geno_file.c_str(), N, 0, 0, stand_method_x, device, accum, &nsnps));
+      else {
+         if (mg.sh->failed.load() == 0) {
+            if (fpca_create_from_bed(&ctx, geno_file.c_str(), N, snp_begin, snp_count, stand_method_x, my_device, accum, &nsnps) != FPCA_OK)
+               multi_fail(mg, fpca_last_error());
+            else if (fpca_set_total_snps(ctx, nsnps) != FPCA_OK)
+               multi_fail(mg, fpca_last_error());
+         }
+         if (!multi_barrier(mg)) return multi_abort();
+         if (mg.test_transport) {
+            if (fpca_set_allreduce(ctx, shm_allreduce, &mg) != FPCA_OK) multi_fail(mg, fpca_last_error());
+         } else {
+            if (mg.rank == 0) {
+               if (fpca_comm_unique_id(mg.sh->id) != FPCA_OK) multi_fail(mg, fpca_last_error());
+               mg.sh->id_ready.store(1);
+            } else
+               while (!mg.sh->id_ready.load() && !mg.sh->failed.load()) sched_yield();
+            if (mg.sh->failed.load() == 0 && fpca_comm_init_rank(ctx, ngpus, mg.rank, mg.sh->id) != FPCA_OK) multi_fail(mg, fpca_last_error());
+         }
+         if (!multi_barrier(mg)) return multi_abort();
+      }
       phase("device init + .bed upload");
       verbose && std::cout << timestamp() << "Detected BED file: " << geno_file << " with " << N << " samples, " << nsnps << " SNPs." << std::endl;
       if (verbose) {
          char name[256];
-         if (fpca_device_name(device, name, sizeof(name)) == FPCA_OK) std::cout << timestamp() << "Device " << device << ": " << name << std::endl;
+         if (fpca_device_name(my_device, name, sizeof(name)) == FPCA_OK) std::cout << timestamp() << "Device " << my_device << ": " << name << std::endl;
+         if (ngpus > 1)
+            std::cout << timestamp() << ngpus << " GPUs, " << snp_count << " SNPs on this one; transport: "
+                      << (mg.test_transport ? "host shared memory (test)" : "RCCL") << std::endl;
       }
 
       // flashpca.cpp:623-633
@@ -433,14 +607,45 @@ int main(int argc, char *argv[])
          o.max_blocks = maxblocks;
          o.verbose = verbose ? 1 : 0;
          o.seed = (uint64_t)seed;
-         U.resize((size_t)N * n_dim);
-         Px.resize((size_t)N * n_dim);
          d.resize(n_dim);
          pve.resize(n_dim);
-         if (do_loadings) V.resize((size_t)nsnps * n_dim);
-         meansd.resize((size_t)nsnps * 2);
          fpca_pca_info info;
-         int rc = fpca_pca(ctx, &o, U.data(), d.data(), Px.data(), pve.data(), do_loadings ? V.data() : nullptr, meansd.data(), &info);
+         int rc;
+         if (ngpus == 1) {
+            U.resize((size_t)N * n_dim);
+            Px.resize((size_t)N * n_dim);
+            if (do_loadings) V.resize((size_t)nsnps * n_dim);
+            meansd.resize((size_t)nsnps * 2);
+            rc = fpca_pca(ctx, &o, U.data(), d.data(), Px.data(), pve.data(), do_loadings ? V.data() : nullptr, meansd.data(), &info);
+         } else {
+            // eigenvectors / PCs are identical on every rank: only rank 0 downloads them; loadings and mean/sd are this
+            // shard's rows and go into the shared region at their place
+            const uint64_t P_loc = fpca_nsnps(ctx);
+            std::vector<double> Vloc, msloc((size_t)P_loc * 2);
+            if (do_loadings) Vloc.resize((size_t)P_loc * n_dim);
+            if (mg.rank == 0) {
+               U.resize((size_t)N * n_dim);
+               Px.resize((size_t)N * n_dim);
+            } else
+               o.verbose = 0;
+            rc = fpca_pca(ctx, &o, mg.rank == 0 ? U.data() : nullptr, d.data(), mg.rank == 0 ? Px.data() : nullptr, pve.data(),
+                          do_loadings ? Vloc.data() : nullptr, msloc.data(), &info);
+            if (rc != FPCA_OK && rc != FPCA_ENOTCONVERGED) multi_fail(mg, fpca_last_error());
+            for (int c = 0; c < n_dim && do_loadings; c++)
+               std::memcpy(mg.V + (size_t)c * nsnps + snp_begin, Vloc.data() + (size_t)c * P_loc, P_loc * sizeof(double));
+            for (int c = 0; c < 2; c++)
+               std::memcpy(mg.meansd + (size_t)c * nsnps + snp_begin, msloc.data() + (size_t)c * P_loc, P_loc * sizeof(double));
+            const bool all_ok = multi_barrier(mg);
+            if (mg.rank > 0) {
+               fpca_destroy(ctx);
+               _exit(all_ok && rc == FPCA_OK ? 0 : 1);
+            }
+            for (pid_t pid : mg.children) (void)waitpid(pid, nullptr, 0);
+            mg.children.clear();
+            if (!all_ok) return multi_abort();
+            if (do_loadings) V.assign(mg.V, mg.V + (size_t)nsnps * n_dim);
+            meansd.assign(mg.meansd, mg.meansd + (size_t)nsnps * 2);
+         }
          if (rc == FPCA_ENOTCONVERGED) // randompca.cpp:210-217
             throw std::runtime_error("Spectra eigen-decomposition was not successful, status: not converging");
          fpca_ok(rc);
@@ -554,9 +759,17 @@ int main(int argc, char *argv[])
    } catch (std::exception &e) {
       std::cerr << timestamp() << "Exception: " << e.what() << std::endl;
       std::cerr << timestamp() << "Terminating" << std::endl;
+      if (g_child_rank > 0) {
+         if (g_shared) g_shared->failed.fetch_add(1);
+         _exit(1);
+      }
       return EXIT_FAILURE;
    } catch (...) {
       std::cerr << timestamp() << "Caught unknown exception, terminating " << std::endl;
+      if (g_child_rank > 0) {
+         if (g_shared) g_shared->failed.fetch_add(1);
+         _exit(1);
+      }
       return EXIT_FAILURE;
    }
    return EXIT_SUCCESS;

@@ -115,3 +115,47 @@ def test_randomised_cli_sweep(built_lib):
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_cli.py"), "12", "3"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all 12 cases ok" in r.stdout
+
+
+def _tab(path, skip=2):
+    return np.array([l.split("\t")[skip:] for l in open(path).read().splitlines()[1:]], dtype=float)
+
+
+@pytest.mark.gpu
+def test_cli_gpus_launcher(tmp_path, built_lib, golden_dir):
+    """flashpca --gpus G: one process per SNP shard, the parent is rank 0 and writes every file.  On a one-GPU box the
+    ranks share the device and sum their partial products through host shared memory (FPCA_CLI_TEST_TRANSPORT=shm -- RCCL
+    refuses two ranks on one device), which exercises the fork / rendezvous / sharding / gather logic; every output must
+    equal the single-process run.  Without the test transport the run either works (enough GPUs: real RCCL) or ends with
+    the out-of-range device message, never a hang."""
+    import flashpca_amd as fp
+
+    data = os.path.join(golden_dir, "hapmap3_data")
+    base = ["--bfile", data, "--ndim", "10", "--outload", "load.txt", "--outmeansd", "ms.txt", "--precision", "12"]
+    outs = {}
+    for g, env_extra in ((1, {}), (2, {"FPCA_CLI_TEST_TRANSPORT": "shm"}), (3, {"FPCA_CLI_TEST_TRANSPORT": "shm"})):
+        d = tmp_path / ("g%d" % g)
+        d.mkdir()
+        args = [fp.CLI_PATH] + base + (["--gpus", str(g)] if g > 1 else [])
+        r = subprocess.run(args, cwd=d, capture_output=True, text=True, env=dict(os.environ, **env_extra), timeout=300)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        assert r.stdout.count("Goodbye!") == 1 and r.stdout.count("PCA done") == 1  # only rank 0 talks
+        outs[g] = d
+    e1 = np.loadtxt(outs[1] / "eigenvalues.txt")
+    U1, V1, m1 = _tab(outs[1] / "eigenvectors.txt"), _tab(outs[1] / "load.txt"), _tab(outs[1] / "ms.txt")
+    for g in (2, 3):
+        e, U, V, m = np.loadtxt(outs[g] / "eigenvalues.txt"), _tab(outs[g] / "eigenvectors.txt"), _tab(outs[g] / "load.txt"), _tab(outs[g] / "ms.txt")
+        sg = np.sign(np.sum(U1 * U, axis=0))
+        assert np.max(np.abs(e - e1) / e1) < 1e-10
+        assert np.max(np.abs(U * sg - U1)) < 1e-9 and np.max(np.abs(V * sg - V1)) < 1e-9
+        assert np.array_equal(m, m1)
+        assert np.max(np.abs(_tab(outs[g] / "pcs.txt") * sg - _tab(outs[1] / "pcs.txt"))) < 1e-8
+    d = tmp_path / "real"
+    d.mkdir()
+    r = subprocess.run([fp.CLI_PATH] + base + ["--gpus", "2"], cwd=d, capture_output=True, text=True, timeout=300)
+    if r.returncode == 0:
+        assert np.max(np.abs(np.loadtxt(d / "eigenvalues.txt") - e1) / e1) < 1e-10
+    else:
+        assert "device index out of range" in r.stderr
+    r = subprocess.run([fp.CLI_PATH, "--bfile", data, "--check", "--gpus", "2"], cwd=d, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "--gpus applies to PCA only" in r.stderr
