@@ -501,6 +501,9 @@ int main(int argc, char *argv[])
          if (P_file < (uint64_t)ngpus) throw std::runtime_error("fewer SNPs than GPUs");
          const char *tt = std::getenv("FPCA_CLI_TEST_TRANSPORT");
          mg.test_transport = tt && std::string(tt) == "shm";
+         if (mg.test_transport)
+            std::cerr << "[fpca-cli] FPCA_CLI_TEST_TRANSPORT=shm: all ranks share one device and exchange through host memory -- a test "
+                         "hook for one-GPU boxes, not a way to run" << std::endl;
          mg.slot_cap = mg.test_transport ? (size_t)(N + 1024) * 64 : 0;
          const size_t head = (sizeof(MultiShared) + 63) / 64 * 64;
          const size_t bytes = head + ((size_t)P_file * (n_dim + 2) + (size_t)ngpus * mg.slot_cap) * sizeof(double);
