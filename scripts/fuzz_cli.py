@@ -1,6 +1,7 @@
 """Randomised sweep of the process boundary (GPU): random PLINK filesets on disk -> the flashpca binary -> its text outputs
 against numpy (eigenvalues, eigenvectors up to sign, PCs, pve, loadings, mean/sd), then --project and --check on the
-same files.  Exercises N % 4 != 0, tabs / multiple spaces as separators, missing calls, --standx / --div / --precision.  python scripts/fuzz_cli.py [cases] [seed]"""
+same files.  Exercises N % 4 != 0, tabs / multiple spaces as separators, missing calls, --standx / --div / --precision,
+and the --gpus launcher (2-4 ranks on one device through the test transport).  python scripts/fuzz_cli.py [cases] [seed]"""
 import os, subprocess, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -58,8 +59,13 @@ for case in range(ncases):
         w, v = w[::-1], v[:, ::-1]
         args = [CLI, "--bfile", pre, "--ndim", str(k), "--standx", stand, "--div", div, "--precision", str(prec), "--outload", "load.txt",
                 "--outmeansd", "ms.txt", "--tol", "1e-9"]
-        r = subprocess.run(args, cwd=td, capture_output=True, text=True)
-        desc = dict(N=N, P=P, k=k, stand=stand, div=div, prec=prec)
+        G = int(rng.choice([1, 1, 2, 3, 4]))  # --gpus G through the host-shared-memory test transport (one GPU here)
+        env = dict(os.environ)
+        if G > 1:
+            args += ["--gpus", str(G)]
+            env["FPCA_CLI_TEST_TRANSPORT"] = "shm"
+        r = subprocess.run(args, cwd=td, capture_output=True, text=True, env=env)
+        desc = dict(N=N, P=P, k=k, stand=stand, div=div, prec=prec, gpus=G)
         if r.returncode != 0:
             print("case", case, desc, "CLI FAILED", r.stdout[-500:], r.stderr[-500:])
             sys.exit(1)
