@@ -133,6 +133,7 @@ struct fpca_ctx {
    double *be_C = nullptr, *be_gpart = nullptr;
    size_t be_C_cap = 0, be_gpart_cap = 0, be_pin_cap = 0;
    void *be_pin = nullptr;
+   void *dl_pin = nullptr; // pinned landing zone for small downloads (HipBackend::download)
    // communication
    ncclComm_t comm = nullptr;
    int nranks = 1, rank = 0;
@@ -249,6 +250,7 @@ void ctx_free(fpca_ctx *c)
    if (c->be_C) (void)hipFree(c->be_C);
    if (c->be_gpart) (void)hipFree(c->be_gpart);
    if (c->be_pin) (void)hipHostFree(c->be_pin);
+   if (c->dl_pin) (void)hipHostFree(c->dl_pin);
    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
    for (hipEvent_t e : c->ev_chunk)
       if (e) (void)hipEventDestroy(e);
@@ -660,6 +662,8 @@ void ensure_io(fpca_ctx *c)
 }
 
 // ---- HIP backend for the eigensolver ---------------------------------------------------------------
+constexpr size_t DL_PIN_BYTES = (size_t)32 << 20;
+
 class HipBackend : public BlockBackend {
  public:
    HipBackend(fpca_ctx *c, int b)
@@ -779,6 +783,18 @@ class HipBackend : public BlockBackend {
    {
       c_->ensure(c_->d_stage, c_->stage_cap, (size_t)c_->N * ncols);
       kern::block_to_colmajor(blocks_[h], c_->N, b_, ncols, c_->d_stage, c_->N, c_->stream);
+      const size_t bytes = (size_t)c_->N * ncols * sizeof(double);
+      if (bytes <= DL_PIN_BYTES) {
+         // small results go through a pinned buffer of our own: a direct copy makes the runtime register the caller's
+         // pages for DMA, and when the caller later frees them (a Python loop dropping the previous result) the
+         // invalidation stalls the next submission by 20-30 ms -- more than a whole solve at this size
+         if (!c_->dl_pin) HIP_CHECK(hipHostMalloc(&c_->dl_pin, DL_PIN_BYTES, hipHostMallocDefault));
+         HIP_CHECK(hipMemcpyAsync(c_->dl_pin, c_->d_stage, bytes, hipMemcpyDeviceToHost, c_->stream));
+         HIP_CHECK(hipStreamSynchronize(c_->stream));
+         for (int c = 0; c < ncols; c++)
+            std::memcpy(host + (size_t)c * ld, static_cast<const double *>(c_->dl_pin) + (size_t)c * c_->N, c_->N * sizeof(double));
+         return;
+      }
       HIP_CHECK(hipMemcpy2DAsync(host, (size_t)ld * sizeof(double), c_->d_stage, c_->N * sizeof(double),
                                  c_->N * sizeof(double), ncols, hipMemcpyDeviceToHost, c_->stream));
       HIP_CHECK(hipStreamSynchronize(c_->stream));
@@ -1281,7 +1297,10 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
       const uint64_t max_dim = lim >= 1 ? (lim - 1) / 2 : 0;
       if (k < 1 || (uint64_t)k > max_dim)
          throw Error(FPCA_EINVAL, "You asked for " + std::to_string(k) + " dimensions, but only " + std::to_string(max_dim) + " allowed");
-      const int b = choose_blockvec(k, opts->blockvec);
+      int b = choose_blockvec(k, opts->blockvec);
+      // the exact-integer path has its sparse missing-indicator route for widths 16 / 32 / 64 only, and 64 columns cost it
+      // less than 48 (43 vs 56 ms per apply at 500k x 100k): the automatic choice skips 48 there
+      if (opts->blockvec <= 0 && b == 48 && ctx->i8_S > 0) b = 64;
       const bool timing = std::getenv("FPCA_TIMING") != nullptr;
       auto tp0 = std::chrono::steady_clock::now();
       auto lap = [&](const char *what) {
