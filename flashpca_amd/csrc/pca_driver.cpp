@@ -1,6 +1,7 @@
 // pca_driver.cpp -- see pca_driver.hpp.  Post-processing follows randompca.cpp:180-208 line by line.
 #include "pca_driver.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -38,6 +39,11 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
    so.max_applies = o.maxiter > 0 ? o.maxiter : 500;
    so.tol = o.tol > 0 ? o.tol : 1e-6;
    so.max_blocks = o.max_blocks;
+   // basis cap when the caller leaves it open: the projected eigenproblem costs O((cap b)^3) on the host at every restart
+   // whatever the data size, a block apply O(N P b) on the device -- small problems with slowly converging spectra are
+   // better off with half the basis (256 columns) and a few more applies.  Decided from the problem size, not from
+   // timings, so that every rank of a multi-GPU run decides alike.
+   if (so.max_blocks <= 0 && (double)N * (double)P_div < 1e10) so.max_blocks = std::max(4, 256 / be.width());
    so.seed = o.seed ? o.seed : 1;
    so.verbose = o.verbose;
    SolverResult r = block_krylov_schur(be, so);

@@ -201,6 +201,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    std::vector<double> S, Srow; // eigenvectors of T (n x n, ld n; only when needed) / their last b rows (b x n)
    int n = 0;
    uint64_t reseed = o.seed * 7919 + 13;
+   int skip_rr = 0; // Rayleigh-Ritz tests to skip (set after a test that ended far from convergence)
 
    while (res.block_applies < o.max_applies) {
       const int m = (int)V.size();
@@ -303,6 +304,16 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
             const double h = 0.5 * (H[((size_t)(m - 1) * b + p) * b + c] + H[((size_t)(m - 1) * b + c) * b + p]);
             Tat((m - 1) * b + p, (m - 1) * b + c) = h;
          }
+      // Far from convergence the Rayleigh-Ritz test cannot succeed at the very next step (residuals fall by one to two
+      // orders of magnitude per block apply at best): it is skipped for a step (two when six orders away).  Convergence is
+      // only ever declared by an actual test, so the worst case is one block apply more than strictly needed.
+      if (skip_rr > 0 && res.block_applies < o.max_applies && m + 1 <= mcap) {
+         skip_rr--;
+         host_s += since(t0);
+         V.push_back(W);
+         W = be.alloc_block();
+         continue;
+      }
       for (int j = 0; j < n; j++) std::memcpy(&Tw[(size_t)j * n], &T[(size_t)j * nmax], sizeof(double) * n);
       // eigenvalues + the last block of rows of the eigenvectors (all the residual test needs); the full
       // eigenvector matrix is formed only when it is used: convergence, thick restart, last step
@@ -344,6 +355,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          break;
       }
       if (res.block_applies >= o.max_applies) break;
+      skip_rr = worst > 1e6 * o.tol ? 2 : worst > 1e3 * o.tol ? 1 : 0;
 
       if (m + 1 > mcap) {
          // ---- thick restart: keep the b best Ritz vectors + the new residual block -----------------
