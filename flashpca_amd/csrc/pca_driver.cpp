@@ -41,9 +41,9 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
    so.max_blocks = o.max_blocks;
    // basis cap when the caller leaves it open: the projected eigenproblem costs O((cap b)^3) on the host at every restart
    // whatever the data size, a block apply O(N P b) on the device -- small problems with slowly converging spectra are
-   // better off with half the basis (256 columns) and a few more applies.  Decided from the problem size, not from
+   // better off with half the basis (256 columns; six blocks at least, so that a restart can keep two) and a few more applies.  Decided from the problem size, not from
    // timings, so that every rank of a multi-GPU run decides alike.
-   if (so.max_blocks <= 0 && (double)N * (double)P_div < 1e10) so.max_blocks = std::max(4, 256 / be.width());
+   if (so.max_blocks <= 0 && (double)N * (double)P_div < 1e10) so.max_blocks = std::max(6, 256 / be.width());
    so.seed = o.seed ? o.seed : 1;
    so.verbose = o.verbose;
    SolverResult r = block_krylov_schur(be, so);

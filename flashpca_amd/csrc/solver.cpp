@@ -358,28 +358,35 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       skip_rr = worst > 1e6 * o.tol ? 2 : worst > 1e3 * o.tol ? 1 : 0;
 
       if (m + 1 > mcap) {
-         // ---- thick restart: keep the b best Ritz vectors + the new residual block -----------------
+         // ---- thick restart: keep the best Ritz vectors + the new residual block ----------------------
+         // nk blocks of them: one when the cap is tight, two otherwise (the second block of Ritz vectors keeps the
+         // neighbourhood of the wanted end of the spectrum in the basis, which is what slowly converging pairs need)
+         const int nk = (mcap >= 6 && m >= 3) ? 2 : 1;
          t0 = clk::now();
-         std::vector<double> Sk((size_t)m * b * b);
-         for (int q = 0; q < m; q++)
-            for (int p = 0; p < b; p++)
-               for (int c = 0; c < b; c++) Sk[((size_t)q * b + p) * b + c] = S[(size_t)(q * b + p) + (size_t)c * n];
-         std::vector<double> Cpl((size_t)b * b); // R * S[last block, 0:b]  (b x b, column-major)
-         matmul(b, b, b, R.data(), b, &S[(size_t)(m - 1) * b], n, Cpl.data(), b);
+         std::vector<std::vector<double>> Sk(nk, std::vector<double>((size_t)m * b * b));
+         std::vector<double> Cpl((size_t)b * b * nk); // R * S[last block, 0 : nk b]  (b x nk b, column-major)
+         for (int j = 0; j < nk; j++)
+            for (int q = 0; q < m; q++)
+               for (int p = 0; p < b; p++)
+                  for (int c = 0; c < b; c++) Sk[j][((size_t)q * b + p) * b + c] = S[(size_t)(q * b + p) + (size_t)(j * b + c) * n];
+         matmul(b, nk * b, b, R.data(), b, &S[(size_t)(m - 1) * b], n, Cpl.data(), b);
          host_s += since(t0);
-         int Y = be.alloc_block();
-         be.gemm(V.data(), m, Sk.data(), -1, Y);
+         std::vector<int> Y(nk);
+         for (int j = 0; j < nk; j++) {
+            Y[j] = be.alloc_block();
+            be.gemm(V.data(), m, Sk[j].data(), -1, Y[j]);
+         }
          for (int q = 0; q < m; q++) be.free_block(V[q]);
          V.clear();
-         V.push_back(Y);
+         for (int j = 0; j < nk; j++) V.push_back(Y[j]);
          V.push_back(W);
          W = be.alloc_block();
          std::fill(T.begin(), T.end(), 0.0);
-         for (int i = 0; i < b; i++) Tat(i, i) = theta[i];
+         for (int i = 0; i < nk * b; i++) Tat(i, i) = theta[i];
          for (int r = 0; r < b; r++)
-            for (int c = 0; c < b; c++) {
-               Tat(b + r, c) = Cpl[(size_t)r + (size_t)c * b];
-               Tat(c, b + r) = Cpl[(size_t)r + (size_t)c * b];
+            for (int c = 0; c < nk * b; c++) {
+               Tat(nk * b + r, c) = Cpl[(size_t)r + (size_t)c * b];
+               Tat(c, nk * b + r) = Cpl[(size_t)r + (size_t)c * b];
             }
          res.restarts++;
       } else {
