@@ -342,9 +342,19 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       }
       res.max_rel_residual = worst;
       if (all_conv || res.block_applies >= o.max_applies || m + 1 > mcap) {
+         // eigenvectors are needed now, but only the leading 2 b of them (Ritz vectors kept by a restart / returned):
+         // selected columns by inverse iteration, verified inside; the full QL decomposition is the fallback
+         const int need = std::min(n, 2 * b);
+         std::vector<double> th(n);
+         S.assign((size_t)n * need, 0.0);
          for (int j = 0; j < n; j++) std::memcpy(&Tw[(size_t)j * n], &T[(size_t)j * nmax], sizeof(double) * n);
-         if (symeig_desc(n, Tw.data(), n, theta.data()) != 0) throw Error(-3, "solver: projected eigensolver failed");
-         S.assign(Tw.begin(), Tw.begin() + (size_t)n * n);
+         if (n > 3 * b && symeig_desc_cols(n, Tw.data(), n, th.data(), need, S.data()) == 0) {
+            std::copy(th.begin(), th.end(), theta.begin());
+         } else {
+            for (int j = 0; j < n; j++) std::memcpy(&Tw[(size_t)j * n], &T[(size_t)j * nmax], sizeof(double) * n);
+            if (symeig_desc(n, Tw.data(), n, theta.data()) != 0) throw Error(-3, "solver: projected eigensolver failed");
+            S.assign(Tw.begin(), Tw.begin() + (size_t)n * n);
+         }
       }
       host_s += since(t0);
       if (o.verbose)

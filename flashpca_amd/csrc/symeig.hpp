@@ -16,6 +16,10 @@ int symeig_desc(int n, double *A, int lda, double *w);
 // block of rows.
 int symeig_desc_rows(int n, double *A, int lda, double *w, int row0, int nrows, double *Zr);
 
+// Eigenvalues (all, descending) and only the first ncols eigenvectors (Z: n x ncols, ld n).  A is destroyed.  The vectors
+// are verified (residual, orthonormality); a nonzero return means "use symeig_desc" -- w is then unspecified.
+int symeig_desc_cols(int n, double *A, int lda, double *w, int ncols, double *Z);
+
 // Upper Cholesky factor: G = R' R, R overwrites the upper triangle of G (strict lower part zeroed).
 // Returns 0 on success, j+1 if the pivot of column j is not sufficiently positive (relative to rel_tol *
 // the largest original diagonal entry).

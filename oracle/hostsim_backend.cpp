@@ -240,6 +240,7 @@ long hostsim_read_bim(const char *filename, char *err, int errlen)
 
 /* dense symmetric eigensolver of the product (symeig.cpp) exposed for unit tests */
 int hostsim_symeig(int n, double *A, double *w) { return fpca::symeig_desc(n, A, n, w); }
+int hostsim_symeig_cols(int n, double *A, double *w, int ncols, double *Z) { return fpca::symeig_desc_cols(n, A, n, w, ncols, Z); }
 int hostsim_symeig_rows(int n, double *A, double *w, int row0, int nrows, double *Zr)
 {
    return fpca::symeig_desc_rows(n, A, n, w, row0, nrows, Zr);
