@@ -51,8 +51,9 @@ WORKLOADS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed block applies [400 / 60 / 12 for cfg2 / cfg3 / cfg5: a second or "
+                                                             "two of device time -- the first ~50 ms after idle run at ramping clocks]")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed block applies before them [20 / 5 / 2]")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--accum", default="i8", choices=["fp64", "fp32", "i8"] + ["i8x%d" % s for s in range(4, 9)],
                     help="i8[xS] (default: the product's default mode) = exact-integer int8 MFMA on S (default 7) byte slices of the "
@@ -93,6 +94,11 @@ def main():
     import flashpca_amd as fp
 
     w = WORKLOADS[args.workload]
+    if args.steps is None:
+        args.steps = {"cfg2": 400, "tiny": 400, "cfg3": 60, "cfg5": 12}[args.workload]
+    if args.warmup is None:
+        args.warmup = {"cfg2": 20, "tiny": 20, "cfg3": 5, "cfg5": 2}[args.workload]
+    steps_alt = min(args.steps, {"cfg2": 100, "tiny": 100, "cfg3": 20, "cfg5": 4}[args.workload])  # the other-mode comparison run
     N, k, b = w["N"], w["k"], w["b"]
     if w["scaling"] == "weak":
         P_rank, P_total, snp_begin = w["P"], w["P"] * world, rank * w["P"]
@@ -155,7 +161,11 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    ctx.profile_begin(args.steps)
+    # in-stream HIP events around K2 / K3 / their GEMM kernels / the all-reduce on every 4th step of the timed region (all of
+    # them when there are fewer than 8 steps): 8 events per apply cost 15 % at cfg2 size, and the clean steps are the ones
+    # the solver actually runs
+    stride = 4 if args.steps >= 8 else 1
+    ctx.profile_begin(args.steps, sample_every=stride)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.apply_xxt_dev(B.data_ptr(), b, Y.data_ptr())
@@ -199,6 +209,7 @@ def main():
                         peak_measured_pure_mfma_stream=3576.0)  # profiles/r01_mfma_i8_microbench.txt (random operands; power-limited)
         del roofline["flops_per_launch"]
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    roofline["hip_events_on_steps"] = "%d of %d (every %d%s step of the timed region)" % (prof["nsteps"], args.steps, stride, "th" if stride > 3 else "")
     if args.accum == "fp64":
         roofline["peak_measured_pure_mfma_stream"] = 74.3  # profiles/r01_mfma_f64_microbench.txt (2 waves/SIMD)
     # HBM traffic per launch of the dominant kernel from the committed PMC passes of this workload (bench.py cannot
@@ -253,9 +264,9 @@ def main():
             for _ in range(max(2, args.warmup)):
                 c2.apply_xxt_dev(B.data_ptr(), b, Y2.data_ptr())
             c2.synchronize()
-            c2.profile_begin(args.steps)
+            c2.profile_begin(steps_alt, sample_every=stride if steps_alt >= 8 else 1)
             t1 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(steps_alt):
                 c2.apply_xxt_dev(B.data_ptr(), b, Y2.data_ptr())
             c2.synchronize()
             el2 = time.perf_counter() - t1
@@ -270,7 +281,7 @@ def main():
             else:
                 rf = dict(bound="mfma", achieved=flops_launch / (ms2 * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                           frac=flops_launch / (ms2 * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, peak_measured_pure_mfma_stream=74.3)
-            alt = dict(accum=other, value=cells / el2, unit="cells/s", ms_per_step=el2 / args.steps * 1e3, ms_xt_b=p2["ms_xt"],
+            alt = dict(accum=other, value=cells / args.steps * steps_alt / el2, unit="cells/s", steps=steps_alt, ms_per_step=el2 / steps_alt * 1e3, ms_xt_b=p2["ms_xt"],
                        ms_x_t=p2["ms_x"], max_abs_diff_between_modes_over_max_abs=diff / scale, roofline=rf)
             if not args.no_pca:
                 t1 = time.perf_counter()

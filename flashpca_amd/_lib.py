@@ -100,6 +100,7 @@ SIGNATURES = {
     "fpca_check": (_I, [_P, _P, C.c_int64, _P, _I, _I, _P, C.POINTER(_D), C.POINTER(_D)]),
     "fpca_bench_apply": (_I, [_P, _I, _I, _I, C.POINTER(BenchResult)]),
     "fpca_profile_begin": (_I, [_P, _I]),
+    "fpca_profile_sample_every": (_I, [_P, _I]),
     "fpca_profile_end": (_I, [_P, _I, C.POINTER(BenchResult), C.POINTER(_I)]),
     "fpca_bench_stats": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D)]),
     "fpca_debug_mfma_probe": (_I, [_P, _P, _P]),

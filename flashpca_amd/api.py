@@ -206,7 +206,8 @@ class Context:
     def synchronize(self):
         check(lib().fpca_synchronize(self.h))
 
-    def profile_begin(self, max_steps):
+    def profile_begin(self, max_steps, sample_every=1):
+        check(lib().fpca_profile_sample_every(self.h, sample_every))
         check(lib().fpca_profile_begin(self.h, max_steps))
 
     def profile_end(self, b):

@@ -143,7 +143,7 @@ struct fpca_ctx {
    void *ar_user = nullptr;
    // live profiling (fpca_profile_begin/end)
    std::vector<hipEvent_t> prof_ev;
-   int prof_used = 0;
+   int prof_used = 0, prof_calls = 0, prof_stride = 1; // every prof_stride-th apply carries the events
    bool prof_on = false;
 
    void ensure(double *&p, size_t &cap, size_t need)
@@ -1213,7 +1213,8 @@ int fpca_apply_xxt_dev(fpca_ctx *ctx, const double *dB, int b, double *dY, void 
       if (b != 16 && b != 32 && b != 48 && b != 64) throw Error(FPCA_EINVAL, "device blocks must be 16, 32, 48 or 64 wide");
       HIP_CHECK(hipSetDevice(ctx->device));
       hipEvent_t *ev = nullptr;
-      if (ctx->prof_on && (size_t)(ctx->prof_used + 1) * 8 <= ctx->prof_ev.size()) ev = &ctx->prof_ev[(size_t)ctx->prof_used++ * 8];
+      if (ctx->prof_on && ctx->prof_calls++ % ctx->prof_stride == 0 && (size_t)(ctx->prof_used + 1) * 8 <= ctx->prof_ev.size())
+         ev = &ctx->prof_ev[(size_t)ctx->prof_used++ * 8];
       apply_xxt_dev(ctx, dB, b, dY, stream ? (hipStream_t)stream : ctx->stream, ev);
    });
 }
@@ -1433,7 +1434,16 @@ int fpca_profile_begin(fpca_ctx *ctx, int max_steps)
          ctx->prof_ev.push_back(e);
       }
       ctx->prof_used = 0;
+      ctx->prof_calls = 0;
       ctx->prof_on = true;
+   });
+}
+
+int fpca_profile_sample_every(fpca_ctx *ctx, int stride)
+{
+   return guarded([&] {
+      if (!ctx || stride < 1) throw Error(FPCA_EINVAL, "bad argument to fpca_profile_sample_every");
+      ctx->prof_stride = stride;
    });
 }
 

@@ -230,6 +230,10 @@ int fpca_bench_apply(fpca_ctx *ctx, int b, int steps, int warmup, fpca_bench_res
  * all-reduce; fpca_profile_end synchronises and returns the per-step averages over the recorded calls
  * (ms_total = sum of all recorded steps; *nsteps = number recorded). */
 int fpca_profile_begin(fpca_ctx *ctx, int max_steps);
+/* Eight in-stream events per apply are not free at small sizes (0.62 vs 0.53 ms per apply at 50,000 x 20,000): with
+ * stride > 1 only every stride-th apply of the profiled span carries them, the others run exactly as the solver runs
+ * them.  Default 1. */
+int fpca_profile_sample_every(fpca_ctx *ctx, int stride);
 int fpca_profile_end(fpca_ctx *ctx, int b, fpca_bench_result *res, int *nsteps);
 /* time the one-off statistics pass (K1) the same way: milliseconds per launch, bytes read */
 int fpca_bench_stats(fpca_ctx *ctx, int reps, double *ms_per_launch, double *bytes_per_launch);

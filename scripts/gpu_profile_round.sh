@@ -4,15 +4,15 @@ R=${1:-r01}
 mkdir -p gpurun_out/$R; export TMPDIR=/tmp
 PMC_SQ="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 # the default line (exact-integer mode; carries the fp64 kernels' numbers as fp64_mode) and the explicit modes
-python bench.py --steps 20 --warmup 3 > gpurun_out/$R/bench_cfg2_n1.json 2> gpurun_out/$R/bench_cfg2_n1.err
-python bench.py --workload cfg3 --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/$R/bench_cfg3_n1.json 2>/dev/null
+python bench.py > gpurun_out/$R/bench_cfg2_n1.json 2> gpurun_out/$R/bench_cfg2_n1.err
+python bench.py --workload cfg3 --no-cpu-baseline > gpurun_out/$R/bench_cfg3_n1.json 2>/dev/null
 for a in fp64 fp32 i8x6; do
-  python bench.py --accum $a --steps 20 --warmup 3 --no-cpu-baseline --no-alt > gpurun_out/$R/bench_cfg2_n1_$a.json 2>/dev/null
-  python bench.py --workload cfg3 --accum $a --steps 5 --warmup 1 --no-cpu-baseline --no-alt > gpurun_out/$R/bench_cfg3_n1_$a.json 2>/dev/null
+  python bench.py --accum $a --no-cpu-baseline --no-alt > gpurun_out/$R/bench_cfg2_n1_$a.json 2>/dev/null
+  python bench.py --workload cfg3 --accum $a --no-cpu-baseline --no-alt > gpurun_out/$R/bench_cfg3_n1_$a.json 2>/dev/null
 done
 for a in i8 fp64; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg2_$a -o bench -- python bench.py --accum $a --steps 20 --warmup 3 --no-cpu-baseline --no-alt > /dev/null 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg3_$a -o bench -- python bench.py --workload cfg3 --accum $a --steps 5 --warmup 1 --no-cpu-baseline --no-alt > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg2_$a -o bench -- python bench.py --accum $a --no-cpu-baseline --no-alt > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg3_$a -o bench -- python bench.py --workload cfg3 --accum $a --no-cpu-baseline --no-alt > /dev/null 2>&1
   for wl in cfg2 cfg3; do
     st=3; [ $wl = cfg3 ] && st=2
     for kind in fetch write sq; do
@@ -30,5 +30,5 @@ python scripts/summarise_pmc.py gpurun_out/$R _i8 > gpurun_out/$R/pmc_summary_i8
 python scripts/mfma_i8_peak.py > gpurun_out/$R/mfma_i8_microbench.txt 2>&1
 python scripts/mfma_peak.py > gpurun_out/$R/mfma_f64_microbench.txt 2>&1
 [ -x flashpca_amd/_build/mx_probe ] && timeout 300 flashpca_amd/_build/mx_probe > gpurun_out/$R/mx_fp4_fp6_probe.txt 2>&1
-python bench.py --workload cfg5 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/$R/bench_cfg5_n1.json 2>/dev/null
+python bench.py --workload cfg5 --no-cpu-baseline > gpurun_out/$R/bench_cfg5_n1.json 2>/dev/null
 cat gpurun_out/$R/pmc_summary_i8.json | head -60; cat gpurun_out/$R/bench_cfg2_n1.json
