@@ -155,6 +155,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # clock spin-up, untimed and on top of the W warm-up steps the caller asked for: the first ~50 ms of work after idle run
+    # at ramping clocks whatever W is (a 20-step region at cfg2 read 0.62 ms per step right after start-up, 0.53 after)
+    # (a fixed count, not a time limit: with several ranks every apply is a collective)
+    for _ in range({"cfg2": 150, "tiny": 300, "cfg3": 4, "cfg5": 1}[args.workload]):
+        ctx.apply_xxt_dev(B.data_ptr(), b, Y.data_ptr())
+    ctx.synchronize()
     for _ in range(args.warmup):
         ctx.apply_xxt_dev(B.data_ptr(), b, Y.data_ptr())
     ctx.synchronize()
