@@ -342,7 +342,13 @@ def main():
                                    host_cores=os.cpu_count())
 
     if rank == 0:
-        print(json.dumps(out))
+        # anything the C side buffered on stdout (RCCL prints a version banner there under NCCL_DEBUG=VERSION) goes out first:
+        # the JSON line is the last line of rank 0's stdout
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
