@@ -9,9 +9,12 @@ of the N x b product when N > 1.  That is b single-vector applications of the re
 (svdwide.cpp:21-68), so   value = N_samples * P_total * b * K / time   [genotype cells / s], the metric
 BASELINE.json names ("N x P x iters" with iters = single-vector operator applications).
 
-Workload (BASELINE.json configs[1]): synthetic 50,000 samples x 20,000 SNPs per GPU, k = 20; weak scaling:
-every rank holds its own 20,000-SNP shard of a (20,000 * N)-SNP matrix, generated directly in HBM.
-`--workload cfg3` selects the 500,000 x 100,000 paper-headline matrix (configs[2]/[3], SNP-sharded = strong).
+Workload (default, BASELINE.json configs[2]/[3] -- the configuration the metric is quoted on): synthetic 500,000 samples x
+100,000 SNPs, k = 20, generated directly in HBM; with N > 1 ranks the SNP columns are sharded N ways (strong scaling,
+rank r holds SNPs [P r / N, P (r+1) / N)) and the N x b product is all-reduced over RCCL.  `--workload cfg2` is the
+50,000 x 20,000 matrix of configs[1] (per GPU: weak scaling), `cfg5` the 1M x 200k / k = 50 matrix of configs[4];
+`cfg4shard` / `cfg5shard` are the one-GPU shards of configs[3] / configs[4] at 8 GPUs (12,500 / 25,000 SNPs of the same
+sample counts): the per-GPU compute of the 8-GPU runs, measurable on one GPU.
 
 Arithmetic: `--accum i8` (default; the product's default FPCA_ACCUM_AUTO resolves to it) runs the two GEMMs on the int8 matrix
 cores -- integer genotype matrices x byte slices of the fp64 operand, exact int32 accumulation, fp64 recombination
@@ -44,23 +47,32 @@ WORKLOADS = {
                  desc="synthetic 500000 samples x 100000 SNPs total, SNP-sharded across GPUs, k=20 (BASELINE configs[2]/[3])"),
     "cfg5": dict(N=1000000, P=200000, k=50, b=64, scaling="strong",
                  desc="synthetic 1000000 samples x 200000 SNPs total, SNP-sharded across GPUs, k=50 (BASELINE configs[4]; use --accum fp32)"),
+    "cfg4shard": dict(N=500000, P=12500, k=20, b=32, scaling="weak", shards=8,
+                      desc="one GPU's shard of BASELINE configs[3]: 500000 samples x 12500 of 100000 SNPs (1/8), k=20"),
+    "cfg5shard": dict(N=1000000, P=25000, k=50, b=64, scaling="weak", shards=8,
+                      desc="one GPU's shard of BASELINE configs[4]: 1000000 samples x 25000 of 200000 SNPs (1/8), k=50 (use --accum fp32)"),
     "tiny": dict(N=4000, P=3000, k=20, b=32, scaling="weak", desc="smoke-size workload"),
 }
+STEPS = {"cfg2": 400, "tiny": 400, "cfg3": 60, "cfg5": 12, "cfg4shard": 200, "cfg5shard": 40}
+WARMUP = {"cfg2": 20, "tiny": 20, "cfg3": 5, "cfg5": 2, "cfg4shard": 10, "cfg5shard": 4}
+# untimed clock spin-up applies before the caller's warm-up (reported in the JSON line as spinup_applies)
+SPINUP = {"cfg2": 150, "tiny": 300, "cfg3": 4, "cfg5": 1, "cfg4shard": 20, "cfg5shard": 4}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed block applies [400 / 60 / 12 for cfg2 / cfg3 / cfg5: a second or "
+    ap.add_argument("--steps", type=int, default=None, help="timed block applies [60 / 400 / 12 for cfg3 / cfg2 / cfg5: a second or "
                                                              "two of device time -- the first ~50 ms after idle run at ramping clocks]")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed block applies before them [20 / 5 / 2]")
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--warmup", type=int, default=None, help="untimed block applies before them [5 / 20 / 2]")
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--accum", default="i8", choices=["fp64", "fp32", "i8"] + ["i8x%d" % s for s in range(4, 9)],
                     help="i8[xS] (default: the product's default mode) = exact-integer int8 MFMA on S (default 7) byte slices of the "
                          "fp64 operand, results equal to the fp64 path; fp64 = v_mfma_f64; fp32 = v_mfma_f32 products, fp64 long "
                          "accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pca", action="store_true")
+    ap.add_argument("--no-pca-hard", action="store_true", help="skip the second full PCA on a slowly converging spectrum (4 sub-populations)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra exact-int8-mode measurement of the same workload")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the bounded baseline sample")
     args = ap.parse_args()
@@ -95,13 +107,14 @@ def main():
 
     w = WORKLOADS[args.workload]
     if args.steps is None:
-        args.steps = {"cfg2": 400, "tiny": 400, "cfg3": 60, "cfg5": 12}[args.workload]
+        args.steps = STEPS[args.workload]
     if args.warmup is None:
-        args.warmup = {"cfg2": 20, "tiny": 20, "cfg3": 5, "cfg5": 2}[args.workload]
-    steps_alt = min(args.steps, {"cfg2": 100, "tiny": 100, "cfg3": 20, "cfg5": 4}[args.workload])  # the other-mode comparison run
+        args.warmup = WARMUP[args.workload]
+    steps_alt = min(args.steps, max(4, STEPS[args.workload] // 4))  # the other-mode comparison run
     N, k, b = w["N"], w["k"], w["b"]
     if w["scaling"] == "weak":
-        P_rank, P_total, snp_begin = w["P"], w["P"] * world, rank * w["P"]
+        # (the shard workloads keep the divisor of the full matrix they are a shard of)
+        P_rank, P_total, snp_begin = w["P"], w["P"] * max(world, w.get("shards", 1)), rank * w["P"]
     else:
         lo, hi = w["P"] * rank // world, w["P"] * (rank + 1) // world
         P_rank, P_total, snp_begin = hi - lo, w["P"], lo
@@ -158,7 +171,7 @@ def main():
     # clock spin-up, untimed and on top of the W warm-up steps the caller asked for: the first ~50 ms of work after idle run
     # at ramping clocks whatever W is (a 20-step region at cfg2 read 0.62 ms per step right after start-up, 0.53 after)
     # (a fixed count, not a time limit: with several ranks every apply is a collective)
-    for _ in range({"cfg2": 150, "tiny": 300, "cfg3": 4, "cfg5": 1}[args.workload]):
+    for _ in range(SPINUP[args.workload]):
         ctx.apply_xxt_dev(B.data_ptr(), b, Y.data_ptr())
     ctx.synchronize()
     for _ in range(args.warmup):
@@ -186,7 +199,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    cells = float(N) * float(P_total) * b * args.steps
+    # SNPs all ranks processed per step (the shard workloads process one shard; their divisor is the full matrix's)
+    P_done = P_rank * world if w["scaling"] == "weak" else P_total
+    cells = float(N) * float(P_done) * b * args.steps
     value = cells / elapsed
 
     # roofline of the dominant kernel (both GEMMs carry 2 N P_g b flops per launch; the slower one dominates)
@@ -218,24 +233,31 @@ def main():
     roofline["hip_events_on_steps"] = "%d of %d (every %d%s step of the timed region)" % (prof["nsteps"], args.steps, stride, "th" if stride > 3 else "")
     if args.accum == "fp64":
         roofline["peak_measured_pure_mfma_stream"] = 74.3  # profiles/r01_mfma_f64_microbench.txt (2 waves/SIMD)
-    # HBM traffic per launch of the dominant kernel from the committed PMC passes of this workload (bench.py cannot
-    # collect hardware counters itself; scripts/gpu_profile_round.sh does, in separate --pmc runs, as the guide asks)
-    try:
-        if world == 1 and args.accum == "i8":
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_i8.json")))[args.workload]["gemm_i8_" + dom]
+    # HBM traffic per launch of the dominant kernel.  bench.py cannot read hardware counters inside its own timed run
+    # (rocprofv3 --pmc serialises the kernels and needs its own passes), so `traffic` is REPLAYED from the committed
+    # counter passes of this same workload and kernel (scripts/gpu_profile_round.sh: separate --pmc runs, FETCH_SIZE x 2
+    # (the gfx950 correction of the guide) + WRITE_SIZE); `traffic_source` names the file, null when there is none.
+    roofline["algorithmic_bytes"] = float((N + 3) // 4) * P_rank + 8.0 * b * (N + P_rank)
+    roofline["traffic_measured_in_this_run"] = False
+    for rnd in ("r02", "r01"):
+        try:
+            if world == 1 and args.accum == "i8":
+                fn = "profiles/%s_pmc_summary_i8.json" % rnd
+                pmc = json.load(open(os.path.join(ROOT, fn)))[args.workload]["gemm_i8_" + dom]
+            elif world == 1 and args.accum == "fp64":
+                fn = "profiles/%s_pmc_summary.json" % rnd
+                pmc = json.load(open(os.path.join(ROOT, fn)))[args.workload][dom]
+            else:
+                break
             roofline["traffic"] = pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r01_pmc_summary_i8.json (FETCH_SIZE x2 + WRITE_SIZE of the int8 GEMM, rocprofv3 --pmc)"
-            roofline["algorithmic_bytes"] = float((N + 3) // 4) * P_rank + 8.0 * b * (N + P_rank)
-        if world == 1 and args.accum == "fp64":
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))[args.workload][dom]
-            roofline["traffic"] = pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc)"
-            roofline["algorithmic_bytes"] = float((N + 3) // 4) * P_rank + 8.0 * b * (N + P_rank)
-    except Exception:
-        pass
+            roofline["traffic_source"] = "replayed from " + fn + " (rocprofv3 --pmc passes of this workload: FETCH_SIZE x2 + WRITE_SIZE per launch)"
+            break
+        except Exception:
+            continue
 
     out = dict(metric="genotype cells/sec (N x P x iters) for k=20 PCA", value=value, unit="cells/s", n_gpus=world,
-               steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
+               steps=args.steps, warmup=args.warmup, spinup_applies=SPINUP[args.workload],
+               ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
                scaling=w["scaling"], vs_baseline=None,
                dtype={"fp64": "f64", "fp32": "f32 (fp64 long accumulation)"}.get(
                    args.accum, "i8 (integer genotypes x 7 byte slices of the f64 operand; exact i32 accumulation, f64 recombination; "
@@ -257,10 +279,30 @@ def main():
         info = r["info"]
         out["pca"] = dict(wall_s=wall, converged=bool(info["converged"]), block_applies=info["block_applies"],
                           vector_ops=info["vector_ops"], restarts=info["restarts"],
-                          cells_per_s=float(N) * P_total * info["vector_ops"] / wall,
+                          cells_per_s=float(N) * P_done * info["vector_ops"] / wall,
                           seconds_apply=info["seconds_apply"], seconds_ortho=info["seconds_ortho"],
                           seconds_host=info["seconds_host"], eigenvalue_1=float(r["d"][0]), eigenvalue_k=float(r["d"][-1]),
                           max_rel_residual=info["max_residual"])
+
+    # ---- the same solve on a slowly converging spectrum: 4 sub-populations, so that 17 of the 20 wanted eigenvalues sit in
+    # the bulk (231 single-vector ops instead of 42 in the probe) -- the cost of a PCA whose k reaches past the
+    # structure in the data; reported beside the easy one, not part of `value` ----------------------------------------------
+    if world == 1 and not args.no_pca and not args.no_pca_hard:
+        with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=4, device=local_rank, accum=args.accum) as ch:
+            ch.set_total_snps(P_total)
+            ch.stats()
+            ch.pca(ndim=k, allow_unconverged=True, maxiter=3)  # one-off set-up of the arithmetic mode, untimed like above
+            ch.synchronize()
+            t1 = time.perf_counter()
+            rh = ch.pca(ndim=k, allow_unconverged=True)
+            ch.synchronize()
+            wall_h = time.perf_counter() - t1
+            ih = rh["info"]
+            out["pca_hard_spectrum"] = dict(n_pop=4, wall_s=wall_h, converged=bool(ih["converged"]), block_applies=ih["block_applies"],
+                                            vector_ops=ih["vector_ops"], restarts=ih["restarts"], seconds_apply=ih["seconds_apply"],
+                                            seconds_ortho=ih["seconds_ortho"], seconds_host=ih["seconds_host"],
+                                            eigenvalue_1=float(rh["d"][0]), eigenvalue_k=float(rh["d"][-1]),
+                                            max_rel_residual=ih["max_residual"])
 
     # ---- the same workload through the other exact path (fp64 MFMA kernels <-> int8 slices): timing and agreement ------
     if world == 1 and args.accum in ("fp64", "i8") and not args.no_alt:
@@ -301,45 +343,83 @@ def main():
 
     # ---- CPU baseline: the oracle (restated reference path) on a bounded sample, rank 0, N=1 only -----------
     if world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+
         from oracle import oracle as O
 
         O.build()
+        ncore = os.cpu_count() or 1
         P_s = min(P_rank, 1000)
         with fp.Context.synthetic(N, P_s, snp_begin=0, n_pop=min(2 * k, 64), device=local_rank) as sh:
             packed = sh.download_packed()
         od = O.OracleData(packed=packed, N=N, P=P_s, stand="binom2")
-        bs = O.lib().orc_default_block_size(N, P_total, k, 0, 2048) or 1  # flashpca.cpp:636-686 on the FULL problem
+        bs = O.lib().orc_default_block_size(N, P_done, k, 0, 2048) or 1  # flashpca.cpp:636-686 on the FULL problem
         op = O.OracleOp(od, min(bs, P_s), nthreads=1)
-        import numpy as np
-
         x = np.random.default_rng(0).standard_normal(N)
         op.perform_op(x)  # first visit computes mean/sd (not timed, like the GPU side's stats pass)
         nops, tc = 0, time.perf_counter()
         while True:
             op.perform_op(x)
             nops += 1
-            if time.perf_counter() - tc > args.cpu_seconds or nops >= 5000:
+            if time.perf_counter() - tc > args.cpu_seconds * 0.5 or nops >= 5000:
                 break
         tc = time.perf_counter() - tc
-        # generous variant (NOT what the shipped reference does): the same loops with OpenMP over all
-        # host cores, ~1/3 of the time budget
-        ncore = os.cpu_count() or 1
-        opa = O.OracleOp(od, min(bs, P_s), nthreads=ncore)
+        out["cpu_baseline"] = dict(value=float(N) * P_s * nops / tc, unit="cells/s", cores=1, kind="port",
+                                   sample="%d single-vector operator applications (decode->LUT->dense fp64 block->2 GEMV, "
+                                          "svdwide.cpp:21-68) on the first %d SNPs x %d samples of the same synthetic matrix, "
+                                          "block size %d, 1 thread (the shipped reference is single-threaded), %.1f s"
+                                          % (nops, P_s, N, min(bs, P_s), tc),
+                                   host_cores=ncore)
+        # generous variant (NOT what the shipped reference does): SNP sub-blocks dealt to all host
+        # cores, every thread with its own dense block and partial y (oracle/fpca_oracle.c op_mt); a sample big enough to
+        # give every core work
+        P_a = min(P_rank, max(1000, 16 * ncore))
+        with fp.Context.synthetic(N, P_a, snp_begin=0, n_pop=min(2 * k, 64), device=local_rank) as sh:
+            packed_a = sh.download_packed()
+        oda = O.OracleData(packed=packed_a, N=N, P=P_a, stand="binom2")
+        opa = O.OracleOp(oda, min(bs, P_a), nthreads=ncore)
         opa.perform_op(x)
         na, ta = 0, time.perf_counter()
         while True:
             opa.perform_op(x)
             na += 1
-            if time.perf_counter() - ta > args.cpu_seconds / 3 or na >= 5000:
+            if time.perf_counter() - ta > args.cpu_seconds * 0.25 or na >= 5000:
                 break
         ta = time.perf_counter() - ta
-        out["cpu_baseline_allcores"] = dict(value=float(N) * P_s * na / ta, unit="cells/s", cores=ncore, kind="port",
-                                            sample="%d operator applications, OpenMP over %d threads, %.1f s" % (na, ncore, ta))
-        out["cpu_baseline"] = dict(value=float(N) * P_s * nops / tc, unit="cells/s", cores=1, kind="port",
-                                   sample="%d single-vector operator applications (decode->LUT->dense fp64 block->2 GEMV, "
-                                          "svdwide.cpp:21-68) on the first %d SNPs x %d samples of the same synthetic matrix, "
-                                          "block size %d, 1 thread, %.1f s" % (nops, P_s, N, min(bs, P_s), tc),
-                                   host_cores=os.cpu_count())
+        out["cpu_baseline_allcores"] = dict(value=float(N) * P_a * na / ta, unit="cells/s", cores=ncore, kind="port",
+                                            sample="%d operator applications on %d SNPs x %d samples, SNP sub-blocks over %d OpenMP "
+                                                   "threads (per-thread dense block + partial y), %.1f s" % (na, P_a, N, ncore, ta))
+        # time to solution of the restated reference solver (Spectra-style IRLM, ncv = 2k+1, tol 1e-6, one operator
+        # application per Lanczos column) on the WHOLE 50,000 x 20,000 matrix of BASELINE configs[1]: run for real on all
+        # host cores (a 1-thread run takes ~ops x 0.45 s and would not fit the bench's time budget), next to this GPU's solve
+        # of the same matrix
+        if args.cpu_seconds >= 5:
+            N2, P2 = WORKLOADS["cfg2"]["N"], WORKLOADS["cfg2"]["P"]
+            with fp.Context.synthetic(N2, P2, snp_begin=0, n_pop=min(2 * k, 64), device=local_rank) as c2g:
+                packed2 = c2g.download_packed()
+                c2g.pca(ndim=k, allow_unconverged=True, maxiter=2)  # untimed set-up
+                t1 = time.perf_counter()
+                rg = c2g.pca(ndim=k)
+                c2g.synchronize()
+                gpu_wall = time.perf_counter() - t1
+            od2 = O.OracleData(packed=packed2, N=N2, P=P2, stand="binom2")
+            t1 = time.perf_counter()
+            rc = O.pca_fast(od2, k, tol=1e-6, nthreads=ncore)
+            cpu_wall = time.perf_counter() - t1
+            op1 = O.OracleOp(O.OracleData(packed=packed2[:1000 * ((N2 + 3) // 4)], N=N2, P=1000, stand="binom2"), 1000, nthreads=1)
+            x2 = np.random.default_rng(0).standard_normal(N2)
+            op1.perform_op(x2)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                op1.perform_op(x2)
+            s_per_op_1t = (time.perf_counter() - t1) / 3 * (P2 / 1000.0)
+            out["cpu_baseline"]["full_solve_cfg2"] = dict(
+                what="orc_pca_fast (restated Spectra IRLM, ncv=2k+1, tol=1e-6) on the full 50000 x 20000 synthetic matrix, k=%d" % k,
+                total_ops=int(rc["nops"]), total_wall_s=cpu_wall, cores=ncore,
+                cells_per_s=float(N2) * P2 * rc["nops"] / cpu_wall,
+                one_thread_s_per_op=s_per_op_1t, one_thread_total_wall_s_extrapolated=s_per_op_1t * rc["nops"],
+                gpu_wall_s_same_matrix=gpu_wall, gpu_block_applies=rg["info"]["block_applies"],
+                max_rel_eigenvalue_diff_gpu_vs_cpu=float(np.max(np.abs(rg["d"] - rc["d"]) / np.abs(rc["d"]))))
 
     if rank == 0:
         # anything the C side buffered on stdout (RCCL prints a version banner there under NCCL_DEBUG=VERSION) goes out first:

@@ -29,6 +29,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -162,28 +163,36 @@ void orc_set_preloaded_meansd(orc_data *d, const double *meansd)
  * mean over non-missing dosages, P = mean/2, sd by the standardisation method, store mean/sd, and
  * (if sd > VAR_TOL) the 4-entry table indexed by RAW code: [3]->(0-mean)/sd, [2]->(1-mean)/sd,
  * [0]->(2-mean)/sd, [1]->0; otherwise the table stays zero.  Every visit: X(i, j) = table[code_i]. */
+static int read_snp_block_scratch(orc_data *d, uint32_t start, uint32_t stop, double *X, unsigned char *tmp, unsigned char *tmp2);
+
 int orc_read_snp_block(orc_data *d, uint32_t start, uint32_t stop, double *X)
 {
+   return read_snp_block_scratch(d, start, stop, X, d->tmp, d->tmp2);
+}
+
+/* the body of read_snp_block with the two scratch rows (data.cpp:190-193) passed in, and positioned reads instead of
+ * seek + read, so that several threads can fill blocks of DISJOINT SNP ranges at once (nthreads > 1 only; disjoint SNPs
+ * touch disjoint entries of visited / meansd / lut) */
+static int read_snp_block_scratch(orc_data *d, uint32_t start, uint32_t stop, double *X, unsigned char *tmp, unsigned char *tmp2)
+{
    const uint64_t N = d->N, np = d->np, P = d->nsnps;
-   if (d->fp) {
-      if (fseeko(d->fp, (off_t)(3 + np * (uint64_t)start), SEEK_SET) != 0) return -1; /* data.cpp:218 */
-   }
    uint32_t bs = stop - start + 1;
    for (uint32_t j = 0; j < bs; j++) {
       uint64_t k = (uint64_t)start + j;
       if (d->fp) {
-         if (fread(d->tmp, 1, np, d->fp) != np) return -2; /* data.cpp:250 */
+         /* data.cpp:218 (seek to 3 + np*start) + :250 (read np bytes per SNP) */
+         if (pread(fileno(d->fp), tmp, np, (off_t)(3 + np * k)) != (ssize_t)np) return -2;
       } else {
-         memcpy(d->tmp, d->mem + np * k, np);
+         memcpy(tmp, d->mem + np * k, np);
       }
       if (!d->visited[k]) { /* data.cpp:257-322 */
          double snp_avg = 0, sd = 0;
          if (!d->use_preloaded_maf) {
-            orc_decode_plink(d->tmp2, d->tmp, (unsigned int)np);
+            orc_decode_plink(tmp2, tmp, (unsigned int)np);
             uint64_t ngood = 0;
             for (uint64_t i = 0; i < N; i++) {
-               if (d->tmp2[i] != PLINK_NA) {
-                  snp_avg += (double)d->tmp2[i];
+               if (tmp2[i] != PLINK_NA) {
+                  snp_avg += (double)tmp2[i];
                   ngood++;
                }
             }
@@ -210,10 +219,10 @@ int orc_read_snp_block(orc_data *d, uint32_t start, uint32_t stop, double *X)
          }
          d->visited[k] = 1;
       }
-      orc_decode_plink_simple(d->tmp2, d->tmp, (unsigned int)np); /* data.cpp:328 */
+      orc_decode_plink_simple(tmp2, tmp, (unsigned int)np); /* data.cpp:328 */
       const double *lut = d->lut + 4 * k;
       double *col = X + (uint64_t)j * N;
-      for (uint64_t i = 0; i < N; i++) col[i] = lut[d->tmp2[i]]; /* data.cpp:330-333 */
+      for (uint64_t i = 0; i < N; i++) col[i] = lut[tmp2[i]]; /* data.cpp:330-333 */
    }
    return 0;
 }
@@ -232,7 +241,11 @@ struct orc_op {
    double *X; /* dat.X, N x block_size */
    double *t; /* block_size scratch */
    int nthreads;
+   void *mt;       /* nthreads > 1: per-thread blocks (orc_mt[nthreads]) */
+   uint32_t mt_bs; /* SNPs per per-thread sub-block */
 };
+
+static void mt_free(orc_op *op);
 
 /* svdwide.h:51-73 */
 orc_op *orc_op_new(orc_data *d, uint32_t block_size, int nthreads)
@@ -255,15 +268,16 @@ orc_op *orc_op_new(orc_data *d, uint32_t block_size, int nthreads)
    op->nops = 1;
    op->trace = 0;
    op->trace_done = 0;
-   op->X = (double *)malloc(sizeof(double) * op->n * block_size);
-   op->t = (double *)malloc(sizeof(double) * block_size * 64);
    op->nthreads = nthreads < 1 ? 1 : nthreads;
+   op->X = op->nthreads > 1 ? NULL : (double *)malloc(sizeof(double) * op->n * block_size); /* threads own their blocks */
+   op->t = (double *)malloc(sizeof(double) * block_size * 64);
    return op;
 }
 
 void orc_op_free(orc_op *op)
 {
    if (!op) return;
+   mt_free(op);
    free(op->start);
    free(op->stop);
    free(op->X);
@@ -276,12 +290,8 @@ uint32_t orc_op_nops(const orc_op *op) { return op->nops; }
 uint32_t orc_op_nblocks(const orc_op *op) { return op->nblocks; }
 
 /* t = Xb' x  (Eigen GEMV, svdwide.cpp:42-43 inner product) */
-static void gemv_t(const double *X, uint64_t n, uint32_t bs, const double *x, double *t, int nthreads)
+static void gemv_t(const double *X, uint64_t n, uint32_t bs, const double *x, double *t)
 {
-   (void)nthreads;
-#ifdef _OPENMP
-#pragma omp parallel for num_threads(nthreads) schedule(static) if (nthreads > 1)
-#endif
    for (uint32_t j = 0; j < bs; j++) {
       const double *col = X + (uint64_t)j * n;
       double s = 0;
@@ -290,19 +300,13 @@ static void gemv_t(const double *X, uint64_t n, uint32_t bs, const double *x, do
    }
 }
 
-/* y (+)= Xb t (Eigen GEMV, svdwide.cpp:42-43 / 58-59 outer product) */
-static void gemv_n_acc(const double *X, uint64_t n, uint32_t bs, const double *t, double *y, int overwrite, int nthreads)
+/* y (+)= Xb t (Eigen GEMV, svdwide.cpp:42-43 / 58-59 outer product); rows in chunks that stay in L1 while the bs columns
+ * stream past, as a blocked GEMV does */
+static void gemv_n_acc(const double *X, uint64_t n, uint32_t bs, const double *t, double *y, int overwrite)
 {
-   (void)nthreads;
-#ifdef _OPENMP
-#pragma omp parallel num_threads(nthreads) if (nthreads > 1)
-   {
-      int nt = omp_get_num_threads(), id = omp_get_thread_num();
-      uint64_t lo = n * (uint64_t)id / nt, hi = n * (uint64_t)(id + 1) / nt;
-#else
-   {
-      uint64_t lo = 0, hi = n;
-#endif
+   const uint64_t RC = 2048;
+   for (uint64_t lo = 0; lo < n; lo += RC) {
+      const uint64_t hi = lo + RC < n ? lo + RC : n;
       if (overwrite)
          for (uint64_t i = lo; i < hi; i++) y[i] = 0;
       for (uint32_t j = 0; j < bs; j++) {
@@ -320,20 +324,130 @@ static double sumsq(const double *X, uint64_t cnt)
    return s;
 }
 
+/* ---- nthreads > 1 (NOT what the shipped reference does; the generous all-cores number of bench.py and the full-size
+ * oracle legs of the GPU tests): the SNP blocks of the block table are cut into sub-blocks of mt_bs SNPs, dealt to the
+ * threads; every thread owns a dense N x mt_bs block, the two scratch rows and a partial y; partial y's are summed over
+ * threads by row ranges at the end.  Same arithmetic per SNP as the serial path, different summation order over SNPs. */
+typedef struct {
+   double *X, *t, *y;
+   unsigned char *tmp, *tmp2;
+} orc_mt;
+
+static void mt_free(orc_op *op)
+{
+   orc_mt *m = (orc_mt *)op->mt;
+   if (!m) return;
+   for (int i = 0; i < op->nthreads; i++) {
+      free(m[i].X);
+      free(m[i].t);
+      free(m[i].y);
+      free(m[i].tmp);
+      free(m[i].tmp2);
+   }
+   free(m);
+   op->mt = NULL;
+}
+
+static orc_mt *mt_get(orc_op *op)
+{
+   if (op->mt) return (orc_mt *)op->mt;
+   /* per-thread dense block <= 4 MB where one SNP column allows it (it is written once and read twice per visit) */
+   uint64_t bs = (4u << 20) / (8 * (op->n ? op->n : 1));
+   if (bs < 1) bs = 1;
+   if (bs > op->block_size) bs = op->block_size;
+   uint64_t per = (op->p + (uint64_t)op->nthreads - 1) / (uint64_t)op->nthreads; /* at least one sub-block per thread */
+   if (per >= 1 && bs > per) bs = per;
+   op->mt_bs = (uint32_t)bs;
+   op->mt = calloc((size_t)op->nthreads, sizeof(orc_mt));
+   return (orc_mt *)op->mt;
+}
+
+static void mt_thread_alloc(orc_op *op, orc_mt *m)
+{
+   if (m->X) return;
+   m->X = (double *)malloc(sizeof(double) * op->n * op->mt_bs);
+   m->t = (double *)malloc(sizeof(double) * op->mt_bs);
+   m->y = (double *)malloc(sizeof(double) * op->n);
+   m->tmp = (unsigned char *)malloc(op->dat->np ? op->dat->np : 1);
+   m->tmp2 = (unsigned char *)malloc(op->dat->np ? op->dat->np * PACK_DENSITY : 1);
+}
+
+/* what: 0 = y = X X' x (perform_op), 1 = out[P] = X' x (crossprod), 2 = y = X v (prod) */
+static void op_mt(orc_op *op, int what, const double *in, double *out)
+{
+   orc_mt *mt = mt_get(op);
+   const uint64_t n = op->n, p = op->p;
+   const uint32_t bs = op->mt_bs;
+   const int64_t nsub = (int64_t)((p + bs - 1) / bs);
+   const int want_trace = (what == 0 && !op->trace_done);
+   double trace = 0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(op->nthreads) reduction(+ : trace)
+#endif
+   {
+#ifdef _OPENMP
+      const int id = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+      const int id = 0, nt = 1;
+#endif
+      orc_mt *m = &mt[id];
+      mt_thread_alloc(op, m);
+      if (what != 1)
+         for (uint64_t i = 0; i < n; i++) m->y[i] = 0;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+      for (int64_t sb = 0; sb < nsub; sb++) {
+         const uint32_t s0 = (uint32_t)(sb * bs);
+         const uint32_t s1 = (uint32_t)((uint64_t)s0 + bs - 1 >= p ? p - 1 : s0 + bs - 1);
+         const uint32_t w = s1 - s0 + 1;
+         read_snp_block_scratch(op->dat, s0, s1, m->X, m->tmp, m->tmp2);
+         if (what == 0) {
+            gemv_t(m->X, n, w, in, m->t);
+            gemv_n_acc(m->X, n, w, m->t, m->y, 0);
+            if (want_trace) trace += sumsq(m->X, n * w);
+         } else if (what == 1) {
+            gemv_t(m->X, n, w, in, out + s0);
+         } else {
+            gemv_n_acc(m->X, n, w, in + s0, m->y, 0);
+         }
+      }
+      /* implicit barrier above; every thread sums its row range over the threads' partials */
+      if (what != 1) {
+         const uint64_t lo = n * (uint64_t)id / (uint64_t)nt, hi = n * (uint64_t)(id + 1) / (uint64_t)nt;
+         for (uint64_t i = lo; i < hi; i++) out[i] = 0;
+         for (int q = 0; q < nt; q++) {
+            const double *yq = mt[q].y;
+            if (!yq) continue;
+            for (uint64_t i = lo; i < hi; i++) out[i] += yq[i];
+         }
+      }
+   }
+   if (want_trace) {
+      op->trace = trace;
+      op->trace_done = 1;
+   }
+   op->nops++;
+}
+
 /* svdwide.cpp:21-68: y = sum_b X_b (X_b' x); trace accumulated on the first call only; block 0 is
  * re-read only when nblocks > 1 or on the very first op. */
 void orc_perform_op(orc_op *op, const double *x_in, double *y_out)
 {
+   if (op->nthreads > 1) {
+      op_mt(op, 0, x_in, y_out);
+      return;
+   }
    uint32_t bs = op->stop[0] - op->start[0] + 1;
    if (op->nblocks > 1 || op->nops == 1) orc_read_snp_block(op->dat, op->start[0], op->stop[0], op->X);
-   gemv_t(op->X, op->n, bs, x_in, op->t, op->nthreads);
-   gemv_n_acc(op->X, op->n, bs, op->t, y_out, 1, op->nthreads);
+   gemv_t(op->X, op->n, bs, x_in, op->t);
+   gemv_n_acc(op->X, op->n, bs, op->t, y_out, 1);
    if (!op->trace_done) op->trace = sumsq(op->X, op->n * bs);
    for (uint32_t k = 1; k < op->nblocks; k++) {
       bs = op->stop[k] - op->start[k] + 1;
       orc_read_snp_block(op->dat, op->start[k], op->stop[k], op->X);
-      gemv_t(op->X, op->n, bs, x_in, op->t, op->nthreads);
-      gemv_n_acc(op->X, op->n, bs, op->t, y_out, 0, op->nthreads);
+      gemv_t(op->X, op->n, bs, x_in, op->t);
+      gemv_n_acc(op->X, op->n, bs, op->t, y_out, 0);
       if (!op->trace_done) op->trace += sumsq(op->X, op->n * bs);
    }
    if (!op->trace_done) op->trace_done = 1;
@@ -343,13 +457,19 @@ void orc_perform_op(orc_op *op, const double *x_in, double *y_out)
 /* svdwide.cpp:71-118: same with a matrix right-hand side (ncols columns, column-major) */
 void orc_perform_op_mat(orc_op *op, const double *Xin, int ncols, double *Y)
 {
+   if (op->nthreads > 1) { /* column by column through the threaded operator (one nops tick, like the serial form) */
+      const uint32_t nops0 = op->nops;
+      for (int c = 0; c < ncols; c++) op_mt(op, 0, Xin + (uint64_t)c * op->n, Y + (uint64_t)c * op->n);
+      op->nops = nops0 + 1;
+      return;
+   }
    double *t = (double *)malloc(sizeof(double) * op->block_size);
    for (uint32_t k = 0; k < op->nblocks; k++) {
       uint32_t bs = op->stop[k] - op->start[k] + 1;
       if (k > 0 || op->nblocks > 1 || op->nops == 1) orc_read_snp_block(op->dat, op->start[k], op->stop[k], op->X);
       for (int c = 0; c < ncols; c++) {
-         gemv_t(op->X, op->n, bs, Xin + (uint64_t)c * op->n, t, op->nthreads);
-         gemv_n_acc(op->X, op->n, bs, t, Y + (uint64_t)c * op->n, k == 0, op->nthreads);
+         gemv_t(op->X, op->n, bs, Xin + (uint64_t)c * op->n, t);
+         gemv_n_acc(op->X, op->n, bs, t, Y + (uint64_t)c * op->n, k == 0);
       }
       if (!op->trace_done) op->trace = (k == 0 ? 0 : op->trace) + sumsq(op->X, op->n * bs);
    }
@@ -361,10 +481,14 @@ void orc_perform_op_mat(orc_op *op, const double *Xin, int ncols, double *Y)
 /* svdwide.cpp:122-153: y[P] = X' x, block by block */
 void orc_crossprod(orc_op *op, const double *x_in, double *y_out)
 {
+   if (op->nthreads > 1) {
+      op_mt(op, 1, x_in, y_out);
+      return;
+   }
    for (uint32_t k = 0; k < op->nblocks; k++) {
       uint32_t bs = op->stop[k] - op->start[k] + 1;
       orc_read_snp_block(op->dat, op->start[k], op->stop[k], op->X);
-      gemv_t(op->X, op->n, bs, x_in, y_out + op->start[k], op->nthreads);
+      gemv_t(op->X, op->n, bs, x_in, y_out + op->start[k]);
    }
    op->nops++;
 }
@@ -372,10 +496,14 @@ void orc_crossprod(orc_op *op, const double *x_in, double *y_out)
 /* svdwide.cpp:193-226: y[N] = X v */
 void orc_prod(orc_op *op, const double *v_in, double *y_out)
 {
+   if (op->nthreads > 1) {
+      op_mt(op, 2, v_in, y_out);
+      return;
+   }
    for (uint32_t k = 0; k < op->nblocks; k++) {
       uint32_t bs = op->stop[k] - op->start[k] + 1;
       orc_read_snp_block(op->dat, op->start[k], op->stop[k], op->X);
-      gemv_n_acc(op->X, op->n, bs, v_in + op->start[k], y_out, k == 0, op->nthreads);
+      gemv_n_acc(op->X, op->n, bs, v_in + op->start[k], y_out, k == 0);
    }
    op->nops++;
 }
