@@ -21,7 +21,9 @@
 #include <vector>
 
 #include <atomic>
+#include <csignal>
 #include <sched.h>
+#include <sys/prctl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -214,13 +216,79 @@ struct Multi {
    double *V = nullptr, *meansd = nullptr; // P x k and P x 2, column-major, in the shared region
    double *slots = nullptr;                // FPCA_CLI_TEST_TRANSPORT=shm only: G x slot_cap doubles
    size_t slot_cap = 0;
-   std::vector<pid_t> children;
    bool test_transport = false;
 };
 
 // set in the children of a --gpus run: an exception there must not fall through to rank 0's output code
 static int g_child_rank = 0;
 static MultiShared *g_shared = nullptr;
+
+// rank 0's view of its children.  A child that dies on its own (segfault, OOM kill, an uncaught exit) can never reach the
+// next rendezvous, and rank 0 may itself be blocked inside an RCCL collective waiting for it -- so the parent watches
+// SIGCHLD: an abnormal child exit that nobody announced in the shared region ends the whole run at once.
+static pid_t g_children[64];
+static int g_nchildren = 0;
+static volatile sig_atomic_t g_child_done[64];
+static volatile sig_atomic_t g_quiesce = 0; // set while rank 0 itself winds the children down
+
+static void kill_children()
+{
+   for (int i = 0; i < g_nchildren; i++)
+      if (!g_child_done[i]) (void)kill(g_children[i], SIGKILL);
+}
+
+static void on_sigchld(int)
+{
+   const int saved = errno;
+   for (int i = 0; i < g_nchildren; i++) {
+      if (g_child_done[i]) continue;
+      int st = 0;
+      if (waitpid(g_children[i], &st, WNOHANG) != g_children[i]) continue;
+      g_child_done[i] = 1;
+      const bool bad = WIFSIGNALED(st) || (WIFEXITED(st) && WEXITSTATUS(st) != 0);
+      if (bad && !g_quiesce && g_shared && g_shared->failed.load() == 0) {
+         g_shared->failed.fetch_add(1);
+         static const char msg[] = "Exception: a GPU rank of the --gpus run died unexpectedly\nTerminating\n";
+         (void)!write(2, msg, sizeof(msg) - 1);
+         kill_children();
+         _exit(EXIT_FAILURE);
+      }
+   }
+   errno = saved;
+}
+
+// rank 0: wait for every child that has not been reaped yet (the handler may reap them first: ECHILD is fine)
+static void wait_children()
+{
+   for (int i = 0; i < g_nchildren; i++) {
+      if (g_child_done[i]) continue;
+      (void)waitpid(g_children[i], nullptr, 0);
+      g_child_done[i] = 1;
+   }
+}
+
+// rank 0 cannot go on (exception, early return after the fork): tell the children through the shared region, give them two
+// seconds to leave at their next rendezvous, then kill what is left (a child inside an RCCL collective never gets there)
+static void abandon_children()
+{
+   if (g_child_rank > 0 || g_nchildren == 0) return;
+   g_quiesce = 1;
+   if (g_shared) g_shared->failed.fetch_add(1);
+   for (int t = 0; t < 200; t++) {
+      bool all = true;
+      for (int i = 0; i < g_nchildren; i++) {
+         if (g_child_done[i]) continue;
+         if (waitpid(g_children[i], nullptr, WNOHANG) != 0) // reaped here, or already by the handler (ECHILD)
+            g_child_done[i] = 1;
+         else
+            all = false;
+      }
+      if (all) return;
+      usleep(10000);
+   }
+   kill_children();
+   wait_children();
+}
 
 void multi_fail(Multi &m, const std::string &why)
 {
@@ -493,6 +561,24 @@ int main(int argc, char *argv[])
       Multi mg;
       mg.ngpus = ngpus;
       uint64_t snp_begin = 0, snp_count = 0; // this rank's shard (0, 0 = the whole file)
+      // everything that can be refused from the file sizes alone is refused here: before any device work, and -- in a
+      // --gpus run -- before the fork, so that no rank is left waiting for another
+      {
+         struct stat st;
+         if (stat(geno_file.c_str(), &st) != 0) throw std::runtime_error("[Data::read_bed] Error reading file " + geno_file + ", error " + strerror(errno));
+         const uint64_t np = (N + 3) / 4;
+         const uint64_t P_file = (uint64_t)st.st_size > 3 ? ((uint64_t)st.st_size - 3) / np : 0; // data.cpp:165-170
+         // flashpca.cpp:623-633
+         const unsigned max_dim = (unsigned)((std::fmin((double)N, (double)P_file) - 1) / 2.0);
+         if ((unsigned)n_dim > max_dim) { // (every mode, like the reference)
+            std::cerr << "Error: You asked for " << n_dim << " dimensions, but only " << max_dim << "allowed" << std::endl;
+            return EXIT_FAILURE;
+         }
+         // the loadings / mean-sd files carry one .bim row name per SNP of the .bed
+         if ((do_loadings || save_meansd) && snp_ids.size() != P_file)
+            throw std::runtime_error("the .bim file has a different number of SNPs (" + std::to_string(snp_ids.size()) + ") than the .bed (" +
+                                     std::to_string(P_file) + ")");
+      }
       if (ngpus > 1) {
          struct stat st;
          if (stat(geno_file.c_str(), &st) != 0) throw std::runtime_error("[Data::read_bed] Error reading file " + geno_file + ": " + strerror(errno));
@@ -521,6 +607,15 @@ int main(int argc, char *argv[])
          mg.slots = mg.meansd + (size_t)P_file * 2;
          std::cout.flush();
          std::fflush(nullptr);
+         g_shared = mg.sh;
+         {
+            struct sigaction sa;
+            std::memset(&sa, 0, sizeof(sa));
+            sa.sa_handler = on_sigchld;
+            sa.sa_flags = SA_RESTART | SA_NOCLDSTOP;
+            sigaction(SIGCHLD, &sa, nullptr);
+         }
+         const pid_t parent = getpid();
          for (int r = 1; r < ngpus; r++) { // nothing has touched HIP yet: the children initialise their own runtime
             const pid_t pid = fork();
             if (pid < 0) {
@@ -528,15 +623,19 @@ int main(int argc, char *argv[])
                break;
             }
             if (pid == 0) {
+               // a child never outlives rank 0 (it may sit in an RCCL collective that will never complete)
+               (void)prctl(PR_SET_PDEATHSIG, SIGKILL);
+               if (getppid() != parent) _exit(1);
+               signal(SIGCHLD, SIG_DFL);
                mg.rank = r;
-               mg.children.clear();
+               g_nchildren = 0;
                g_child_rank = r;
-               g_shared = mg.sh;
                quiet = true;
                std::cout.setstate(std::ios::failbit); // progress lines come from rank 0 only
                break;
             }
-            mg.children.push_back(pid);
+            g_child_done[g_nchildren] = 0;
+            g_children[g_nchildren++] = pid;
          }
          snp_begin = P_file * (uint64_t)mg.rank / (uint64_t)ngpus;
          snp_count = P_file * (uint64_t)(mg.rank + 1) / (uint64_t)ngpus - snp_begin;
@@ -547,7 +646,8 @@ int main(int argc, char *argv[])
             if (ctx) fpca_destroy(ctx);
             _exit(1);
          }
-         for (pid_t pid : mg.children) (void)waitpid(pid, nullptr, 0);
+         g_quiesce = 1;
+         wait_children();
          std::cerr << timestamp() << "Exception: " << mg.sh->msg << std::endl << timestamp() << "Terminating" << std::endl;
          if (ctx) fpca_destroy(ctx);
          return EXIT_FAILURE;
@@ -585,13 +685,6 @@ int main(int argc, char *argv[])
                       << (mg.test_transport ? "host shared memory (test)" : "RCCL") << std::endl;
       }
 
-      // flashpca.cpp:623-633
-      const unsigned max_dim = (unsigned)((std::fmin((double)N, (double)nsnps) - 1) / 2.0);
-      if ((unsigned)n_dim > max_dim) {
-         std::cerr << "Error: You asked for " << n_dim << " dimensions, but only " << max_dim << "allowed" << std::endl;
-         fpca_destroy(ctx);
-         return EXIT_FAILURE;
-      }
       // the reference prints its dense block geometry here (flashpca.cpp:688-690); the whole packed matrix is one resident block
       std::cout << timestamp() << "blocksize: " << nsnps << " (" << (long long)((N + 3) / 4) * (long long)nsnps << " bytes per block)" << std::endl;
 
@@ -641,11 +734,10 @@ int main(int argc, char *argv[])
             const bool all_ok = multi_barrier(mg);
             if (mg.rank > 0) {
                fpca_destroy(ctx);
-               _exit(all_ok && rc == FPCA_OK ? 0 : 1);
+               _exit(all_ok ? 0 : 1); // (rank 0 reports "not converged": every rank got the same rc)
             }
-            for (pid_t pid : mg.children) (void)waitpid(pid, nullptr, 0);
-            mg.children.clear();
             if (!all_ok) return multi_abort();
+            wait_children();
             if (do_loadings) V.assign(mg.V, mg.V + (size_t)nsnps * n_dim);
             meansd.assign(mg.meansd, mg.meansd + (size_t)nsnps * 2);
          }
@@ -670,10 +762,11 @@ int main(int argc, char *argv[])
          std::vector<double> err(K);
          double mse = 0, rmse = 0;
          fpca_ok(fpca_check(ctx, evec.v.data(), (int64_t)N, ev.v.data(), K, divisor, err.data(), &mse, &rmse));
-         std::cout << timestamp() << "Checking mean square error between (X X' U) / div and (U D^2) for " << K << " dimensions" << std::endl;
+         // printed under --verbose only, like the reference (randompca.cpp:670-700)
+         verbose && std::cout << timestamp() << "Checking mean square error between (X X' U) / div and (U D^2) for " << K << " dimensions" << std::endl;
          for (int j = 0; j < K; j++)
-            std::cout << timestamp() << "eval(" << (j + 1) << "): " << ev.v[j] << ", sum squared error: " << err[j] << std::endl;
-         std::cout << timestamp() << "Mean squared error: " << mse << ", Root mean squared error: " << rmse << " (n=" << N << ")" << std::endl;
+            verbose && std::cout << timestamp() << "eval(" << (j + 1) << "): " << ev.v[j] << ", sum squared error: " << err[j] << std::endl;
+         verbose && std::cout << timestamp() << "Mean squared error: " << mse << ", Root mean squared error: " << rmse << " (n=" << N << ")" << std::endl;
       } else { // MODE_PROJECT: RandomPCA::project (randompca.cpp:745-820)
          fpca::TextMatrix L = fpca::read_text(in_load_file, 3, -1, 1);
          if (L.rows != nsnps) throw std::runtime_error("number of SNPs in the loadings file doesn't match the data");
@@ -766,6 +859,7 @@ int main(int argc, char *argv[])
          if (g_shared) g_shared->failed.fetch_add(1);
          _exit(1);
       }
+      abandon_children(); // rank 0 of a --gpus run: the others must not wait for it
       return EXIT_FAILURE;
    } catch (...) {
       std::cerr << timestamp() << "Caught unknown exception, terminating " << std::endl;
@@ -773,6 +867,7 @@ int main(int argc, char *argv[])
          if (g_shared) g_shared->failed.fetch_add(1);
          _exit(1);
       }
+      abandon_children();
       return EXIT_FAILURE;
    }
    return EXIT_SUCCESS;

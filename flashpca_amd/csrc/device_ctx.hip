@@ -69,6 +69,18 @@ static RcclApi &rccl()
    return api;
 }
 
+// allocations whose failure may legitimately be "does not fit": out-of-memory becomes FPCA_ENOMEM, anything else FPCA_EHIP
+#define HIP_ALLOC(expr)                                                                                      \
+   do {                                                                                                      \
+      hipError_t e__ = (expr);                                                                               \
+      if (e__ == hipErrorOutOfMemory) {                                                                      \
+         (void)hipGetLastError();                                                                            \
+         throw Error(FPCA_ENOMEM, std::string(#expr) + ": out of device memory");                            \
+      }                                                                                                      \
+      if (e__ != hipSuccess)                                                                                 \
+         throw Error(FPCA_EHIP, std::string(#expr) + " failed: " + hipGetErrorString(e__));                  \
+   } while (0)
+
 #define RCCL_CHECK(expr)                                                                                     \
    do {                                                                                                      \
       ncclResult_t r__ = (expr);                                                                             \
@@ -310,7 +322,7 @@ bool ensure_i8(fpca_ctx *c, int b)
       ensure_i8_alloc(c, b);
       return true;
    } catch (const Error &e) {
-      if (!c->i8_auto || (e.code != FPCA_EHIP && e.code != FPCA_ENOMEM)) throw;
+      if (!c->i8_auto || e.code != FPCA_ENOMEM) throw; // only "does not fit"; a kernel or launch failure is not masked
       (void)hipGetLastError();
       std::fprintf(stderr, "[fpca] exact-integer mode needs more device memory than is free (%s); using the fp64 kernels\n", e.what());
       void **ptrs[] = {(void **)&c->d_packedT, (void **)&c->d_Qb, (void **)&c->d_Qg, (void **)&c->d_Qm, (void **)&c->d_i8ws};
@@ -337,10 +349,10 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
       throw Error(FPCA_EINVAL, "the int8-sliced mode supports up to 8,380,000 samples and SNPs per GPU (int32 accumulation)");
    if (!c->i8_transposed) {
       c->pitchT = (size_t)c->P_pad / 4;
-      if (!c->d_inv_sd) HIP_CHECK(hipMalloc(&c->d_inv_sd, c->P_pad * sizeof(double)));
-      if (!c->d_mu_inv_sd) HIP_CHECK(hipMalloc(&c->d_mu_inv_sd, c->P_pad * sizeof(double)));
-      if (!c->d_i8w) HIP_CHECK(hipMalloc(&c->d_i8w, I8W_TOTAL * sizeof(double)));
-      HIP_CHECK(hipMalloc(&c->d_packedT, c->pitchT * c->N_pad));
+      if (!c->d_inv_sd) HIP_ALLOC(hipMalloc(&c->d_inv_sd, c->P_pad * sizeof(double)));
+      if (!c->d_mu_inv_sd) HIP_ALLOC(hipMalloc(&c->d_mu_inv_sd, c->P_pad * sizeof(double)));
+      if (!c->d_i8w) HIP_ALLOC(hipMalloc(&c->d_i8w, I8W_TOTAL * sizeof(double)));
+      HIP_ALLOC(hipMalloc(&c->d_packedT, c->pitchT * c->N_pad));
       kern::transpose_packed(c->d_packed, c->pitch, c->N_pad, c->P_pad, c->d_packedT, c->pitchT, s);
       c->i8_transposed = true;
    }
@@ -355,9 +367,9 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
             HIP_CHECK(hipFree(*q));
             *q = nullptr;
          }
-      HIP_CHECK(hipMalloc(&c->d_Qb, (size_t)nsc * c->N_pad));
-      HIP_CHECK(hipMalloc(&c->d_Qg, (size_t)nsc * c->P_pad));
-      HIP_CHECK(hipMalloc(&c->d_Qm, (size_t)nsc * c->P_pad));
+      HIP_ALLOC(hipMalloc(&c->d_Qb, (size_t)nsc * c->N_pad));
+      HIP_ALLOC(hipMalloc(&c->d_Qg, (size_t)nsc * c->P_pad));
+      HIP_ALLOC(hipMalloc(&c->d_Qm, (size_t)nsc * c->P_pad));
       c->i8_nsc = nsc;
    }
    // rows >= S*b of the Q operands must be zero (they are multiplied like any other column)
@@ -381,7 +393,7 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
       if (c->d_i8ws) HIP_CHECK(hipFree(c->d_i8ws));
       c->d_i8ws = nullptr;
       c->i8ws_cap = 0;
-      HIP_CHECK(hipMalloc(&c->d_i8ws, need * sizeof(double)));
+      HIP_ALLOC(hipMalloc(&c->d_i8ws, need * sizeof(double)));
       c->i8ws_cap = need;
    }
 }
@@ -554,6 +566,23 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_
                  eplane, b, c->i8_S, nullptr, s, gev, wait);
 }
 
+// The all-reduce of a finished Y, in the SAME sequence of collectives as the overlapped row chunks of the exact-integer
+// path (ar_chunks depends on N and the communicator only): every rank issues identical calls whatever arithmetic it runs --
+// a rank whose int8 buffers did not fit (FPCA_ACCUM_AUTO falls back to fp64 per rank) still matches the others.
+void allreduce_rows(fpca_ctx *c, double *dY, int b, hipStream_t s)
+{
+   if (!c->multi()) return;
+   const int nch = ar_chunks(c);
+   if (nch <= 1) {
+      c->allreduce(dY, (uint64_t)c->N_pad * b, s);
+      return;
+   }
+   for (int i = 0; i < nch; i++) {
+      const uint64_t r0 = ar_chunk_begin(c, nch, i), r1 = ar_chunk_begin(c, nch, i + 1);
+      if (r1 > r0) RCCL_CHECK(rccl().AllReduce(dY + r0 * b, dY + r0 * b, (r1 - r0) * b, ncclDouble, ncclSum, c->comm, s));
+   }
+}
+
 // the operator on device-resident blocks: dY = X_g X_g' dB (+ all-reduce).  ev (optional): 4 events recorded
 // at [start, after K2(+reduce), after K3(+reduce), after all-reduce].
 void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t s, hipEvent_t *ev)
@@ -585,7 +614,7 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
       }
       x_i8(c, b, dY, s, true, true, 0, 0, ev ? ev + 6 : nullptr);
       if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
-      if (c->multi()) c->allreduce(dY, (uint64_t)c->N_pad * b, s);
+      allreduce_rows(c, dY, b, s);
       if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
       return;
    }
@@ -613,7 +642,7 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
    if (ev) HIP_CHECK(hipEventRecord(ev[7], s));
    if (s3 > 1) kern::reduce_sum(c->d_part, dY, (uint64_t)c->N_pad * b, s3, s);
    if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
-   if (c->multi()) c->allreduce(dY, (uint64_t)c->N_pad * b, s);
+   allreduce_rows(c, dY, b, s);
    if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
 }
 
@@ -955,6 +984,15 @@ int fpca_create_from_bed(fpca_ctx **out, const char *bed_path, uint64_t N, uint6
          throw Error(FPCA_EIO, std::string("[Data::read_bed] Error reading file ") + bed_path + ", error " + strerror(errno));
       struct stat st;
       if (fstat(fd, &st) != 0 || st.st_size < 3) throw Error(FPCA_EIO, std::string("cannot stat ") + bed_path);
+      // The reference skips the three header bytes unseen (data.cpp:218: seekg(3 + ...)); a sample-major file (third byte 0)
+      // or something that is not a .bed at all would be decoded as garbage without a word.  Checked here.
+      unsigned char magic[3] = {0, 0, 0};
+      if (pread(fd, magic, 3, 0) != 3) throw Error(FPCA_EIO, std::string("[Data::read_bed] Error reading file ") + bed_path);
+      if (magic[0] != 0x6c || magic[1] != 0x1b)
+         throw Error(FPCA_EIO, std::string(bed_path) + " is not a PLINK .bed file (it does not start with the magic bytes 6c 1b)");
+      if (magic[2] != 0x01)
+         throw Error(FPCA_EIO, std::string(bed_path) + (magic[2] == 0x00 ? " is a sample-major .bed (header 6c 1b 00)" : " has an unknown .bed mode byte") +
+                                   "; only SNP-major files (header 6c 1b 01) are supported -- convert with plink --make-bed");
       const uint64_t len = (uint64_t)st.st_size - 3; // data.cpp:165
       const uint64_t np = (N + 3) / 4;               // data.cpp:168
       const uint64_t nsnps = len / np;               // data.cpp:170 (integer division; .bim is not consulted)
@@ -1316,7 +1354,7 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
       out.d = d;
       out.Px = Px;
       out.pve = pve;
-      int ritz = -1;
+      std::vector<int> ritz;
       double div = 1;
       std::vector<double> dloc(k);
       if (!out.d) out.d = dloc.data();
@@ -1324,16 +1362,22 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
       lap("run_pca");
       if (opts->do_loadings && V) {
          // randompca.cpp:191-204: V[:, j] = X' u_j / sqrt(d_j) / sqrt(div); one K2 pass for all k columns
-         xt_dev(ctx, be.ptr(ritz), b, ctx->stream);
-         std::vector<double> sc(b, 0.0);
-         for (int j = 0; j < k; j++) sc[j] = (1.0 / std::sqrt(out.d[j])) / std::sqrt(div);
-         HIP_CHECK(hipMemcpyAsync(ctx->d_small, sc.data(), b * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-         ctx->ensure(ctx->d_stage, ctx->stage_cap, (size_t)std::max(ctx->N, ctx->P_g) * k);
-         kern::t_to_colmajor(ctx->d_T, ctx->P_g, b, k, ctx->d_small, ctx->d_stage, ctx->P_g, ctx->stream);
-         HIP_CHECK(hipMemcpyAsync(V, ctx->d_stage, (size_t)ctx->P_g * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+         // (b eigenvectors per Ritz block; ndim > b takes several)
+         ctx->ensure(ctx->d_stage, ctx->stage_cap, (size_t)std::max(ctx->N, ctx->P_g) * std::min(k, b));
+         std::vector<double> sc(b);
+         for (int j0 = 0, q = 0; j0 < k; j0 += b, q++) {
+            const int nc = std::min(b, k - j0);
+            xt_dev(ctx, be.ptr(ritz[q]), b, ctx->stream);
+            std::fill(sc.begin(), sc.end(), 0.0);
+            for (int j = 0; j < nc; j++) sc[j] = (1.0 / std::sqrt(out.d[j0 + j])) / std::sqrt(div);
+            HIP_CHECK(hipMemcpyAsync(ctx->d_small, sc.data(), b * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            kern::t_to_colmajor(ctx->d_T, ctx->P_g, b, nc, ctx->d_small, ctx->d_stage, ctx->P_g, ctx->stream);
+            HIP_CHECK(hipMemcpyAsync(V + (size_t)j0 * ctx->P_g, ctx->d_stage, (size_t)ctx->P_g * nc * sizeof(double), hipMemcpyDeviceToHost,
+                                     ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream)); // sc / d_stage are reused by the next block
+         }
       }
-      be.free_block(ritz);
+      for (int h : ritz) be.free_block(h);
       if (mean_sd && ctx->P_g) {
          HIP_CHECK(hipMemcpy(mean_sd, ctx->d_mean, ctx->P_g * sizeof(double), hipMemcpyDeviceToHost));
          HIP_CHECK(hipMemcpy(mean_sd + ctx->P_g, ctx->d_sd, ctx->P_g * sizeof(double), hipMemcpyDeviceToHost));

@@ -17,19 +17,17 @@ namespace fpca {
 int choose_blockvec(int ndim, int requested)
 {
    if (ndim < 1) throw Error(FPCA_EINVAL, "ndim must be >= 1");
-   if (ndim > MAX_BLOCKVEC) throw Error(FPCA_EINVAL, "ndim > 64 is not supported by this build");
-   int b = requested;
+   int b = requested; // ndim > b is fine: the solver keeps ceil(ndim / b) + 1 Ritz blocks (solver.cpp)
    if (b <= 0) {
       b = (int)round_up((uint64_t)ndim + 4, 16);
       if (b > MAX_BLOCKVEC) b = MAX_BLOCKVEC;
    }
    if (b % 16 != 0 || b < 16 || b > MAX_BLOCKVEC) throw Error(FPCA_EINVAL, "blockvec must be 16, 32, 48 or 64");
-   if (b < ndim) throw Error(FPCA_EINVAL, "blockvec must be >= ndim");
    return b;
 }
 
 int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaOutputs &out, fpca_pca_info *info,
-            int *ritz_block, double *div_out)
+            std::vector<int> *ritz_blocks, double *div_out)
 {
    auto t0 = std::chrono::steady_clock::now();
    const uint64_t N = be.nrows();
@@ -77,7 +75,8 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
          U = tmp.data();
       }
       lap("trace, eigenvalues");
-      be.download(r.ritz_block, k, U, (int64_t)N);
+      for (int j0 = 0, q = 0; j0 < k; j0 += be.width(), q++)
+         be.download(r.ritz_blocks[q], std::min(be.width(), k - j0), U + (size_t)j0 * N, (int64_t)N);
       lap("download U");
       if (out.Px) { // :207  Px = U diag(sqrt(d)); a memory-bound N x k pass, one column per thread when it is big
          auto column = [&](int j) {
@@ -98,10 +97,10 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
       }
       lap("Px = U sqrt(d)");
    }
-   if (ritz_block)
-      *ritz_block = r.ritz_block;
+   if (ritz_blocks)
+      *ritz_blocks = r.ritz_blocks;
    else
-      be.free_block(r.ritz_block);
+      for (int h : r.ritz_blocks) be.free_block(h);
    if (info) {
       info->converged = r.converged ? 1 : 0;
       info->block_applies = r.block_applies;

@@ -140,9 +140,13 @@ SolverResult dense_small(BlockBackend &be, const SolverOpts &o)
       res.residuals[i] = std::sqrt(r2);
       res.max_rel_residual = std::max(res.max_rel_residual, res.residuals[i] / std::max(std::pow(DBL_EPSILON, 2.0 / 3.0), std::fabs(w[i])));
    }
-   be.upload(in, (int)std::min<uint64_t>((uint64_t)b, N), A.data(), (int64_t)N);
    be.free_block(out);
-   res.ritz_block = in;
+   be.free_block(in);
+   for (int j0 = 0; j0 < k; j0 += b) { // Ritz block j holds eigenvectors j b .. (j+1) b - 1
+      const int h = be.alloc_block();
+      be.upload(h, (int)std::min<uint64_t>((uint64_t)b, N - (uint64_t)j0), &A[(size_t)j0 * N], (int64_t)N);
+      res.ritz_blocks.push_back(h);
+   }
    res.converged = true;
    res.seconds_host = since(t0);
    if (o.verbose) std::fprintf(stderr, "[fpca] %llu samples < 3 x block width %d: dense eigendecomposition of X X' (%d applies)\n",
@@ -157,11 +161,16 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    const int b = be.width();
    const int k = o.k;
    const uint64_t N = be.nrows();
-   if (k < 1 || k > b) throw Error(-1, "solver: need 1 <= k <= block width");
+   if (k < 1 || (uint64_t)k > N) throw Error(-1, "solver: need 1 <= k <= N");
+   // k > b (more wanted pairs than one block holds; the reference admits ndim up to (min(N,P)-1)/2, flashpca.cpp:623-633):
+   // the wanted Ritz vectors occupy kb blocks, a thick restart keeps kb + 1 blocks of them, and the basis cap grows with k
+   const int kb = (k + b - 1) / b;
+   const int nk_wide = kb > 1 ? kb + 1 : 0; // Ritz blocks a restart keeps when k > b (0: the k <= b rule below)
    int mcap = o.max_blocks > 0 ? o.max_blocks : std::max(4, 512 / b);
+   if (kb > 1) mcap = std::max(mcap, 2 * nk_wide + 2);
    // the basis [V_0..V_{m-1}, Q] must fit in N dimensions
    const int fit = (int)std::min<uint64_t>(N / (uint64_t)b, 1u << 20) - 1;
-   if (fit < 2) return dense_small(be, o);
+   if (fit < 2 || (kb > 1 && fit < nk_wide + 2)) return dense_small(be, o);
    mcap = std::min(mcap, fit);
    if (mcap < 2) mcap = 2;
    const int nmax = mcap * b;
@@ -307,6 +316,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       // Far from convergence the Rayleigh-Ritz test cannot succeed at the very next step (residuals fall by one to two
       // orders of magnitude per block apply at best): it is skipped for a step (two when six orders away).  Convergence is
       // only ever declared by an actual test, so the worst case is one block apply more than strictly needed.
+      if (n < k && skip_rr == 0) skip_rr = 1; // fewer basis columns than wanted pairs: nothing to test yet
       if (skip_rr > 0 && res.block_applies < o.max_applies && m + 1 <= mcap) {
          skip_rr--;
          host_s += since(t0);
@@ -314,6 +324,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          W = be.alloc_block();
          continue;
       }
+      if (n < k) throw Error(-5, "solver: maxiter allows fewer basis vectors than the wanted number of eigenpairs");
       for (int j = 0; j < n; j++) std::memcpy(&Tw[(size_t)j * n], &T[(size_t)j * nmax], sizeof(double) * n);
       // eigenvalues + the last block of rows of the eigenvectors (all the residual test needs); the full
       // eigenvector matrix is formed only when it is used: convergence, thick restart, last step
@@ -344,11 +355,11 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       if (all_conv || res.block_applies >= o.max_applies || m + 1 > mcap) {
          // eigenvectors are needed now, but only the leading 2 b of them (Ritz vectors kept by a restart / returned):
          // selected columns by inverse iteration, verified inside; the full QL decomposition is the fallback
-         const int need = std::min(n, 2 * b);
+         const int need = std::min(n, std::max(2, nk_wide) * b);
          std::vector<double> th(n);
          S.assign((size_t)n * need, 0.0);
          for (int j = 0; j < n; j++) std::memcpy(&Tw[(size_t)j * n], &T[(size_t)j * nmax], sizeof(double) * n);
-         if (n > 3 * b && symeig_desc_cols(n, Tw.data(), n, th.data(), need, S.data()) == 0) {
+         if (n > need + b && symeig_desc_cols(n, Tw.data(), n, th.data(), need, S.data()) == 0) {
             std::copy(th.begin(), th.end(), theta.begin());
          } else {
             for (int j = 0; j < n; j++) std::memcpy(&Tw[(size_t)j * n], &T[(size_t)j * nmax], sizeof(double) * n);
@@ -371,7 +382,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          // ---- thick restart: keep the best Ritz vectors + the new residual block ----------------------
          // nk blocks of them: one when the cap is tight, two otherwise (the second block of Ritz vectors keeps the
          // neighbourhood of the wanted end of the spectrum in the basis, which is what slowly converging pairs need)
-         const int nk = (mcap >= 6 && m >= 3) ? 2 : 1;
+         const int nk = nk_wide ? nk_wide : (mcap >= 6 && m >= 3) ? 2 : 1;
          t0 = clk::now();
          std::vector<std::vector<double>> Sk(nk, std::vector<double>((size_t)m * b * b));
          std::vector<double> Cpl((size_t)b * b * nk); // R * S[last block, 0 : nk b]  (b x nk b, column-major)
@@ -405,16 +416,20 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       }
    }
 
-   // ---- Ritz vectors of the last Rayleigh-Ritz: U = V S[:, 0:b] -----------------------------------
+   // ---- Ritz vectors of the last Rayleigh-Ritz: U_j = V S[:, j b : (j+1) b], j < kb ------------------
    {
       const int m = n / b;
+      const int have = (int)(S.size() / (size_t)std::max(n, 1)); // columns of S that were formed
       std::vector<double> Sk((size_t)m * b * b);
-      for (int q = 0; q < m; q++)
-         for (int p = 0; p < b; p++)
-            for (int c = 0; c < b; c++) Sk[((size_t)q * b + p) * b + c] = S[(size_t)(q * b + p) + (size_t)c * n];
-      int U = be.alloc_block();
-      be.gemm(V.data(), m, Sk.data(), -1, U);
-      res.ritz_block = U;
+      for (int j = 0; j < kb; j++) {
+         for (int q = 0; q < m; q++)
+            for (int p = 0; p < b; p++)
+               for (int c = 0; c < b; c++)
+                  Sk[((size_t)q * b + p) * b + c] = (j * b + c < have) ? S[(size_t)(q * b + p) + (size_t)(j * b + c) * n] : 0.0;
+         int U = be.alloc_block();
+         be.gemm(V.data(), m, Sk.data(), -1, U);
+         res.ritz_blocks.push_back(U);
+      }
    }
    for (int h : V) be.free_block(h);
    be.free_block(W);

@@ -11,7 +11,7 @@
 namespace fpca {
 
 struct SolverOpts {
-   int k = 10;            // wanted eigenpairs (<= b)
+   int k = 10;            // wanted eigenpairs (any k <= N; k > b keeps ceil(k/b) + 1 Ritz blocks across restarts)
    int max_applies = 500; // operator applications (blocks) before giving up
    double tol = 1e-6;
    int max_blocks = 0;    // basis cap in blocks (>= 3); 0 = automatic
@@ -27,7 +27,7 @@ struct SolverResult {
    double seconds_host = 0;      // projected eigenproblem + small dense algebra
    std::vector<double> evals;    // k eigenvalues of A, descending
    std::vector<double> residuals; // k residual norm estimates ||A u - theta u||
-   int ritz_block = -1;          // backend block whose first k columns are the eigenvectors (caller frees)
+   std::vector<int> ritz_blocks; // ceil(k/b) backend blocks: block j holds eigenvectors j b .. (j+1) b - 1 (caller frees)
 };
 
 // Throws fpca::Error on backend failure.  Result.converged == false means max_applies was reached.

@@ -147,6 +147,40 @@ def test_block_krylov_schur_vs_golden(golden_dir, name, k, kw):
     assert r["applies"] <= 40
 
 
+@pytest.mark.parametrize("k,kw", [(100, {}), (70, dict(blockvec=32)), (200, {})])
+def test_more_components_than_the_block_width(golden_dir, k, kw):
+    """ndim > 64 (the reference admits ndim <= (min(N,P)-1)/2 = 478 here, flashpca.cpp:623-633): the wanted Ritz vectors
+    span several blocks, restarts keep ceil(k/b)+1 blocks.  Against the dense eigendecomposition, eigenvectors through the
+    residual (the tail of the wanted spectrum sits in the bulk: single vectors are ill-conditioned, the residual is not)."""
+    N = O.count_fam_rows(os.path.join(golden_dir, "data_chr1.fam"))
+    d = O.OracleData(os.path.join(golden_dir, "data_chr1.bed"), N, "binom2")
+    X = d.dense()
+    w = np.linalg.eigvalsh(X @ X.T)[::-1][:k] / d.P
+    rc, r = run_pca(d, k, **kw)
+    assert rc == 0 and r["converged"] == 1
+    assert r["b"] == kw.get("blockvec", 64)
+    assert np.max(np.abs(r["d"] - w) / w) < 1e-9
+    assert np.max(np.abs(r["U"].T @ r["U"] - np.eye(k))) < 1e-9
+    res = np.linalg.norm(X @ (X.T @ r["U"]) / d.P - r["U"] * r["d"], axis=0)
+    assert np.max(res / r["d"]) < 2e-6  # the solver's own rule: ||A u - theta u|| < tol max(eps^(2/3), theta), tol = 1e-6
+    assert np.max(np.abs(r["Px"] - r["U"] * np.sqrt(r["d"]))) < 1e-12
+
+
+def test_more_components_than_the_block_width_few_samples():
+    """k > b and too few samples for ceil(k/b)+3 blocks: the dense route, Ritz vectors in several blocks."""
+    rng = np.random.default_rng(11)
+    N, P, k = 300, 900, 120
+    packed = rng.integers(0, 256, size=(P, (N + 3) // 4), dtype=np.uint8)
+    d = O.OracleData(packed=packed, N=N, P=P, stand="binom2")
+    X = d.dense()
+    w = np.linalg.eigvalsh(X @ X.T / P)[::-1]
+    rc, r = run_pca(d, k)
+    assert rc == 0 and r["converged"] == 1 and r["applies"] == -(-N // 64)
+    assert np.max(np.abs(r["d"] - w[:k])) < 1e-10 * w[0]
+    assert np.max(np.abs(r["U"].T @ r["U"] - np.eye(k))) < 1e-10
+    assert np.max(np.abs(X @ (X.T @ r["U"]) / P - r["U"] * r["d"])) < 1e-9 * w[0]
+
+
 def test_not_converged_is_reported(golden_dir):
     N = O.count_fam_rows(os.path.join(golden_dir, "data_chr1.fam"))
     d = O.OracleData(os.path.join(golden_dir, "data_chr1.bed"), N, "binom2")
