@@ -664,6 +664,12 @@ int main(int argc, char *argv[])
          }
          if (!multi_barrier(mg)) return multi_abort();
          if (mg.test_transport) {
+            // failure injection for tests/test_cli.py (test transport only): rank R kills itself / rank 0 throws after the
+            // fork -- the run must end with a message and a non-zero status instead of hanging
+            if (const char *kr = std::getenv("FPCA_CLI_TEST_KILL_RANK")) {
+               if (atoi(kr) == mg.rank && mg.rank > 0) raise(SIGKILL);
+               if (atoi(kr) == 0 && mg.rank == 0) throw std::runtime_error("injected failure of rank 0 after the fork");
+            }
             if (fpca_set_allreduce(ctx, shm_allreduce, &mg) != FPCA_OK) multi_fail(mg, fpca_last_error());
          } else {
             if (mg.rank == 0) {

@@ -93,7 +93,7 @@ for case in range(ncases):
             sys.exit(1)
         proj = table(os.path.join(td, "proj.txt"))
         e_proj = float(np.max(np.abs(proj - pcs)) / np.sqrt(w[0]))
-        r3 = subprocess.run([CLI, "--bfile", pre, "--check", "--outvec", "eigenvectors.txt", "--outval", "eigenvalues.txt", "--standx", stand, "--div", div],
+        r3 = subprocess.run([CLI, "--bfile", pre, "--check", "--verbose", "--outvec", "eigenvectors.txt", "--outval", "eigenvalues.txt", "--standx", stand, "--div", div],
                             cwd=td, capture_output=True, text=True)
         ok3 = r3.returncode == 0 and r3.stdout.count("eval") >= k
         tol_txt = max(rt, 1e-8)

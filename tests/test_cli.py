@@ -78,7 +78,10 @@ def test_cli_end_to_end(tmp_path, built_lib):
     assert ms[0] == "SNP\tRefAllele\tMean\tSD" and len(ms) == 1130
     assert ms[1].split("\t")[2] == "%.7g" % g["mean_first8"][0]
     # --check re-reads eigenvectors/eigenvalues (randompca.cpp:627-661); 7-digit files -> mse ~1e-12
+    # (printed under --verbose only, like the reference: randompca.cpp:670-700)
     r = run(["--bfile", DATA, "--check", "--notime"], cwd=tmp_path)
+    assert r.returncode == 0 and "Mean squared error:" not in r.stdout
+    r = run(["--bfile", DATA, "--check", "--notime", "--verbose"], cwd=tmp_path)
     assert r.returncode == 0 and "Mean squared error:" in r.stdout
     mse = float(r.stdout.split("Mean squared error: ")[1].split(",")[0])
     assert mse < 1e-8
@@ -159,3 +162,63 @@ def test_cli_gpus_launcher(tmp_path, built_lib, golden_dir):
         assert "device index out of range" in r.stderr
     r = subprocess.run([fp.CLI_PATH, "--bfile", data, "--check", "--gpus", "2"], cwd=d, capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "--gpus applies to PCA only" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_gpus_launcher_failures_do_not_hang(tmp_path, built_lib, golden_dir):
+    """A rank that dies (SIGKILL: what an OOM kill looks like), or rank 0 failing after the fork, must end the whole --gpus
+    run promptly with a message and a non-zero status; what can be refused from the file sizes is refused before the fork."""
+    import time
+
+    import flashpca_amd as fp
+
+    data = os.path.join(golden_dir, "hapmap3_data")
+    env = dict(os.environ, FPCA_CLI_TEST_TRANSPORT="shm")
+    for victim, text in (("1", "died unexpectedly"), ("2", "died unexpectedly"), ("0", "injected failure of rank 0")):
+        t0 = time.time()
+        r = subprocess.run([fp.CLI_PATH, "--bfile", data, "--ndim", "5", "--gpus", "3"], cwd=tmp_path, capture_output=True, text=True,
+                           env=dict(env, FPCA_CLI_TEST_KILL_RANK=victim), timeout=120)
+        assert r.returncode == 1 and text in r.stderr, (victim, r.stdout[-800:], r.stderr[-800:])
+        assert time.time() - t0 < 60
+        assert not os.path.exists(tmp_path / "eigenvalues.txt")
+    # refused before the fork: ndim limit, .bim / .bed mismatch when a file with SNP row names is asked for
+    r = subprocess.run([fp.CLI_PATH, "--bfile", data, "--ndim", "500", "--gpus", "3"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=60)
+    assert r.returncode == 1 and "You asked for 500 dimensions, but only 478allowed" in r.stderr
+    import shutil
+
+    for ext in (".bed", ".fam"):
+        shutil.copy(data + ext, str(tmp_path / ("mm" + ext)))
+    lines = open(data + ".bim").read().splitlines(True)
+    open(tmp_path / "mm.bim", "w").writelines(lines[:-7])
+    for extra in ([], ["--gpus", "2"]):
+        r = subprocess.run([fp.CLI_PATH, "--bfile", str(tmp_path / "mm"), "--ndim", "5", "--outload", "l.txt"] + extra, cwd=tmp_path,
+                           capture_output=True, text=True, env=env, timeout=60)
+        assert r.returncode == 1 and "different number of SNPs" in r.stderr
+        assert not os.path.exists(tmp_path / "eigenvalues.txt")  # nothing was computed or written first
+    # without a file that needs the names the mismatch does not matter (the reference never consults the .bim for sizes)
+    r = subprocess.run([fp.CLI_PATH, "--bfile", str(tmp_path / "mm"), "--ndim", "5"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [100, 200])
+def test_cli_more_components_than_the_block_width(tmp_path, built_lib, golden_dir, k):
+    """flashpca --ndim 100 / 200 (the reference admits up to 478 here): files against a dense eigendecomposition."""
+    import flashpca_amd as fp
+    from oracle import oracle as O
+
+    data = os.path.join(golden_dir, "hapmap3_data")
+    r = subprocess.run([fp.CLI_PATH, "--bfile", data, "--ndim", str(k), "--precision", "14", "--notime"], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    N = O.count_fam_rows(data + ".fam")
+    od = O.OracleData(data + ".bed", N, "binom2")
+    X = od.dense()
+    w = np.linalg.eigvalsh(X @ X.T)[::-1][:k] / od.P
+    e = np.loadtxt(tmp_path / "eigenvalues.txt")
+    assert e.shape == (k,) and np.max(np.abs(e - w) / w) < 1e-9
+    U = _tab(tmp_path / "eigenvectors.txt")
+    assert U.shape == (N, k) and np.max(np.abs(U.T @ U - np.eye(k))) < 1e-9
+    res = np.linalg.norm(X @ (X.T @ U) / od.P - U * e, axis=0)
+    assert np.max(res / e) < 2e-6
+    assert np.max(np.abs(_tab(tmp_path / "pcs.txt") - U * np.sqrt(e))) < 1e-10

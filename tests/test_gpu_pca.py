@@ -144,6 +144,93 @@ def test_config2_pca_end_to_end(fp, orc):
             assert np.max(np.abs(y - y_ref)) <= 1e-11 * np.max(np.abs(y_ref))
 
 
+@pytest.mark.parametrize("accum", ["auto", "fp64"])
+def test_config2_full_oracle_solve(fp, orc, accum):
+    """the WHOLE 50,000 x 20,000 / k = 20 problem solved twice -- by the restated reference
+    path on the CPU (orc_pca_fast: Spectra-style IRLM, ncv = 2k+1, tol 1e-6, one decode -> LUT -> 2 GEMV pass over all
+    20,000 SNPs per Lanczos column; SNP sub-blocks dealt over the host cores) and by the GPU product in both arithmetic
+    modes.  Eigenvalues <= 1e-6 relative (north_star), eigenvectors up to sign, pve, trace, mean/sd bit-equal."""
+    N, P, k = 50000, 20000, 20
+    with fp.Context.synthetic(N, P, accum=accum) as ctx:
+        packed = ctx.download_packed()
+        r = ctx.pca(ndim=k)
+        assert r["info"]["converged"] == 1
+    od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+    ref = orc.pca_fast(od, k, tol=1e-6, nthreads=os.cpu_count() or 1)
+    assert ref["nops"] >= 2 * k + 1  # at least one full Lanczos factorisation: this is the reference's cost structure
+    rel = np.abs(r["d"] - ref["d"]) / ref["d"]
+    assert np.max(rel) < 1e-6, rel
+    assert np.max(np.abs(r["pve"] - ref["pve"])) < 1e-9
+    assert abs(r["info"]["trace"] - ref["trace"]) <= 1e-12 * ref["trace"]
+    assert np.array_equal(r["meansd"], ref["meansd"])
+    # eigenvectors up to sign (test_pca.R:29-31); 39 structured eigenvalues, k = 20 of them: every wanted pair is isolated.
+    # Both solvers stop at ||A u - theta u|| < 1e-6 theta, so vectors agree to ~tol x theta / gap
+    for c in range(k):
+        sgn = np.sign(ref["U"][:, c] @ r["U"][:, c])
+        assert np.max(np.abs(ref["U"][:, c] * sgn - r["U"][:, c])) < 1e-5, c
+        assert abs(abs(ref["U"][:, c] @ r["U"][:, c]) - 1.0) < 1e-8, c
+
+
+def test_config3_oracle_residual_at_full_size(fp, orc):
+    """at 500,000 x 100,000 the CPU oracle cannot run a whole solve, but it can apply the
+    reference operator (svdwide.cpp:21-68) to single vectors over ALL 100,000 SNPs: the residual || X X' u / P - d u ||
+    of the top two and of the k-th converged pair is computed BY THE ORACLE from the GPU's u and d (randompca.cpp:663-703
+    with the oracle as the operator), and one column of the loadings by the oracle's crossprod (svdwide.cpp:122-153).
+    Anything that goes wrong only at full size -- index width past 2^16 rows / 2^32 bytes, split-K plans, the XCD-aware
+    grid, two-phase split rows -- shows up here, in the default arithmetic mode."""
+    N, P, k = 500000, 100000, 20
+    nt = os.cpu_count() or 1
+    with fp.Context.synthetic(N, P, accum="auto") as ctx:
+        packed = ctx.download_packed()
+        r = ctx.pca(ndim=k, do_loadings=True)
+        assert r["info"]["converged"] == 1
+        od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+        op = orc.OracleOp(od, 1000, nthreads=nt)
+        for c in (0, 1, k - 1):
+            u = np.ascontiguousarray(r["U"][:, c])
+            y = op.perform_op(u) / P
+            res = np.linalg.norm(y - r["d"][c] * u)
+            assert res <= 1e-6 * r["d"][c], (c, res, r["d"][c])  # Spectra's rule at tol 1e-6, judged by the oracle
+            # and the GPU operator itself against the oracle's on the same vector, entry by entry
+            if c == 0:
+                yg = ctx.apply_xxt(r["U"][:, :1])[:, 0] / P
+                assert np.max(np.abs(yg - y)) <= 1e-11 * np.max(np.abs(y))
+        # statistics of all 100,000 SNPs: bit-equal (K1 vs data.cpp:257-322)
+        assert np.array_equal(r["meansd"], od.meansd())
+        # loadings column k-1: V = X' u / sqrt(d) / sqrt(P) (randompca.cpp:191-204) with the oracle's crossprod
+        c = k - 1
+        v = op.crossprod(np.ascontiguousarray(r["U"][:, c])) / np.sqrt(r["d"][c]) / np.sqrt(P)
+        assert np.max(np.abs(v - r["V"][:, c])) <= 1e-11 * np.max(np.abs(v))
+        assert abs(op.trace / P - r["info"]["trace"]) <= 1e-12 * r["info"]["trace"]
+
+
+@pytest.mark.parametrize("k,accum", [(100, "auto"), (200, "fp64"), (478, "auto")])
+def test_more_components_than_the_block_width(golden_dir, fp, k, accum):
+    """ndim > 64 up to the reference's limit (min(N,P)-1)/2 = 478 on HapMap3 (flashpca.cpp:623-633): against the dense
+    eigendecomposition to 1e-9, eigenvectors through orthonormality and the per-pair residual, loadings unit-norm."""
+    name = "hapmap3_data"
+    N = fp.count_fam_rows(os.path.join(golden_dir, name + ".fam"))
+    with fp.Context.from_bed(os.path.join(golden_dir, name + ".bed"), N, accum=accum) as ctx:
+        packed = ctx.download_packed()
+        P = ctx.P
+        r = ctx.pca(ndim=k, do_loadings=True)
+        assert r["info"]["converged"] == 1 and r["info"]["blockvec"] == 64
+        with pytest.raises(fp.FpcaError):
+            ctx.pca(ndim=479)
+    from oracle import oracle as O
+
+    X = O.OracleData(packed=packed, N=N, P=P, stand="binom2").dense()
+    w = np.linalg.eigvalsh(X @ X.T)[::-1][:k] / P
+    assert np.max(np.abs(r["d"] - w) / w) < 1e-9
+    assert np.max(np.abs(r["U"].T @ r["U"] - np.eye(k))) < 1e-9
+    res = np.linalg.norm(X @ (X.T @ r["U"]) / P - r["U"] * r["d"], axis=0)
+    assert np.max(res / r["d"]) < 2e-6
+    assert np.max(np.abs(r["Px"] - r["U"] * np.sqrt(r["d"]))) < 1e-12
+    Vref = X.T @ r["U"] / np.sqrt(r["d"]) / np.sqrt(P)
+    assert np.max(np.abs(r["V"] - Vref)) < 1e-10
+    assert np.max(np.abs(np.sum(r["V"] ** 2, axis=0) - 1.0)) < 1e-5
+
+
 def test_fp32_mode_tolerance_study(golden_dir, fp):
     """Config-5 style tolerance study at fixture size: eigenvalues of the mixed fp32 path vs the dense golden.
     north_star: eigenvalues within 1e-6 relative."""
@@ -228,6 +315,20 @@ def test_config5_full_size_properties(fp):
         assert r["info"]["converged"] == 1 and r["info"]["blockvec"] == 64 and r["info"]["block_applies"] <= 12
         err, mse, rmse = ctx.check(r["U"], r["d"])
         assert np.all(np.sqrt(err) <= 1.01e-6 * r["d"])
+        d8, U8 = r["d"], r["U"]
+    # configs[4] names "fp32 accumulate (tolerance study)": the mixed fp32 mode at FULL size -- eigenvalues against the
+    # exact-integer result (north_star: 1e-6 relative), the operator's entry-wise error on a probe, and the --check quantity
+    with fp.Context.synthetic(N, P, n_pop=64, accum="fp32") as c32:
+        A32 = c32.apply_xxt(u[:, :1])
+        op_err = np.max(np.abs(A32[:, 0] - A64[:, 0])) / np.max(np.abs(A64[:, 0]))
+        assert op_err < 5e-6, op_err
+        r32 = c32.pca(ndim=k)
+        assert r32["info"]["converged"] == 1
+        ev_err = np.max(np.abs(r32["d"] - d8) / d8)
+        assert ev_err < 1e-6, ev_err
+        print("config 5 fp32 tolerance study: operator max rel err %.3e, eigenvalue max rel err %.3e" % (op_err, ev_err))
+        for c in range(k):
+            assert abs(abs(U8[:, c] @ r32["U"][:, c]) - 1.0) < 1e-6, c
     per = P // 8  # config 5's shard: 25,000 SNPs per GPU
     acc = np.zeros(N)
     for g in range(8):
