@@ -308,6 +308,7 @@ def main():
     if world == 1 and args.accum in ("fp64", "i8") and not args.no_alt:
         other = "fp64" if args.accum == "i8" else "i8"
         with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=min(2 * k, 64), device=local_rank, accum=other) as c2:
+            c2.set_total_snps(P_total)
             Y2 = torch.zeros_like(Y)
             for _ in range(max(2, args.warmup)):
                 c2.apply_xxt_dev(B.data_ptr(), b, Y2.data_ptr())
@@ -348,7 +349,7 @@ def main():
         from oracle import oracle as O
 
         O.build()
-        ncore = os.cpu_count() or 1
+        ncore = O.host_threads()  # logical CPUs this container may use at once (cgroup quota; 16 of 256 on the test boxes)
         P_s = min(P_rank, 1000)
         with fp.Context.synthetic(N, P_s, snp_begin=0, n_pop=min(2 * k, 64), device=local_rank) as sh:
             packed = sh.download_packed()
@@ -369,11 +370,11 @@ def main():
                                           "svdwide.cpp:21-68) on the first %d SNPs x %d samples of the same synthetic matrix, "
                                           "block size %d, 1 thread (the shipped reference is single-threaded), %.1f s"
                                           % (nops, P_s, N, min(bs, P_s), tc),
-                                   host_cores=ncore)
+                                   host_cores=os.cpu_count(), host_cores_usable=ncore)
         # generous variant (NOT what the shipped reference does): SNP sub-blocks dealt to all host
         # cores, every thread with its own dense block and partial y (oracle/fpca_oracle.c op_mt); a sample big enough to
         # give every core work
-        P_a = min(P_rank, max(1000, 16 * ncore))
+        P_a = min(P_rank, max(2000, 64 * ncore))
         with fp.Context.synthetic(N, P_a, snp_begin=0, n_pop=min(2 * k, 64), device=local_rank) as sh:
             packed_a = sh.download_packed()
         oda = O.OracleData(packed=packed_a, N=N, P=P_a, stand="binom2")
@@ -388,7 +389,8 @@ def main():
         ta = time.perf_counter() - ta
         out["cpu_baseline_allcores"] = dict(value=float(N) * P_a * na / ta, unit="cells/s", cores=ncore, kind="port",
                                             sample="%d operator applications on %d SNPs x %d samples, SNP sub-blocks over %d OpenMP "
-                                                   "threads (per-thread dense block + partial y), %.1f s" % (na, P_a, N, ncore, ta))
+                                                   "threads = the CPUs this container may use (cgroup quota) of the host's %d "
+                                                   "(per-thread dense block + partial y), %.1f s" % (na, P_a, N, ncore, os.cpu_count() or 1, ta))
         # time to solution of the restated reference solver (Spectra-style IRLM, ncv = 2k+1, tol 1e-6, one operator
         # application per Lanczos column) on the WHOLE 50,000 x 20,000 matrix of BASELINE configs[1]: run for real on all
         # host cores (a 1-thread run takes ~ops x 0.45 s and would not fit the bench's time budget), next to this GPU's solve

@@ -81,6 +81,32 @@ def lib():
     return _lib
 
 
+def host_threads():
+    """CPU threads this process can actually run at once: the smallest of the logical CPU count, the affinity mask and the
+    cgroup CPU quota (cpu.max = "quota period"; containers on the GPU boxes get 16 CPUs of a 256-thread host -- running
+    256 OpenMP threads against a 16-CPU quota is throttled to a crawl)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for f in ("/sys/fs/cgroup/cpu.max", ):
+        try:
+            q, per = open(f).read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) // int(per))))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def count_fam_rows(path):
     """N = number of newline-terminated lines (data.cpp:526: an unterminated last line is dropped)."""
     with open(path, "rb") as f:

@@ -156,7 +156,7 @@ def test_config2_full_oracle_solve(fp, orc, accum):
         r = ctx.pca(ndim=k)
         assert r["info"]["converged"] == 1
     od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
-    ref = orc.pca_fast(od, k, tol=1e-6, nthreads=os.cpu_count() or 1)
+    ref = orc.pca_fast(od, k, tol=1e-6, nthreads=orc.host_threads())
     assert ref["nops"] >= 2 * k + 1  # at least one full Lanczos factorisation: this is the reference's cost structure
     rel = np.abs(r["d"] - ref["d"]) / ref["d"]
     assert np.max(rel) < 1e-6, rel
@@ -179,7 +179,7 @@ def test_config3_oracle_residual_at_full_size(fp, orc):
     Anything that goes wrong only at full size -- index width past 2^16 rows / 2^32 bytes, split-K plans, the XCD-aware
     grid, two-phase split rows -- shows up here, in the default arithmetic mode."""
     N, P, k = 500000, 100000, 20
-    nt = os.cpu_count() or 1
+    nt = orc.host_threads()
     with fp.Context.synthetic(N, P, accum="auto") as ctx:
         packed = ctx.download_packed()
         r = ctx.pca(ndim=k, do_loadings=True)
