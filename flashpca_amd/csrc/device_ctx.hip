@@ -419,7 +419,12 @@ int i8_mode(const fpca_ctx *c, int b)
 // The gather-sum runs on the low-priority side stream, released together with the GEMM of its stage, when it is big enough
 // to be worth two event hand-offs (~30 us): measured 11.0 / 11.9 ms vs 11.9 / 12.2 ms at cfg3, but 0.338 / 0.360 vs
 // 0.306 / 0.334 ms at cfg2, where it stays inline.
-bool sparse_on_side_stream(const fpca_ctx *c, int b) { return (double)c->n_missing * b * 8.0 > 2e9; }
+// FPCA_SPARSE_SIDE_BYTES overrides the threshold (bytes gathered per stage).
+bool sparse_on_side_stream(const fpca_ctx *c, int b)
+{
+   static const double thr = getenv("FPCA_SPARSE_SIDE_BYTES") ? atof(getenv("FPCA_SPARSE_SIDE_BYTES")) : 2e9;
+   return (double)c->n_missing * b * 8.0 > thr;
+}
 
 // index lists of the missing calls, built once (by SNP from the SNP-major stream, by sample from the sample-major copy)
 void ensure_sparse(fpca_ctx *c, int b)

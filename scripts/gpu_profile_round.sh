@@ -1,18 +1,24 @@
-# Regenerates the committed profile evidence of a round:  bash scripts/gpu_profile_round.sh r01
-# (run through gpurun; writes under gpurun_out/, copy the summaries into profiles/)
-R=${1:-r01}
+# Regenerates the committed profile evidence of a round:  bash scripts/gpu_profile_round.sh r02
+# (run through gpurun; writes under gpurun_out/<round>/, scripts/copy_profiles.sh copies the summaries into profiles/)
+R=${1:-r02}
 mkdir -p gpurun_out/$R; export TMPDIR=/tmp
 PMC_SQ="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-# the default line (exact-integer mode; carries the fp64 kernels' numbers as fp64_mode) and the explicit modes
-python bench.py > gpurun_out/$R/bench_cfg2_n1.json 2> gpurun_out/$R/bench_cfg2_n1.err
-python bench.py --workload cfg3 --no-cpu-baseline > gpurun_out/$R/bench_cfg3_n1.json 2>/dev/null
+Q="--no-cpu-baseline --no-pca-hard"
+# the default line = the driver's command (500k x 100k headline, exact-integer mode; carries the fp64 kernels' numbers as
+# fp64_mode, the CPU baseline and both PCA solves), then the other workloads and the explicit modes
+python bench.py > gpurun_out/$R/bench_cfg3_n1.json 2> gpurun_out/$R/bench_cfg3_n1.err
+python bench.py --workload cfg2 > gpurun_out/$R/bench_cfg2_n1.json 2>/dev/null
 for a in fp64 fp32 i8x6; do
-  python bench.py --accum $a --no-cpu-baseline --no-alt > gpurun_out/$R/bench_cfg2_n1_$a.json 2>/dev/null
-  python bench.py --workload cfg3 --accum $a --no-cpu-baseline --no-alt > gpurun_out/$R/bench_cfg3_n1_$a.json 2>/dev/null
+  python bench.py --workload cfg2 --accum $a $Q --no-alt > gpurun_out/$R/bench_cfg2_n1_$a.json 2>/dev/null
+  python bench.py --workload cfg3 --accum $a $Q --no-alt > gpurun_out/$R/bench_cfg3_n1_$a.json 2>/dev/null
 done
+for wl in cfg4shard cfg5shard; do python bench.py --workload $wl $Q > gpurun_out/$R/bench_${wl}_n1.json 2>/dev/null; done
+python bench.py --workload cfg5shard --accum fp32 $Q --no-alt > gpurun_out/$R/bench_cfg5shard_n1_fp32.json 2>/dev/null
 for a in i8 fp64; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg2_$a -o bench -- python bench.py --accum $a --no-cpu-baseline --no-alt > /dev/null 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg3_$a -o bench -- python bench.py --workload cfg3 --accum $a --no-cpu-baseline --no-alt > /dev/null 2>&1
+  # kernel trace of the driver's command line itself for the default mode (same flags), of --accum fp64 for the other
+  if [ $a = i8 ]; then X=""; else X="--accum fp64 $Q --no-alt"; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg3_$a -o bench -- python bench.py $X > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg2_$a -o bench -- python bench.py --workload cfg2 --accum $a $Q --no-alt > /dev/null 2>&1
   for wl in cfg2 cfg3; do
     st=3; [ $wl = cfg3 ] && st=2
     for kind in fetch write sq; do
@@ -25,10 +31,13 @@ for a in i8 fp64; do
     done
   done
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg4shard_i8 -o bench -- python bench.py --workload cfg4shard $Q --no-alt > /dev/null 2>&1
 python scripts/summarise_pmc.py gpurun_out/$R _fp64 > gpurun_out/$R/pmc_summary.json
 python scripts/summarise_pmc.py gpurun_out/$R _i8 > gpurun_out/$R/pmc_summary_i8.json
 python scripts/mfma_i8_peak.py > gpurun_out/$R/mfma_i8_microbench.txt 2>&1
 python scripts/mfma_peak.py > gpurun_out/$R/mfma_f64_microbench.txt 2>&1
-[ -x flashpca_amd/_build/mx_probe ] && timeout 300 flashpca_amd/_build/mx_probe > gpurun_out/$R/mx_fp4_fp6_probe.txt 2>&1
-python bench.py --workload cfg5 --no-cpu-baseline > gpurun_out/$R/bench_cfg5_n1.json 2>/dev/null
-cat gpurun_out/$R/pmc_summary_i8.json | head -60; cat gpurun_out/$R/bench_cfg2_n1.json
+python bench.py --workload cfg5 $Q > gpurun_out/$R/bench_cfg5_n1.json 2>/dev/null
+bash scripts/power_sample.sh i8 > gpurun_out/$R/power_sample.txt 2>&1
+# slim the raw traces before they travel back (the stats CSVs are what profiles/ keeps)
+find gpurun_out/$R -name "*kernel_trace.csv" -size +2M -delete; find gpurun_out/$R -name "*counter_collection.csv" -size +8M -delete
+cat gpurun_out/$R/pmc_summary_i8.json | head -70; tail -c 1500 gpurun_out/$R/bench_cfg3_n1.json
