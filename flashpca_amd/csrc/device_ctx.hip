@@ -125,6 +125,7 @@ struct fpca_ctx {
    double *d_inv_sd = nullptr, *d_mu_inv_sd = nullptr, *d_i8w = nullptr;
    int8_t *d_Qb = nullptr, *d_Qg = nullptr, *d_Qm = nullptr;
    int i8_nsc = 0; // rows currently allocated (and zero-padded) in the Q buffers
+   int i8_pad_zeroed_for = -1; // S*b for which rows [S*b, i8_nsc) of the Q buffers are known to be zero
    double *d_i8ws = nullptr;
    size_t i8ws_cap = 0;
    bool i8_scales_done = false, i8_transposed = false;
@@ -333,6 +334,7 @@ bool ensure_i8(fpca_ctx *c, int b)
          }
       c->i8_transposed = false;
       c->i8_nsc = 0;
+      c->i8_pad_zeroed_for = -1;
       c->i8ws_cap = 0;
       c->i8_S = 0;
       c->accum = FPCA_ACCUM_FP64;
@@ -371,9 +373,12 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
       HIP_ALLOC(hipMalloc(&c->d_Qg, (size_t)nsc * c->P_pad));
       HIP_ALLOC(hipMalloc(&c->d_Qm, (size_t)nsc * c->P_pad));
       c->i8_nsc = nsc;
+      c->i8_pad_zeroed_for = -1;
    }
-   // rows >= S*b of the Q operands must be zero (they are multiplied like any other column)
-   if (nsc != c->i8_S * b) {
+   // rows >= S*b of the Q operands must be zero (they are multiplied like any other column); the slicing kernels never
+   // write them, so once per (allocation, S*b) is enough -- this runs at the top of every apply
+   if (nsc != c->i8_S * b && c->i8_pad_zeroed_for != c->i8_S * b) {
+      c->i8_pad_zeroed_for = c->i8_S * b;
       const size_t used = (size_t)c->i8_S * b;
       HIP_CHECK(hipMemsetAsync(c->d_Qb + used * c->N_pad, 0, (nsc - used) * c->N_pad, s));
       HIP_CHECK(hipMemsetAsync(c->d_Qg + used * c->P_pad, 0, (nsc - used) * c->P_pad, s));

@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -49,15 +50,15 @@ inline void matmul(int m, int n, int k, const double *A, int lda, const double *
    }
 }
 
-// Orthonormalise the columns of backend block w in place: W_in = W_out * R (R b x b, column-major, general).
-// Column-scaled eigen-orthonormalisation of the Gram matrix (robust to residual columns of very different
-// norms, which a plain Cholesky QR is not).  Directions whose scaled Gram eigenvalue is below the noise
-// floor are zeroed (returned count); their rows of R are zero.
-int svqb_pass(BlockBackend &be, int w, double zero_scale, std::vector<double> &R, std::vector<unsigned char> &dead_col)
+// Host part of the column-scaled eigen-orthonormalisation (SVQB) of a block with Gram matrix G (b x b, row-major ==
+// symmetric): W_in = W_out R, W_out = W_in M.  M row-major [p][c] (the layout BlockBackend::gemm takes), R column-major.
+// Robust to residual columns of very different norms, which a plain Cholesky QR is not.  Directions whose scaled Gram
+// eigenvalue is below the noise floor are zeroed (returned count, dead_col); their rows of R are zero.
+int svqb_factor(int b, std::vector<double> &G, double zero_scale, std::vector<double> &M, std::vector<double> &R,
+                std::vector<unsigned char> &dead_col)
 {
-   const int b = be.width();
-   std::vector<double> G((size_t)b * b), Gs((size_t)b * b), lam(b), d(b), M((size_t)b * b, 0.0);
-   be.gram(&w, 1, w, G.data()); // G[p][c] row-major == symmetric
+   std::vector<double> Gs((size_t)b * b), lam(b), d(b);
+   M.assign((size_t)b * b, 0.0);
    for (int i = 0; i < b; i++)
       for (int j = 0; j < i; j++) {
          const double a = 0.5 * (G[(size_t)i * b + j] + G[(size_t)j * b + i]);
@@ -76,12 +77,31 @@ int svqb_pass(BlockBackend &be, int w, double zero_scale, std::vector<double> &R
    for (int i = 0; i < b; i++)
       for (int j = 0; j < b; j++)
          Gs[(size_t)i + (size_t)j * b] = (zero_in[i] || zero_in[j]) ? 0.0 : G[(size_t)i * b + j] / (d[i] * d[j]);
+   R.assign((size_t)b * b, 0.0);
+   dead_col.assign(b, 0);
+   // Well-conditioned blocks -- every second normalisation, most first ones -- take the Cholesky factor of the scaled Gram
+   // matrix (b^3/3 flops against ~6 b^3 for the eigen-decomposition, which at b = 32 was a tenth of a millisecond twice per
+   // step): Gs = U'U, W_in = W_out (U D), M = D^-1 U^-1.  Accepted only when every pivot stays above 1e-4 (unit
+   // diagonal: condition number below ~1e8, so W_out is orthonormal to ~1e-8 x eps-level and the next pass finishes the
+   // job); anything less clear-cut -- nearly dependent or vanished columns -- goes the eigen route below.
+   bool any_zero = false;
+   for (int i = 0; i < b; i++) any_zero = any_zero || zero_in[i];
+   if (!any_zero) {
+      std::vector<double> U(Gs), Ui((size_t)b * b);
+      if (cholesky_upper(b, U.data(), b, 1e-4) == 0) {
+         upper_inverse(b, U.data(), b, Ui.data(), b);
+         for (int p = 0; p < b; p++)
+            for (int c = 0; c < b; c++) {
+               M[(size_t)p * b + c] = Ui[(size_t)p + (size_t)c * b] / d[p];   // (D^-1 U^-1)[p][c]
+               R[(size_t)p + (size_t)c * b] = U[(size_t)p + (size_t)c * b] * d[c]; // (U D)(p, c), column-major
+            }
+         return 0;
+      }
+   }
    if (symeig_desc(b, Gs.data(), b, lam.data()) != 0) throw Error(-3, "svqb: small eigensolver failed");
    const double floor_rel = 64.0 * b * DBL_EPSILON;
    const double lmax = std::max(lam[0], 0.0);
    int ndead = 0;
-   R.assign((size_t)b * b, 0.0);
-   dead_col.assign(b, 0);
    // new column j of W = sum_p W[:, p] * M[p][j],  M = D^-1 Z Lambda^-1/2 ; R = Lambda^1/2 Z' D
    for (int j = 0; j < b; j++) {
       if (!(lam[j] > floor_rel * lmax) || lmax == 0.0) {
@@ -96,6 +116,16 @@ int svqb_pass(BlockBackend &be, int w, double zero_scale, std::vector<double> &R
          R[(size_t)j + (size_t)p * b] = zero_in[p] ? 0.0 : sq * z * d[p]; // column-major R(j, p)
       }
    }
+   return ndead;
+}
+
+// Orthonormalise the columns of backend block w in place: W_in = W_out * R (one Gram pass + one update pass).
+int svqb_pass(BlockBackend &be, int w, double zero_scale, std::vector<double> &R, std::vector<unsigned char> &dead_col)
+{
+   const int b = be.width();
+   std::vector<double> G((size_t)b * b), M;
+   be.gram(&w, 1, w, G.data()); // G[p][c] row-major == symmetric
+   const int ndead = svqb_factor(b, G, zero_scale, M, R, dead_col);
    be.gemm(&w, 1, M.data(), -1, w);
    return ndead;
 }
@@ -178,10 +208,22 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
 
    SolverResult res;
    double host_s = 0;
+   // FPCA_TIMING=1: wall-clock per phase of the iteration (host view: each phase ends at its own synchronisation point)
+   const bool timing = std::getenv("FPCA_TIMING") != nullptr;
+   enum { PH_APPLY, PH_PROJ, PH_SVQB, PH_RR, PH_RESTART, PH_N };
+   double ph[PH_N] = {0, 0, 0, 0, 0};
+   auto tph = clk::now();
+   auto phase = [&](int which) {
+      if (!timing) return;
+      const auto now = clk::now();
+      ph[which] += std::chrono::duration<double>(now - tph).count();
+      tph = now;
+   };
    std::vector<int> V;
    std::vector<double> T((size_t)nmax * nmax, 0.0), Tw((size_t)nmax * nmax), theta(nmax);
-   std::vector<double> H((size_t)nmax * b), C((size_t)nmax * b), negC((size_t)nmax * b);
-   std::vector<double> R1, R2, R3, R((size_t)b * b), tmp((size_t)b * b);
+   std::vector<double> H((size_t)nmax * b), C((size_t)(nmax + b) * b), negC((size_t)(nmax + b) * b);
+   std::vector<double> R1, R2, R3, R((size_t)b * b), tmp((size_t)b * b), M1, M2, Gw;
+   std::vector<int> VW;
    std::vector<unsigned char> dead, dead2;
    auto Tat = [&](int i, int j) -> double & { return T[(size_t)i + (size_t)j * nmax]; };
 
@@ -207,6 +249,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    V.push_back(v0);
    int W = be.alloc_block();
    double scale = 0; // running estimate of ||A|| (largest Ritz value)
+   TridiagKeep keep;            // Householder reduction of the last Rayleigh-Ritz matrix
    std::vector<double> S, Srow; // eigenvectors of T (n x n, ld n; only when needed) / their last b rows (b x n)
    int n = 0;
    uint64_t reseed = o.seed * 7919 + 13;
@@ -214,41 +257,91 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
 
    while (res.block_applies < o.max_applies) {
       const int m = (int)V.size();
+      phase(PH_RESTART);
       be.apply(V[m - 1], W);
+      phase(PH_APPLY);
       res.block_applies++;
-      std::fill(H.begin(), H.begin() + (size_t)m * b * b, 0.0);
-      project_out(W, true);
-      project_out(W, true);
+      // Three passes over (basis, W), each ONE Gram launch -- C = V'W and G = W'W together, the block itself riding along
+      // as the last "basis" block -- and ONE update launch:
+      //   1  W <- W - V C1
+      //   2  W <- (W - V C2) M1      M1 from the Gram matrix of W - V C2, which is G - C2'C2 (V is orthonormal; C2 is the
+      //   3  W <- (W - V C3) M2      small second-pass correction, so nothing cancels) -- column-scaled eigen-
+      //                              orthonormalisation, W_before = W_after R
+      // i.e. classical Gram-Schmidt twice, normalisation, a third projection (the normalisation may have amplified
+      // components along V) and a second normalisation: what used to be five Gram + five update launches, each Gram a
+      // round trip to the host.  H = V'AV column = C1 + C2 + C3 R1.
+      VW.assign(V.begin(), V.end());
+      VW.push_back(W);
+      const size_t cnt = (size_t)m * b * b;
+      auto gram_vw = [&]() { // C[0 .. m b b) = V'W, Gw = W'W
+         be.gram(VW.data(), m + 1, W, C.data());
+         Gw.assign(C.begin() + (long)cnt, C.begin() + (long)(cnt + (size_t)b * b));
+      };
+      auto minus_ctc = [&]() { // Gw -= C'C  (C: [q][p][c])
+         for (size_t qp = 0; qp < (size_t)m * b; qp++) {
+            const double *row = &C[qp * b];
+            for (int c1 = 0; c1 < b; c1++) {
+               const double x = row[c1];
+               if (x == 0.0) continue;
+               for (int c2 = 0; c2 < b; c2++) Gw[(size_t)c1 * b + c2] -= x * row[c2];
+            }
+         }
+      };
+      auto update_with = [&](const std::vector<double> &M) { // W <- (W - V C) M : coefficients [-C_q M ; M]
+         for (size_t qp = 0; qp < (size_t)m * b; qp++) {
+            const double *row = &C[qp * b];
+            double *out = &negC[qp * b];
+            for (int c = 0; c < b; c++) out[c] = 0.0;
+            for (int j = 0; j < b; j++) {
+               const double x = -row[j];
+               if (x == 0.0) continue;
+               const double *mj = &M[(size_t)j * b];
+               for (int c = 0; c < b; c++) out[c] += x * mj[c];
+            }
+         }
+         std::copy(M.begin(), M.end(), negC.begin() + (long)cnt);
+         be.gemm(VW.data(), m + 1, negC.data(), -1, W);
+      };
+      std::fill(H.begin(), H.begin() + (long)cnt, 0.0);
+      gram_vw();
+      for (size_t i = 0; i < cnt; i++) {
+         negC[i] = -C[i];
+         H[i] += C[i];
+      }
+      be.gemm(V.data(), m, negC.data(), W, W);
+      phase(PH_PROJ);
 
-      // ---- orthonormalise the residual block: W = Q R --------------------------------------------
+      gram_vw();
       auto t0 = clk::now();
       if (scale == 0) {
          // first step: ||A|| estimate from the diagonal block H_00 (Rayleigh quotients)
          for (int i = 0; i < b; i++) scale = std::max(scale, std::fabs(H[(size_t)i * b + i]));
       }
-      host_s += since(t0);
+      for (size_t i = 0; i < cnt; i++) H[i] += C[i];
+      minus_ctc();
       const double zero_scale = scale * 16 * DBL_EPSILON * std::sqrt((double)N);
-      int ndead = svqb_pass(be, W, zero_scale, R1, dead);
-      // third projection (the normalisation may have amplified components along V), folded into H
-      {
-         be.gram(V.data(), m, W, C.data());
-         const size_t cnt = (size_t)m * b * b;
-         for (size_t i = 0; i < cnt; i++) negC[i] = -C[i];
-         be.gemm(V.data(), m, negC.data(), W, W);
-         // H += C * R1   (C: [q][p][c] row-major b x b per q; R1 column-major)
-         t0 = clk::now();
-         for (int q = 0; q < m; q++)
-            for (int p = 0; p < b; p++)
-               for (int c = 0; c < b; c++) {
-                  double s = 0;
-                  const double *cr = &C[((size_t)q * b + p) * b];
-                  for (int j = 0; j < b; j++) s += cr[j] * R1[(size_t)j + (size_t)c * b];
-                  H[((size_t)q * b + p) * b + c] += s;
-               }
-         host_s += since(t0);
-      }
-      ndead = std::max(ndead, 0);
-      int nd2 = svqb_pass(be, W, 0.0, R2, dead2);
+      int ndead = svqb_factor(b, Gw, zero_scale, M1, R1, dead);
+      host_s += since(t0);
+      update_with(M1);
+      phase(PH_SVQB);
+
+      gram_vw();
+      t0 = clk::now();
+      // H += C3 * R1   (C: [q][p][c] row-major b x b per q; R1 column-major)
+      for (int q = 0; q < m; q++)
+         for (int p = 0; p < b; p++) {
+            const double *cr = &C[((size_t)q * b + p) * b];
+            for (int c = 0; c < b; c++) {
+               double sacc = 0;
+               for (int j = 0; j < b; j++) sacc += cr[j] * R1[(size_t)j + (size_t)c * b];
+               H[((size_t)q * b + p) * b + c] += sacc;
+            }
+         }
+      minus_ctc();
+      int nd2 = svqb_factor(b, Gw, 0.0, M2, R2, dead2);
+      host_s += since(t0);
+      update_with(M2);
+      phase(PH_SVQB);
       // R = R2 * R1
       matmul(b, b, b, R2.data(), b, R1.data(), b, R.data(), b);
       // columns that died in either pass carry no information from A V: refill them with fresh random
@@ -298,6 +391,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       }
 
       // ---- projected matrix and Rayleigh-Ritz ------------------------------------------------------
+      phase(PH_RESTART);
       t0 = clk::now();
       n = m * b;
       for (int q = 0; q < m; q++)
@@ -320,6 +414,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       if (skip_rr > 0 && res.block_applies < o.max_applies && m + 1 <= mcap) {
          skip_rr--;
          host_s += since(t0);
+         phase(PH_RR);
          V.push_back(W);
          W = be.alloc_block();
          continue;
@@ -329,7 +424,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       // eigenvalues + the last block of rows of the eigenvectors (all the residual test needs); the full
       // eigenvector matrix is formed only when it is used: convergence, thick restart, last step
       Srow.resize((size_t)b * n);
-      if (symeig_desc_rows(n, Tw.data(), n, theta.data(), (m - 1) * b, b, Srow.data()) != 0)
+      if (symeig_desc_rows(n, Tw.data(), n, theta.data(), (m - 1) * b, b, Srow.data(), &keep) != 0)
          throw Error(-3, "solver: projected eigensolver failed");
       scale = std::max(scale, std::fabs(theta[0]));
       // residual estimates: || R * S[(m-1)b : mb, i] ||
@@ -356,11 +451,9 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          // eigenvectors are needed now, but only the leading 2 b of them (Ritz vectors kept by a restart / returned):
          // selected columns by inverse iteration, verified inside; the full QL decomposition is the fallback
          const int need = std::min(n, std::max(2, nk_wide) * b);
-         std::vector<double> th(n);
          S.assign((size_t)n * need, 0.0);
-         for (int j = 0; j < n; j++) std::memcpy(&Tw[(size_t)j * n], &T[(size_t)j * nmax], sizeof(double) * n);
-         if (n > need + b && symeig_desc_cols(n, Tw.data(), n, th.data(), need, S.data()) == 0) {
-            std::copy(th.begin(), th.end(), theta.begin());
+         // (from the reduction the residual test has just made: no second O(n^3) pass)
+         if (n > need + b && keep.n == n && symeig_cols_from_keep(keep, theta.data(), need, S.data()) == 0) {
          } else {
             for (int j = 0; j < n; j++) std::memcpy(&Tw[(size_t)j * n], &T[(size_t)j * nmax], sizeof(double) * n);
             if (symeig_desc(n, Tw.data(), n, theta.data()) != 0) throw Error(-3, "solver: projected eigensolver failed");
@@ -368,6 +461,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          }
       }
       host_s += since(t0);
+      phase(PH_RR);
       if (o.verbose)
          std::fprintf(stderr, "[fpca] apply %3d  basis %4d  theta1 %.6g  theta_k %.6g  max rel resid %.3e\n",
                       res.block_applies, n, theta[0], theta[k - 1], worst);
@@ -434,6 +528,10 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    for (int h : V) be.free_block(h);
    be.free_block(W);
    res.seconds_host = host_s;
+   phase(PH_RESTART);
+   if (timing)
+      std::fprintf(stderr, "[fpca] solver phases (ms): apply %.3f  projections %.3f  orthonormalisation %.3f  Rayleigh-Ritz %.3f  restart/Ritz vectors/other %.3f\n",
+                   ph[PH_APPLY] * 1e3, ph[PH_PROJ] * 1e3, ph[PH_SVQB] * 1e3, ph[PH_RR] * 1e3, ph[PH_RESTART] * 1e3);
    return res;
 }
 

@@ -16,8 +16,8 @@ namespace {
 
 // A = Q T Q', T tridiagonal (d, e).  On return A holds Q (column-major).
 // With rows != nullptr Q is not formed: rows (nrows x n, ld nrows) receives rows row0..row0+nrows-1 of Q instead.
-// With beta_out != nullptr neither Q nor rows are formed: the reflectors stay below the sub-diagonal of A and their
-// coefficients are returned, for the caller to apply (symeig_desc_cols).
+// With beta_out != nullptr Q is not formed: the reflectors stay below the sub-diagonal of A and their coefficients are
+// returned, for the caller to apply (symeig_desc_cols); rows are still produced when asked for.
 // fixed-order vectorised dot product (4 lanes x 4 accumulators): the result does not depend on who computes it
 typedef double v4d __attribute__((vector_size(32)));
 inline double dot_fixed(const double *a, const double *b, int m)
@@ -95,7 +95,7 @@ void tridiagonalise(int n, double *A, int lda, double *d, double *e, int row0 = 
    d[n - 1] = AA(n - 1, n - 1);
    if (beta_out) {
       for (int k = 0; k < n; k++) beta_out[k] = beta[k];
-      return;
+      if (!rows) return;
    }
    if (rows) {
       // e_r' Q = e_r' H_0 H_1 ... H_{n-3}: the reflectors applied to unit rows, front to back
@@ -240,8 +240,9 @@ int symeig_desc(int n, double *A, int lda, double *w)
    return 0;
 }
 
-int symeig_desc_rows(int n, double *A, int lda, double *w, int row0, int nrows, double *Zr)
+int symeig_desc_rows(int n, double *A, int lda, double *w, int row0, int nrows, double *Zr, TridiagKeep *keep)
 {
+   if (keep) keep->n = 0;
    if (n <= 0) return 0;
    if (n == 1) {
       w[0] = A[0];
@@ -249,7 +250,18 @@ int symeig_desc_rows(int n, double *A, int lda, double *w, int row0, int nrows, 
       return 0;
    }
    std::vector<double> d(n), e(n, 0.0), rows((size_t)nrows * n);
-   tridiagonalise(n, A, lda, d.data(), e.data(), row0, nrows, rows.data());
+   if (keep && n > 2) { // the reduction is kept for symeig_cols_from_keep: original matrix, reflectors, tridiagonal form
+      keep->A0.resize((size_t)n * n);
+      for (int j = 0; j < n; j++) std::memcpy(&keep->A0[(size_t)j * n], A + (size_t)j * lda, sizeof(double) * n);
+      keep->beta.assign(n, 0.0);
+      tridiagonalise(n, A, lda, d.data(), e.data(), row0, nrows, rows.data(), keep->beta.data());
+      keep->A.resize((size_t)n * n);
+      for (int j = 0; j < n; j++) std::memcpy(&keep->A[(size_t)j * n], A + (size_t)j * lda, sizeof(double) * n);
+      keep->d = d;
+      keep->e = e;
+      keep->n = n;
+   } else
+      tridiagonalise(n, A, lda, d.data(), e.data(), row0, nrows, rows.data());
    int rc = tridiag_ql(n, d.data(), e.data(), rows.data(), nrows, nrows);
    if (rc) return rc;
    std::vector<int> idx(n);
@@ -267,6 +279,11 @@ int symeig_desc_rows(int n, double *A, int lda, double *w, int row0, int nrows, 
 // against the already computed neighbours of a cluster, as LAPACK's dstein does), back-transformation through the
 // Householder reflectors.  O(4/3 n^3 + n^2 ncols) instead of O(6 n^3).  The result is VERIFIED -- residual
 // ||A z - lambda z|| and orthonormality -- and a nonzero return tells the caller to use symeig_desc instead.
+namespace {
+int cols_core(int n, const double *A, int lda, const std::vector<double> &d, const std::vector<double> &e, const std::vector<double> &beta,
+              const std::vector<double> &A0, const double *w, int ncols, double *Z);
+}
+
 int symeig_desc_cols(int n, double *A, int lda, double *w, int ncols, double *Z)
 {
    if (n <= 2 || ncols <= 0 || ncols > n) return 1;
@@ -279,6 +296,21 @@ int symeig_desc_cols(int n, double *A, int lda, double *w, int ncols, double *Z)
    if (tridiag_ql(n, dq.data(), eq.data(), nullptr, 0, 0) != 0) return 2;
    std::sort(dq.begin(), dq.end(), [](double a, double b) { return a > b; });
    for (int j = 0; j < n; j++) w[j] = dq[j];
+   return cols_core(n, A, lda, d, e, beta, A0, w, ncols, Z);
+}
+
+// the same from a reduction symeig_desc_rows has already made (its eigenvalues w, descending): no second O(n^3) pass
+int symeig_cols_from_keep(const TridiagKeep &keep, const double *w, int ncols, double *Z)
+{
+   const int n = keep.n;
+   if (n <= 2 || ncols <= 0 || ncols > n) return 1;
+   return cols_core(n, keep.A.data(), n, keep.d, keep.e, keep.beta, keep.A0, w, ncols, Z);
+}
+
+namespace {
+int cols_core(int n, const double *A, int lda, const std::vector<double> &d, const std::vector<double> &e, const std::vector<double> &beta,
+              const std::vector<double> &A0, const double *w, int ncols, double *Z)
+{
    double tnorm = 0;
    for (int i = 0; i < n; i++) tnorm = std::max(tnorm, std::fabs(d[i]) + (i ? std::fabs(e[i - 1]) : 0.0) + (i < n - 1 ? std::fabs(e[i]) : 0.0));
    if (!(tnorm > 0.0) || !std::isfinite(tnorm)) return 3;
@@ -403,6 +435,7 @@ int symeig_desc_cols(int n, double *A, int lda, double *w, int ncols, double *Z)
    for (int c = 0; c < ncols; c++) std::memcpy(Z + (size_t)c * n, &y[(size_t)c * n], sizeof(double) * n);
    return 0;
 }
+} // namespace
 
 int cholesky_upper(int n, double *G, int ld, double rel_tol)
 {

@@ -14,7 +14,16 @@ int symeig_desc(int n, double *A, int lda, double *w);
 // Same eigenvalues, but only rows row0..row0+nrows-1 of the eigenvector matrix: Zr (nrows x n, ld nrows), column j
 // belonging to w[j].  A is destroyed.  O(4/3 n^3) instead of O(6 n^3): the Krylov residual test needs only the last
 // block of rows.
-int symeig_desc_rows(int n, double *A, int lda, double *w, int row0, int nrows, double *Zr);
+// With keep != nullptr the Householder reduction (original matrix, reflectors, tridiagonal form) is left in *keep, from
+// which symeig_cols_from_keep forms leading eigenvectors later without a second reduction.
+struct TridiagKeep {
+   int n = 0;
+   std::vector<double> A0, A, beta, d, e;
+};
+int symeig_desc_rows(int n, double *A, int lda, double *w, int row0, int nrows, double *Zr, TridiagKeep *keep = nullptr);
+// First ncols eigenvectors (Z: n x ncols, ld n) of the matrix last reduced into keep; w = its eigenvalues (descending) as
+// symeig_desc_rows returned them.  Verified like symeig_desc_cols; nonzero = "use symeig_desc".
+int symeig_cols_from_keep(const TridiagKeep &keep, const double *w, int ncols, double *Z);
 
 // Eigenvalues (all, descending) and only the first ncols eigenvectors (Z: n x ncols, ld n).  A is destroyed.  The vectors
 // are verified (residual, orthonormality); a nonzero return means "use symeig_desc" -- w is then unspecified.
