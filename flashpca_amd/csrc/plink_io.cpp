@@ -55,7 +55,9 @@ void split_ws(const std::string &s, std::vector<Token> &tok)
    }
 }
 // strtod / strtol over a token: the character after it is whitespace or the string's terminating NUL, so the C parsers
-// stop there by themselves; "fully parsed" = they stopped exactly at the token's end
+// stop there by themselves; "fully parsed" = they stopped exactly at the token's end.  This IS the reference's rule
+// (data.cpp:571-579: strtod, then `*err != '\0' || errno != 0` is an error) -- so "nan" / "inf" / hex floats are accepted
+// and a subnormal that raises ERANGE is rejected there as here; operator>>(double) is not what the reference uses.
 inline bool parse_double(const Token &t, double &v)
 {
    char *end = nullptr;
