@@ -289,7 +289,10 @@ enum { I8_FULL = 0, I8_SKIP_EMPTY = 1, I8_NO_MISSING = 2 };
 
 // ABL (builds with -DFPCA_I8_ABLATION only; results are wrong by construction): bit 0 drops the operand staging of the
 // main loop, bit 1 the genotype decode, bit 2 the LDS fragment reads, bit 3 the packed-word loads -- what each costs
-// (scripts/i8_ablation.py)
+// (scripts/i8_ablation.py); bits 4 / 5 keep every instruction but make the operand stream / the packed words L2-resident
+// (4 chunks re-read): what their misses cost.  Round 2: operand stream 8.68 -> 8.71 ms (nothing), packed words 8.68 ->
+// 8.22 ms -- and that is their HBM energy, not their latency: a variant that issued the packed words 1.5-2.5 chunks ahead
+// instead of half a chunk (chunks in straight-line pairs, four register sets) ran 9.20 ms against 8.70 on the same box.
 template <bool TWO_, int MT_, int NT_, int WR_, int WC_, int KC_, int G_, int MODE_ = I8_FULL, int ABL_ = 0>
 struct I8Cfg {
    static constexpr bool TWO = TWO_;
@@ -399,11 +402,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
 
    auto issue_q = [&](auto rr, int cc) {
       constexpr int r = decltype(rr)::value, o = r / NP1, r1 = r % NP1;
-      const int8_t *sb = ((TWO && o) ? Qm : Qg) + (uint64_t)(col0 + C::RSTEP * r1) * k_pad + (uint64_t)cc * KC;
+      const int ccq = (C::ABL & 16) ? (cc & 3) : cc; // ablation: the operand stream stays L2-resident (4 chunks, re-read)
+      const int8_t *sb = ((TWO && o) ? Qm : Qg) + (uint64_t)(col0 + C::RSTEP * r1) * k_pad + (uint64_t)ccq * KC;
       qreg[r] = gload16<0>(sb, qvoff);
    };
    auto issue_p = [&](u4(&dst)[MT][PW], int cc) {
-      const uint8_t *pb = prow + (size_t)cc * (KC / 4);
+      const uint8_t *pb = prow + (size_t)((C::ABL & 32) ? (cc & 3) : cc) * (KC / 4); // ablation: packed words L2-resident
 #pragma unroll
       for (int m = 0; m < MT; m++) {
          dst[m][0] = gload16<0>(pb, pvoff[m]);
@@ -828,6 +832,9 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
          case 8: FPCA_I8_AB(8); break;
          case 9: FPCA_I8_AB(9); break;
          case 6: FPCA_I8_AB(6); break;
+         case 16: FPCA_I8_AB(16); break;
+         case 32: FPCA_I8_AB(32); break;
+         case 48: FPCA_I8_AB(48); break;
          default: FPCA_I8_AB(15); break;
          }
       } else

@@ -102,3 +102,96 @@ def test_gemm_kernels_do_not_spill():
             hot = [(n, int(s)) for n, s in zip(names, spills) if re.search(pat, n)]
             assert hot, src
             assert all(s == 0 for _, s in hot), [(n, s) for n, s in hot if s]
+
+
+def _inflight_hazards(body):
+    """Follow one kernel's assembly along EVERY control-flow path (both ways at a conditional branch; a state = program
+    counter + the loads in flight, each visited once) and report every instruction that reads or writes a VGPR while a
+    global load into it is still outstanding according to the s_waitcnt vmcnt(N) sequence (loads return in issue order)."""
+    import re
+
+    def regs(tok):
+        out = set()
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+            if m.group(1):
+                out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            else:
+                out.add(int(m.group(3)))
+        return frozenset(out)
+
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"\s*(\.LBB\w+):", l)] if m}
+    ins = []  # (kind, payload) per line
+    for l in body:
+        t = l.strip()
+        if not t or t[0] in ";." or re.match(r"\.?\w+:", t):
+            ins.append(None)
+            continue
+        op = t.split()[0]
+        args = t[len(op):]
+        if op.startswith("global_load"):
+            ins.append(("load", regs(args.split(",")[0])))
+        elif op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", t)
+            ins.append(("wait", int(m.group(1))) if m else None)
+        elif op == "s_branch":
+            ins.append(("jump", labels[args.split()[0]]))
+        elif op.startswith("s_cbranch"):
+            ins.append(("cjump", labels[args.split()[0]]))
+        elif op == "s_endpgm":
+            ins.append(("end", None))
+        else:
+            ins.append(("use", regs(args), t))
+    bad, seen, stack = {}, set(), [(0, ())]
+    while stack:
+        pc, fl = stack.pop()
+        while pc < len(ins):
+            key = (pc, tuple(ln for _, ln in fl))
+            if ins[pc] is not None and ins[pc][0] in ("cjump", "jump", "load"):
+                if key in seen:
+                    break
+                seen.add(key)
+            x = ins[pc]
+            if x is None:
+                pc += 1
+                continue
+            if x[0] == "load":
+                fl = fl + ((x[1], pc),)
+            elif x[0] == "wait":
+                fl = fl[max(0, len(fl) - x[1]):]
+            elif x[0] == "jump":
+                pc = x[1]
+                continue
+            elif x[0] == "cjump":
+                stack.append((x[1], fl))
+            elif x[0] == "end":
+                break
+            else:
+                for dst, ln in fl:
+                    if x[1] & dst:
+                        bad[(pc, ln)] = (pc, x[2], ln)
+            pc += 1
+    return sorted(bad.values())
+
+
+def test_int8_gemm_never_touches_a_register_with_a_load_in_flight():
+    """The int8 GEMM issues its global loads by inline asm and waits for them much later with hand-counted s_waitcnt: the
+    compiler does not know a destination register is 'in flight' and is free to copy or reuse it (it did, once, when an
+    in-flight value was carried around the loop: every parity test on the shapes of the day stayed green while another
+    template instance produced noise).  This checks the generated code of EVERY instance: main loop in one straight-line
+    block, nothing in flight across its back-edge, and no instruction touching a VGPR before its load has been waited for."""
+    import re
+    import subprocess
+    import tempfile
+
+    csrc = os.path.join(ROOT, "flashpca_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                               os.path.join(csrc, "kernels_i8.hip"), "-o", out], stderr=subprocess.DEVNULL)
+        src = open(out).read().split("\n")
+    starts = [i for i, l in enumerate(src) if re.match(r"_ZN4fpca4kern9k_gemm_i8\S*:", l)]
+    assert len(starts) >= 15
+    for st in starts:
+        end = next(i for i in range(st, len(src)) if src[i].startswith(".Lfunc_end"))
+        bad = _inflight_hazards(src[st:end])
+        assert not bad, (src[st][:90], bad[:5])
