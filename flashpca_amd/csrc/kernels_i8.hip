@@ -293,6 +293,9 @@ enum { I8_FULL = 0, I8_SKIP_EMPTY = 1, I8_NO_MISSING = 2 };
 // (4 chunks re-read): what their misses cost.  Round 2: operand stream 8.68 -> 8.71 ms (nothing), packed words 8.68 ->
 // 8.22 ms -- and that is their HBM energy, not their latency: a variant that issued the packed words 1.5-2.5 chunks ahead
 // instead of half a chunk (chunks in straight-line pairs, four register sets) ran 9.20 ms against 8.70 on the same box.
+// Bit 6 drops the per-chunk barrier: 8.77 -> 8.82 ms, i.e. the barrier and the pipeline refill behind it cost nothing.
+// With an all-zero fp64 operand (same instructions, same traffic; scripts/i8_power_probe.py) the same launch takes 7.07 ms
+// instead of 9.04: the kernel follows the bare MFMA stream's power curve (3470 -> 4540 TOP/s) -- it is energy, not time.
 template <bool TWO_, int MT_, int NT_, int WR_, int WC_, int KC_, int G_, int MODE_ = I8_FULL, int ABL_ = 0>
 struct I8Cfg {
    static constexpr bool TWO = TWO_;
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
                pk[m][h] = pkn[m][h];
             }
       }
-      __syncthreads();
+      if constexpr (!(C::ABL & 64)) __syncthreads(); // (ablation bit 6: what the per-chunk barrier + pipeline refill costs)
    }
 
    // epilogue: the slices are recombined here, per split and column block, into fp64 partial sums -- virtual column
@@ -835,6 +838,8 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
          case 16: FPCA_I8_AB(16); break;
          case 32: FPCA_I8_AB(32); break;
          case 48: FPCA_I8_AB(48); break;
+         case 64: FPCA_I8_AB(64); break;
+         case 112: FPCA_I8_AB(112); break;
          default: FPCA_I8_AB(15); break;
          }
       } else

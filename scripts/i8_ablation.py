@@ -11,7 +11,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 names = {0: "full loop", 1: "- operand staging (global->LDS)", 2: "- genotype decode", 4: "- LDS fragment reads", 8: "- packed-word loads",
          9: "- staging - packed loads", 6: "- decode - LDS reads", 15: "MFMAs + barrier only",
-         16: "operand stream L2-resident", 32: "packed words L2-resident", 48: "both L2-resident"}
+         16: "operand stream L2-resident", 32: "packed words L2-resident", 48: "both L2-resident",
+         64: "no per-chunk barrier", 112: "no barrier, both streams L2-resident"}
 for ab in [int(a) for a in os.environ.get("ABLS", "0,1,2,4,8,9,6,15,16,32,48").split(",")]:
     env = dict(os.environ, FPCA_I8_ABL=str(ab))
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True)
