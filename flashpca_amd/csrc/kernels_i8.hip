@@ -1032,17 +1032,70 @@ __global__ __launch_bounds__(256) void k_sparse_rows_sum(const uint32_t *__restr
    }
 }
 
+// The same sum with the index list read in coalesced batches of 64 (one entry per lane, broadcast by shuffles) instead of
+// one dependent 4-byte load per gathered row: the loop above is a chain idx -> row of V, both at Infinity-Cache latency,
+// with four rows in flight per wave; here the rows of a batch are independent of any further index load and eight of them
+// are in flight (per lane slot).  The per-row factors of a batch are gathered once, one per lane, the same way.
+template <int B>
+__global__ __launch_bounds__(256) void k_sparse_rows_sum_batched(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
+                                                                  const double *__restrict__ V, const double *__restrict__ rowscale,
+                                                                  uint64_t nrec, uint64_t rows_out, double *__restrict__ out)
+{
+   constexpr int EPW = 64 / B, U = 8;
+   const int lane = threadIdx.x & 63, c = lane % B, e0 = lane / B;
+   for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows_out; r += (uint64_t)gridDim.x * 4) {
+      double acc[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) acc[u] = 0.0;
+      if (r < nrec) {
+         const uint32_t p0 = ptr[r], p1 = ptr[r + 1];
+         for (uint32_t t0 = p0; t0 < p1; t0 += 64) {
+            const int cnt = (int)(p1 - t0 < 64u ? p1 - t0 : 64u);
+            const uint32_t mine = lane < cnt ? idx[t0 + lane] : 0u;
+            const double myscale = (rowscale && lane < cnt) ? rowscale[mine] : 1.0;
+            for (int u0 = 0; u0 < cnt; u0 += EPW * U) {
+#pragma unroll
+               for (int u = 0; u < U; u++) {
+                  const int e = u0 + u * EPW + e0;
+                  const uint32_t srow = (uint32_t)__shfl((int)mine, e & 63);
+                  const double sc = __shfl(myscale, e & 63);
+                  if (e < cnt) acc[u] += V[(uint64_t)srow * B + c] * sc;
+               }
+            }
+         }
+      }
+      double a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+#pragma unroll
+      for (int o = 32; o >= B; o >>= 1) a += __shfl_down(a, o);
+      if (lane < B) out[r * B + c] = a;
+   }
+}
+
 void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, const double *rowscale, int b, uint64_t nrec,
                      uint64_t rows_out, double *out, hipStream_t stream)
 {
    if (!rows_out) return;
    const unsigned blocks = (unsigned)std::min<uint64_t>(65536, (rows_out + 3) / 4);
+   // measured (scripts/ab_gather.sh, cfg3): the batched kernel takes 0.3 ms off the K3 gather (short lists per sample, a row
+   // factor per entry), nothing off the K2 one and costs it 6-50 us at the small sizes -- so K3 (rowscale given) takes the
+   // batched kernel, K2 the plain one.  Both sit at ~7 TB/s out of the Infinity Cache; with the gathered matrix resident in
+   // L2 the same kernel reaches 9.4 TB/s (scripts/gather_l2_probe.py), which is all an L2-blocked gather order could win.
+   static const int forced = getenv("FPCA_GATHER") ? atoi(getenv("FPCA_GATHER")) : 0; // 1 / 2 force one kernel (A/B)
+   const int variant = forced ? forced : (rowscale ? 2 : 1);
+#define FPCA_GATHER_CASE(B_)                                                                                                    \
+   case B_:                                                                                                                     \
+      if (variant == 1)                                                                                                         \
+         hipLaunchKernelGGL(k_sparse_rows_sum<B_>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out); \
+      else                                                                                                                      \
+         hipLaunchKernelGGL(k_sparse_rows_sum_batched<B_>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out); \
+      break;
    switch (b) {
-   case 16: hipLaunchKernelGGL(k_sparse_rows_sum<16>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out); break;
-   case 32: hipLaunchKernelGGL(k_sparse_rows_sum<32>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out); break;
-   case 64: hipLaunchKernelGGL(k_sparse_rows_sum<64>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out); break;
+      FPCA_GATHER_CASE(16)
+      FPCA_GATHER_CASE(32)
+      FPCA_GATHER_CASE(64)
    default: throw Error(-1, "sparse_rows_sum: block width must be 16, 32 or 64");
    }
+#undef FPCA_GATHER_CASE
    HIP_CHECK_LAUNCH();
 }
 
