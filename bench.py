@@ -59,6 +59,39 @@ WARMUP = {"cfg2": 20, "tiny": 20, "cfg3": 5, "cfg5": 2, "cfg4shard": 10, "cfg5sh
 SPINUP = {"cfg2": 150, "tiny": 300, "cfg3": 4, "cfg5": 1, "cfg4shard": 20, "cfg5shard": 4}
 
 
+def measure_traffic(args, dom):
+    """bytes per launch of the dominant GEMM kernel from two rocprofv3 --pmc child runs (see main)."""
+    import collections
+    import csv
+    import glob
+    import subprocess
+    import tempfile
+
+    total = 0.0
+    for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):  # KiB; FETCH_SIZE counts 64 of every 128 B on gfx950
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__), "--workload", args.workload, "--accum", args.accum, "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-pca", "--no-alt", "--traffic", "none"]
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True,
+                           env={k: v for k, v in dict(os.environ, TMPDIR="/tmp").items() if k != "LD_PRELOAD"})
+            fs = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+            if not fs:
+                raise RuntimeError("rocprofv3 wrote no counter file")
+            rows = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Dispatch_Id"]))
+        if args.accum == "i8":  # one template serves K2 and K3: its launches alternate K2, K3, K2, ...
+            ids = [int(r["Dispatch_Id"]) for r in rows if "k_gemm_i8" in r["Kernel_Name"]]
+            want = {d for i, d in enumerate(sorted(set(ids))) if i % 2 == (0 if dom == "xt_b" else 1)}
+            vals = [float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) in want and r["Counter_Name"] == counter]
+        else:
+            key = "k_xt_b" if dom == "xt_b" else "k_x_t"
+            vals = [float(r["Counter_Value"]) for r in rows if key in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        if not vals:
+            raise RuntimeError("no launches of the dominant kernel in the counter file")
+        total += sum(vals) / len(vals) * scale
+    return total
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +108,10 @@ def main():
     ap.add_argument("--no-pca-hard", action="store_true", help="skip the second full PCA on a slowly converging spectrum (4 sub-populations)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra exact-int8-mode measurement of the same workload")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the bounded baseline sample")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "replay", "none"],
+                    help="roofline.traffic: measure = two extra rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of a 2-step run of the "
+                         "same workload as child processes after the timed region; replay = the committed passes under profiles/; "
+                         "auto = measure when rocprofv3 is there and this is a one-GPU run, else replay")
     args = ap.parse_args()
 
     # the host driver of these boxes only supports dmabuf IPC; RCCL across processes needs this (already exported there)
@@ -233,27 +270,44 @@ def main():
     roofline["hip_events_on_steps"] = "%d of %d (every %d%s step of the timed region)" % (prof["nsteps"], args.steps, stride, "th" if stride > 3 else "")
     if args.accum == "fp64":
         roofline["peak_measured_pure_mfma_stream"] = 74.3  # profiles/r01_mfma_f64_microbench.txt (2 waves/SIMD)
-    # HBM traffic per launch of the dominant kernel.  bench.py cannot read hardware counters inside its own timed run
-    # (rocprofv3 --pmc serialises the kernels and needs its own passes), so `traffic` is REPLAYED from the committed
-    # counter passes of this same workload and kernel (scripts/gpu_profile_round.sh: separate --pmc runs, FETCH_SIZE x 2
-    # (the gfx950 correction of the guide) + WRITE_SIZE); `traffic_source` names the file, null when there is none.
+    # HBM traffic per launch of the dominant kernel: hardware counters serialise the kernels, so they cannot be read inside
+    # the timed region.  `measure`: right after it, this process runs itself twice more under rocprofv3 --pmc (FETCH_SIZE,
+    # then WRITE_SIZE: separate passes, as the guide prescribes; 2 block applies each, nothing else) and reads the dominant
+    # kernel's counters per launch -- FETCH_SIZE x 2 (the gfx950 correction: it counts 64 of every 128 B) + WRITE_SIZE, KiB.
+    # `replay`: the committed passes of the same workload under profiles/.  `traffic_source` says which.
     roofline["algorithmic_bytes"] = float((N + 3) // 4) * P_rank + 8.0 * b * (N + P_rank)
     roofline["traffic_measured_in_this_run"] = False
-    for rnd in ("r02", "r01"):
+    mode = args.traffic
+    if mode == "auto":
+        import shutil
+
+        under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        mode = "measure" if (world == 1 and shutil.which("rocprofv3") and args.accum in ("i8", "fp64") and not under_profiler) else "replay"
+    if mode == "measure" and world == 1:
         try:
-            if world == 1 and args.accum == "i8":
-                fn = "profiles/%s_pmc_summary_i8.json" % rnd
-                pmc = json.load(open(os.path.join(ROOT, fn)))[args.workload]["gemm_i8_" + dom]
-            elif world == 1 and args.accum == "fp64":
-                fn = "profiles/%s_pmc_summary.json" % rnd
-                pmc = json.load(open(os.path.join(ROOT, fn)))[args.workload][dom]
-            else:
+            roofline["traffic"] = measure_traffic(args, dom)
+            roofline["traffic_measured_in_this_run"] = True
+            roofline["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child runs of this bench, 2 block applies "
+                                          "each, right after the timed region): FETCH_SIZE x2 + WRITE_SIZE per launch of the dominant kernel")
+        except Exception as e:  # no rocprofv3, counters busy, time-out: fall back to the committed passes
+            print("traffic measurement failed (%s); replaying profiles/" % e, file=sys.stderr)
+            mode = "replay"
+    if mode == "replay":
+        for rnd in ("r02", "r01"):
+            try:
+                if world == 1 and args.accum == "i8":
+                    fn = "profiles/%s_pmc_summary_i8.json" % rnd
+                    pmc = json.load(open(os.path.join(ROOT, fn)))[args.workload]["gemm_i8_" + dom]
+                elif world == 1 and args.accum == "fp64":
+                    fn = "profiles/%s_pmc_summary.json" % rnd
+                    pmc = json.load(open(os.path.join(ROOT, fn)))[args.workload][dom]
+                else:
+                    break
+                roofline["traffic"] = pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]
+                roofline["traffic_source"] = "replayed from " + fn + " (rocprofv3 --pmc passes of this workload: FETCH_SIZE x2 + WRITE_SIZE per launch)"
                 break
-            roofline["traffic"] = pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]
-            roofline["traffic_source"] = "replayed from " + fn + " (rocprofv3 --pmc passes of this workload: FETCH_SIZE x2 + WRITE_SIZE per launch)"
-            break
-        except Exception:
-            continue
+            except Exception:
+                continue
 
     out = dict(metric="genotype cells/sec (N x P x iters) for k=20 PCA", value=value, unit="cells/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, spinup_applies=SPINUP[args.workload],
@@ -270,14 +324,21 @@ def main():
 
     # ---- one full PCA solve to convergence (reported, not the timed region) -------------------------------
     if not args.no_pca:
+        # two solves: the first one also allocates the Krylov basis blocks and the solver's scratch (kept by the context
+        # afterwards), `wall_s` is the second
         barrier()
+        t1 = time.perf_counter()
+        r = ctx.pca(ndim=k, allow_unconverged=True)
+        ctx.synchronize()
+        barrier()
+        wall_first = time.perf_counter() - t1
         t1 = time.perf_counter()
         r = ctx.pca(ndim=k, allow_unconverged=True)
         ctx.synchronize()
         barrier()
         wall = time.perf_counter() - t1
         info = r["info"]
-        out["pca"] = dict(wall_s=wall, converged=bool(info["converged"]), block_applies=info["block_applies"],
+        out["pca"] = dict(wall_s=wall, first_call_wall_s=wall_first, converged=bool(info["converged"]), block_applies=info["block_applies"],
                           vector_ops=info["vector_ops"], restarts=info["restarts"],
                           cells_per_s=float(N) * P_done * info["vector_ops"] / wall,
                           seconds_apply=info["seconds_apply"], seconds_ortho=info["seconds_ortho"],

@@ -24,9 +24,9 @@ for a in i8 fp64; do
     for kind in fetch write sq; do
       case $kind in fetch) C="FETCH_SIZE";; write) C="WRITE_SIZE";; sq) C="--kernel-trace $PMC_SQ";; esac
       if [ $kind = sq ]; then
-        rocprofv3 --kernel-trace --pmc $PMC_SQ --output-format csv -d gpurun_out/$R/pmc_${kind}_${wl}_$a -o pmc -- python bench.py --workload $wl --accum $a --steps $st --warmup 1 --no-cpu-baseline --no-pca --no-alt > /dev/null 2>&1
+        rocprofv3 --kernel-trace --pmc $PMC_SQ --output-format csv -d gpurun_out/$R/pmc_${kind}_${wl}_$a -o pmc -- python bench.py --workload $wl --accum $a --steps $st --warmup 1 --no-cpu-baseline --no-pca --no-alt --traffic none > /dev/null 2>&1
       else
-        rocprofv3 --pmc $C --output-format csv -d gpurun_out/$R/pmc_${kind}_${wl}_$a -o pmc -- python bench.py --workload $wl --accum $a --steps $st --warmup 1 --no-cpu-baseline --no-pca --no-alt > /dev/null 2>&1
+        rocprofv3 --pmc $C --output-format csv -d gpurun_out/$R/pmc_${kind}_${wl}_$a -o pmc -- python bench.py --workload $wl --accum $a --steps $st --warmup 1 --no-cpu-baseline --no-pca --no-alt --traffic none > /dev/null 2>&1
       fi
     done
   done
