@@ -166,6 +166,22 @@ def test_more_components_than_the_block_width(golden_dir, k, kw):
     assert np.max(np.abs(r["Px"] - r["U"] * np.sqrt(r["d"]))) < 1e-12
 
 
+def test_more_components_than_the_block_width_with_restarts(golden_dir):
+    """k > b with a basis cap so tight (2 (kb+1) + 2 blocks is the minimum the solver takes) that thick restarts, which keep
+    kb + 1 blocks of Ritz vectors, must happen; b = 16 so that k = 40 spans three blocks."""
+    N = O.count_fam_rows(os.path.join(golden_dir, "data_chr1.fam"))
+    d = O.OracleData(os.path.join(golden_dir, "data_chr1.bed"), N, "binom2")
+    X = d.dense()
+    k = 40
+    w = np.linalg.eigvalsh(X @ X.T)[::-1][:k] / d.P
+    rc, r = run_pca(d, k, blockvec=16, max_blocks=4)  # raised to 2 (3 + 1) + 2 = 10 blocks by the solver
+    assert rc == 0 and r["converged"] == 1 and r["restarts"] >= 1 and r["b"] == 16
+    assert np.max(np.abs(r["d"] - w) / w) < 1e-9
+    assert np.max(np.abs(r["U"].T @ r["U"] - np.eye(k))) < 1e-9
+    res = np.linalg.norm(X @ (X.T @ r["U"]) / d.P - r["U"] * r["d"], axis=0)
+    assert np.max(res / r["d"]) < 2e-6
+
+
 def test_more_components_than_the_block_width_few_samples():
     """k > b and too few samples for ceil(k/b)+3 blocks: the dense route, Ritz vectors in several blocks."""
     rng = np.random.default_rng(11)
