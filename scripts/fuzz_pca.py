@@ -1,5 +1,5 @@
 """Randomised end-to-end sweep (GPU): fpca_pca on small random genotype matrices against numpy's dense eigendecomposition of
-X X'/div -- random N, P, k (up to the reference's limit), standardisation, divisor, block width, rank-deficient inputs
+X X'/div -- random N, P, k (up to the reference's limit, beyond the block width of 64 included), standardisation, divisor, block width, rank-deficient inputs
 (duplicated samples, few SNPs).  python scripts/fuzz_pca.py [cases] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,7 +32,8 @@ for case in range(ncases):
     N = int(rng.integers(8, 1500))
     P = int(rng.integers(8, 2500))
     kmax = (min(N, P) - 1) // 2
-    k = int(min(kmax, rng.choice([1, 2, 5, 10, 20, 40])))
+    # (70 .. 300: more components than the block width -- several blocks of Ritz vectors, or the dense route when N is small)
+    k = int(min(kmax, rng.choice([1, 2, 5, 10, 20, 40, 70, 130, 300])))
     if k < 1:
         continue
     stand = str(rng.choice(["binom2", "binom"]))
