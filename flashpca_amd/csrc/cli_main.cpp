@@ -253,8 +253,24 @@ static void on_sigchld(int)
          kill_children();
          _exit(EXIT_FAILURE);
       }
+      // A rank that ANNOUNCED its failure and left: normally everybody meets at the next rendezvous and rank 0 reports the
+      // message -- unless the others (rank 0 included) sit inside a collective that the leaver will never join.  Give the
+      // orderly path five seconds, then end the run from the alarm.
+      if (bad && !g_quiesce) alarm(5);
    }
    errno = saved;
+}
+
+static void on_sigalrm(int)
+{
+   if (g_quiesce) return;
+   static const char head[] = "Exception: ";
+   static const char tail[] = " (the other ranks were still inside a collective)\nTerminating\n";
+   (void)!write(2, head, sizeof(head) - 1);
+   if (g_shared) (void)!write(2, g_shared->msg, strnlen(g_shared->msg, sizeof(g_shared->msg)));
+   (void)!write(2, tail, sizeof(tail) - 1);
+   kill_children();
+   _exit(EXIT_FAILURE);
 }
 
 // rank 0: wait for every child that has not been reaped yet (the handler may reap them first: ECHILD is fine)
@@ -614,6 +630,8 @@ int main(int argc, char *argv[])
             sa.sa_handler = on_sigchld;
             sa.sa_flags = SA_RESTART | SA_NOCLDSTOP;
             sigaction(SIGCHLD, &sa, nullptr);
+            sa.sa_handler = on_sigalrm;
+            sigaction(SIGALRM, &sa, nullptr);
          }
          const pid_t parent = getpid();
          for (int r = 1; r < ngpus; r++) { // nothing has touched HIP yet: the children initialise their own runtime
@@ -627,6 +645,7 @@ int main(int argc, char *argv[])
                (void)prctl(PR_SET_PDEATHSIG, SIGKILL);
                if (getppid() != parent) _exit(1);
                signal(SIGCHLD, SIG_DFL);
+               signal(SIGALRM, SIG_DFL);
                mg.rank = r;
                g_nchildren = 0;
                g_child_rank = r;
@@ -646,8 +665,8 @@ int main(int argc, char *argv[])
             if (ctx) fpca_destroy(ctx);
             _exit(1);
          }
-         g_quiesce = 1;
-         wait_children();
+         abandon_children(); // (two seconds for the orderly exit, then SIGKILL: a rank may be inside a collective)
+         alarm(0);
          std::cerr << timestamp() << "Exception: " << mg.sh->msg << std::endl << timestamp() << "Terminating" << std::endl;
          if (ctx) fpca_destroy(ctx);
          return EXIT_FAILURE;
