@@ -4,10 +4,14 @@
   python bench.py --gpus N --steps K --warmup W          (N=1 directly; N>1 under torch.distributed.run)
 
 A "step" is ONE pass of the hot path over the resident genotype matrix: the block operator
-Y = sum_g X_g X_g' B on b = 32 columns (k = 20 PCA -> b = 32), i.e. K2 (xt_b) + K3 (x_t) + the all-reduce
-of the N x b product when N > 1.  That is b single-vector applications of the reference's perform_op
-(svdwide.cpp:21-68), so   value = N_samples * P_total * b * K / time   [genotype cells / s], the metric
-BASELINE.json names ("N x P x iters" with iters = single-vector operator applications).
+Y = sum_g X_g X_g' B on b = 32 columns, i.e. K2 (xt_b) + K3 (x_t) + the all-reduce of the N x b product when N > 1.  That is b
+single-vector applications of the reference's perform_op (svdwide.cpp:21-68), so
+value = N_samples * P_total * b * K / time   [genotype cells / s], the metric BASELINE.json names ("N x P x iters" with iters =
+single-vector operator applications).  b = 32 is the width at which the operator has its best throughput (7 byte slices x 32
+columns = exactly 7 column tiles of the int8 GEMM) and the width round 1 measured.  Since round 2 the SOLVER picks 16-column
+blocks by default (the k wanted Ritz vectors may span several blocks): fewer cells/s per pass -- `apply_at_solver_width` in the
+same line -- but fewer, cheaper passes and a 20-60 % shorter time to solution, which is the `pca` object (wall-clock of
+fpca_pca with its default options) -- the honest end-to-end figure.
 
 Workload (default, BASELINE.json configs[2]/[3] -- the configuration the metric is quoted on): synthetic 500,000 samples x
 100,000 SNPs, k = 20, generated directly in HBM; with N > 1 ranks the SNP columns are sharded N ways (strong scaling,
@@ -318,9 +322,43 @@ def main():
                                "agrees with the f64 kernels to ~3e-15, see fp64_mode)"),
                data="synthetic",
                config=dict(workload=args.workload + ": " + w["desc"], samples=N, snps_total=P_total, snps_per_gpu=P_rank,
-                           k=k, blockvec=b, missing_call_rate=0.001, parallelism="snp-shard x%d + all-reduce(N x b) [%s]" % (world, transport),
+                           k=k, blockvec=b, solver_default_blockvec=(16 if k <= 64 else 32 if k <= 128 else 64), missing_call_rate=0.001, parallelism="snp-shard x%d + all-reduce(N x b) [%s]" % (world, transport),
                            iters_per_step=b, generate_s=round(t_gen, 3)),
                roofline=roofline)
+
+    # ---- the same block apply at the width the SOLVER picks by default for this k (16 columns since round 2: the shortest
+    # time to solution), beside `value`'s width (the widest tile-exact one, S b = 224 = 7 column tiles): fewer
+    # columns per pass and 12.5 % of the last column tile empty, so fewer cells/s -- and still the faster PCA -------------
+    b_solver = 16 if k <= 64 else 32 if k <= 128 else 64
+    if b_solver != b and not args.no_pca:
+        Bs = torch.zeros((rows, b_solver), dtype=torch.float64, device="cuda")
+        Bs[:N] = torch.rand((N, b_solver), dtype=torch.float64, device="cuda", generator=g) - 0.5
+        Ys = torch.zeros((rows, b_solver), dtype=torch.float64, device="cuda")
+        steps_s = max(4, args.steps // 3)
+        for _ in range(max(2, args.warmup)):
+            ctx.apply_xxt_dev(Bs.data_ptr(), b_solver, Ys.data_ptr())
+        ctx.synchronize()
+        barrier()
+        ctx.profile_begin(steps_s, sample_every=stride if steps_s >= 8 else 1)
+        t1 = time.perf_counter()
+        for _ in range(steps_s):
+            ctx.apply_xxt_dev(Bs.data_ptr(), b_solver, Ys.data_ptr())
+        ctx.synchronize()
+        barrier()
+        el_s = time.perf_counter() - t1
+        ps = ctx.profile_end(b_solver)
+        ms_s = max(ps["ms_gemm_xt"], ps["ms_gemm_x"])
+        sw = dict(blockvec=b_solver, steps=steps_s, ms_per_step=el_s / steps_s * 1e3, value=float(N) * P_done * b_solver * steps_s / el_s,
+                  unit="cells/s", ms_gemm_kernel_xt_b=ps["ms_gemm_xt"], ms_gemm_kernel_x_t=ps["ms_gemm_x"])
+        if args.accum.startswith("i8"):
+            S = int(args.accum[3:]) if len(args.accum) > 2 else 7
+            nm = 1 if ctx.missing_mode(b_solver) in (2, 3) else 2
+            ops = nm * 2.0 * N * P_rank * b_solver * S
+            sw["roofline"] = dict(bound="mfma", achieved=ops / (ms_s * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s",
+                                  frac=ops / (ms_s * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, ops_per_launch=ops,
+                                  note="S b = %d slice-columns fill %.1f of %d column tiles" % (S * b_solver, S * b_solver / 32.0, -(-S * b_solver // 32)))
+        out["apply_at_solver_width"] = sw
+        del Bs, Ys
 
     # ---- one full PCA solve to convergence (reported, not the timed region) -------------------------------
     if not args.no_pca:
@@ -338,7 +376,8 @@ def main():
         barrier()
         wall = time.perf_counter() - t1
         info = r["info"]
-        out["pca"] = dict(wall_s=wall, first_call_wall_s=wall_first, converged=bool(info["converged"]), block_applies=info["block_applies"],
+        out["pca"] = dict(wall_s=wall, first_call_wall_s=wall_first, blockvec=info["blockvec"], converged=bool(info["converged"]),
+                          block_applies=info["block_applies"],
                           vector_ops=info["vector_ops"], restarts=info["restarts"],
                           cells_per_s=float(N) * P_done * info["vector_ops"] / wall,
                           seconds_apply=info["seconds_apply"], seconds_ortho=info["seconds_ortho"],

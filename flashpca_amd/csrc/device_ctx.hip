@@ -1346,10 +1346,7 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
       const uint64_t max_dim = lim >= 1 ? (lim - 1) / 2 : 0;
       if (k < 1 || (uint64_t)k > max_dim)
          throw Error(FPCA_EINVAL, "You asked for " + std::to_string(k) + " dimensions, but only " + std::to_string(max_dim) + " allowed");
-      int b = choose_blockvec(k, opts->blockvec);
-      // the exact-integer path has its sparse missing-indicator route for widths 16 / 32 / 64 only, and 64 columns cost it
-      // less than 48 (43 vs 56 ms per apply at 500k x 100k): the automatic choice skips 48 there
-      if (opts->blockvec <= 0 && b == 48 && ctx->i8_S > 0) b = 64;
+      const int b = choose_blockvec(k, opts->blockvec); // automatic: 16 (32 / 64 for ndim > 64 / > 128), never 48
       const bool timing = std::getenv("FPCA_TIMING") != nullptr;
       auto tp0 = std::chrono::steady_clock::now();
       auto lap = [&](const char *what) {

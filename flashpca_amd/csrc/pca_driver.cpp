@@ -19,8 +19,13 @@ int choose_blockvec(int ndim, int requested)
    if (ndim < 1) throw Error(FPCA_EINVAL, "ndim must be >= 1");
    int b = requested; // ndim > b is fine: the solver keeps ceil(ndim / b) + 1 Ritz blocks (solver.cpp)
    if (b <= 0) {
-      b = (int)round_up((uint64_t)ndim + 4, 16);
-      if (b > MAX_BLOCKVEC) b = MAX_BLOCKVEC;
+      // Automatic width: the NARROWEST block the kernels have.  A block apply on 16 columns costs 0.6 of one on 32 (12.6 vs
+      // 20.5 ms at 500,000 x 100,000) and 0.3 of one on 64, while the Krylov iteration needs only 1.1-1.4x as many of them:
+      // measured time to solution for k = 10 / 20 / 50 on an easy and on a slowly converging spectrum at 50,000 x 20,000
+      // and 500,000 x 100,000 (scripts/width_vs_k.py) is shortest at b = 16 in all twelve cases -- by 20 % (k = 20, easy)
+      // to 64 % (k = 50, slow) against the round-1 rule "smallest multiple of 16 >= k + 4".  Wider blocks only where k is so
+      // large that the ceil(k/b) + 1 blocks of Ritz vectors a restart keeps would crowd the basis.
+      b = ndim <= 64 ? 16 : ndim <= 128 ? 32 : MAX_BLOCKVEC;
    }
    if (b % 16 != 0 || b < 16 || b > MAX_BLOCKVEC) throw Error(FPCA_EINVAL, "blockvec must be 16, 32, 48 or 64");
    return b;

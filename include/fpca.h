@@ -170,9 +170,10 @@ int fpca_set_total_snps(fpca_ctx *ctx, uint64_t P_total);
  * X X' is formed from ceil(N/b) applies on the identity and decomposed directly. */
 typedef struct fpca_pca_opts {
    int ndim;        /* --ndim (flashpca.cpp:325 default 10) */
-   int blockvec;    /* block width b (multiple of 16, <= 64); 0 = smallest multiple of 16 >= ndim + 4, at most 64 (64 instead
-                     * of 48 in the exact-integer mode).  ndim may exceed b -- up to the reference's (min(N,P)-1)/2 --: the
-                     * solver then carries ceil(ndim/b) + 1 blocks of Ritz vectors across restarts */
+   int blockvec;    /* block width b (16, 32, 48 or 64); 0 = automatic: 16 for ndim <= 64, 32 for ndim <= 128, else 64 -- the
+                     * narrowest block gives the shortest time to solution (pca_driver.cpp).  ndim may exceed b -- up to the
+                     * reference's (min(N,P)-1)/2 --: the solver then carries ceil(ndim/b) + 1 blocks of Ritz vectors across
+                     * restarts */
    int maxiter;     /* maximum block applies (reference: 500 restarts, flashpca.cpp:426) */
    double tol;      /* --tol (flashpca.cpp:440 default 1e-6) */
    int divisor;     /* FPCA_DIVISOR_* (flashpca.cpp:484 default p) */

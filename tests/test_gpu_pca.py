@@ -214,7 +214,7 @@ def test_more_components_than_the_block_width(golden_dir, fp, k, accum):
         packed = ctx.download_packed()
         P = ctx.P
         r = ctx.pca(ndim=k, do_loadings=True)
-        assert r["info"]["converged"] == 1 and r["info"]["blockvec"] == 64
+        assert r["info"]["converged"] == 1 and r["info"]["blockvec"] == (32 if k <= 128 else 64)  # automatic width
         with pytest.raises(fp.FpcaError):
             ctx.pca(ndim=479)
     from oracle import oracle as O
@@ -312,7 +312,8 @@ def test_config5_full_size_properties(fp):
         s1, s2 = u[:, 0] @ Au[:, 1], Au[:, 0] @ u[:, 1]
         assert abs(s1 - s2) <= 1e-10 * np.linalg.norm(Au[:, 0]) * np.linalg.norm(u[:, 1])
         r = ctx.pca(ndim=k)
-        assert r["info"]["converged"] == 1 and r["info"]["blockvec"] == 64 and r["info"]["block_applies"] <= 12
+        # automatic block width: 16 columns, the k = 50 Ritz vectors span four blocks
+        assert r["info"]["converged"] == 1 and r["info"]["blockvec"] == 16 and r["info"]["block_applies"] <= 16
         err, mse, rmse = ctx.check(r["U"], r["d"])
         assert np.all(np.sqrt(err) <= 1.01e-6 * r["d"])
         d8, U8 = r["d"], r["U"]

@@ -158,7 +158,7 @@ def test_more_components_than_the_block_width(golden_dir, k, kw):
     w = np.linalg.eigvalsh(X @ X.T)[::-1][:k] / d.P
     rc, r = run_pca(d, k, **kw)
     assert rc == 0 and r["converged"] == 1
-    assert r["b"] == kw.get("blockvec", 64)
+    assert r["b"] == kw.get("blockvec", 32 if k <= 128 else 64)  # automatic width: 16 / 32 / 64 for k <= 64 / <= 128 / beyond
     assert np.max(np.abs(r["d"] - w) / w) < 1e-9
     assert np.max(np.abs(r["U"].T @ r["U"] - np.eye(k))) < 1e-9
     res = np.linalg.norm(X @ (X.T @ r["U"]) / d.P - r["U"] * r["d"], axis=0)
@@ -190,11 +190,14 @@ def test_more_components_than_the_block_width_few_samples():
     d = O.OracleData(packed=packed, N=N, P=P, stand="binom2")
     X = d.dense()
     w = np.linalg.eigvalsh(X @ X.T / P)[::-1]
-    rc, r = run_pca(d, k)
+    rc, r = run_pca(d, k, blockvec=64)  # (ceil(120/64) + 1) + 2 = 5 blocks of 64 do not fit in 300 samples
     assert rc == 0 and r["converged"] == 1 and r["applies"] == -(-N // 64)
     assert np.max(np.abs(r["d"] - w[:k])) < 1e-10 * w[0]
     assert np.max(np.abs(r["U"].T @ r["U"] - np.eye(k))) < 1e-10
     assert np.max(np.abs(X @ (X.T @ r["U"]) / P - r["U"] * r["d"])) < 1e-9 * w[0]
+    rc, r2 = run_pca(d, k)  # automatic width 32: the Krylov route fits
+    assert rc == 0 and r2["converged"] == 1 and r2["b"] == 32
+    assert np.max(np.abs(r2["d"] - w[:k])) < 1e-9 * w[0]
 
 
 def test_not_converged_is_reported(golden_dir):
