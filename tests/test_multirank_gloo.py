@@ -20,9 +20,9 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_pca_matches_golden(golden_dir, tmp_path, world):
-    name, k = "data_chr1", 10
+@pytest.mark.parametrize("world,k", [(2, 10), (3, 10), (2, 20)])  # k = 20: two blocks of Ritz vectors at the automatic width 16
+def test_sharded_pca_matches_golden(golden_dir, tmp_path, world, k):
+    name = "data_chr1"
     g = json.load(open(os.path.join(golden_dir, "golden_%s_binom2.json" % name)))
     port = free_port()
     out = str(tmp_path / "res.json")
