@@ -95,7 +95,7 @@ const OptSpec OPTS[] = {
    {"version", 0, false, "version"},
    {"device", 0, true, "HIP device index [0] (with --gpus G: the first of G consecutive devices)"},
    {"gpus", 0, true, "number of GPUs for PCA [1]: the SNPs are split into that many contiguous shards, one process per GPU, partial products summed by an RCCL all-reduce"},
-   {"blockvec", 0, true, "block width of the eigensolver: 16, 32, 48 or 64 [smallest multiple of 16 >= ndim+4]"},
+   {"blockvec", 0, true, "block width of the eigensolver: 16, 32, 48 or 64 [16; 32 / 64 for ndim > 64 / > 128]"},
    {"maxblocks", 0, true, "basis cap (in blocks) before a thick restart [automatic]"},
    {"accum", 0, true, "arithmetic of the two genotype GEMMs [auto | fp64 | fp32 | i8 | i8xS]: i8 = exact-integer int8 MFMA on S = 7 (i8xS: S = 2..8) byte slices of the fp64 operand, results equal to fp64; fp32 = fp32 MFMA products, fp64 long accumulation; auto (default) = i8, or fp64 if the int8 buffers do not fit"},
 };

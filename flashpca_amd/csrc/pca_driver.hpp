@@ -8,7 +8,7 @@
 
 namespace fpca {
 
-// block width for ndim wanted components: requested (validated) or the smallest multiple of 16 >= ndim + 4
+// block width for ndim wanted components: requested (validated) or automatic: 16 (32 / 64 for ndim > 64 / > 128)
 int choose_blockvec(int ndim, int requested);
 
 struct PcaOutputs {
