@@ -46,7 +46,11 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
    // whatever the data size, a block apply O(N P b) on the device -- small problems with slowly converging spectra are
    // better off with half the basis (256 columns; six blocks at least, so that a restart can keep two) and a few more applies.  Decided from the problem size, not from
    // timings, so that every rank of a multi-GPU run decides alike.
-   if (so.max_blocks <= 0 && (double)N * (double)P_div < 1e10) so.max_blocks = std::max(6, 256 / be.width());
+   if (so.max_blocks <= 0 && (double)N * (double)P_div < 1e10) {
+      so.max_blocks = std::max(6, (be.width() == 16 ? 192 : 256) / be.width());
+      const int kb = (k + be.width() - 1) / be.width();
+      if (kb > 1) so.max_blocks = std::max(so.max_blocks, 3 * (kb + 1)); // k > b: a restart keeps kb + 1 blocks
+   }
    so.seed = o.seed ? o.seed : 1;
    so.verbose = o.verbose;
    SolverResult r = block_krylov_schur(be, so);

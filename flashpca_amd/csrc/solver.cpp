@@ -196,8 +196,11 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    // the wanted Ritz vectors occupy kb blocks, a thick restart keeps kb + 1 blocks of them, and the basis cap grows with k
    const int kb = (k + b - 1) / b;
    const int nk_wide = kb > 1 ? kb + 1 : 0; // Ritz blocks a restart keeps when k > b (0: the k <= b rule below)
-   int mcap = o.max_blocks > 0 ? o.max_blocks : std::max(4, 512 / b);
+   // (basis cap in columns: 512, or 384 for 16-column blocks -- where the sum of block applies and dense Rayleigh-Ritz cost
+   // was smallest on the slowly converging test spectrum, scripts/hard_spectrum_cap.py)
+   int mcap = o.max_blocks > 0 ? o.max_blocks : std::max(4, (b == 16 ? 384 : 512) / b);
    if (kb > 1) mcap = std::max(mcap, 2 * nk_wide + 2);
+   if (kb > 1 && o.max_blocks <= 0) mcap = std::max(mcap, 3 * nk_wide); // room to grow between two restarts
    // the basis [V_0..V_{m-1}, Q] must fit in N dimensions
    const int fit = (int)std::min<uint64_t>(N / (uint64_t)b, 1u << 20) - 1;
    if (fit < 2 || (kb > 1 && fit < nk_wide + 2)) return dense_small(be, o);
