@@ -415,9 +415,11 @@ int i8_mode(const fpca_ctx *c, int b)
    if (!c->missing_known) return I8M_FULL;
    if (c->n_missing == 0) return I8M_NONE;
    const double rate = (double)c->n_missing / ((double)c->N * (double)std::max<uint64_t>(c->P_g, 1));
-   // a gathered fp64 row costs 8 b bytes per missing call (1.9-2.2 ms per 0.1 % at N x P = 500k x 100k, b = 32); the E half
-   // of the int8 GEMMs costs 7.5-9 ms there whatever the rate: break-even measured near 0.4 %
-   if (sparse_ok && rate <= 0.003) return I8M_SPARSE;
+   // a gathered fp64 row costs 8 b bytes per missing call; the E half of the int8 GEMMs costs the same whatever the rate.
+   // Measured at 500k x 100k (scripts/sparse_breakeven.py, K2 / K3 stage in ms, sparse | dense): b = 16: 0.3 % 7.2 / 7.5 |
+   // 8.7 / 9.5, 0.5 % 8.7 / 9.2 | 8.8 / 9.5, 1 % 12.8 / 13.1 | 8.8 / 9.5; b = 32: 0.3 % 12.4 / 13.4 | 15.6 / 18.1, 0.5 % 15.7 / 16.5 |
+   // 15.6 / 18.1, 1 % 23.7 / 24.4 | 15.6 / 18.1 -- break-even at 0.5 % for both widths
+   if (sparse_ok && rate <= 0.0045) return I8M_SPARSE;
    return rate < 3e-4 ? I8M_SKIP : I8M_FULL; // (block skipping: only where the sparse path does not apply)
 }
 
