@@ -202,6 +202,89 @@ def test_config3_oracle_residual_at_full_size(fp, orc):
         v = op.crossprod(np.ascontiguousarray(r["U"][:, c])) / np.sqrt(r["d"][c]) / np.sqrt(P)
         assert np.max(np.abs(v - r["V"][:, c])) <= 1e-11 * np.max(np.abs(v))
         assert abs(op.trace / P - r["info"]["trace"]) <= 1e-12 * r["info"]["trace"]
+        # the same solve on 32-column blocks (the width bench.py's `apply_at_b32` side block times): a different kernel
+        # instantiation (7 column tiles per wave), judged by the oracle the same way
+        r32 = ctx.pca(ndim=k, blockvec=32)
+        assert r32["info"]["converged"] == 1 and r32["info"]["blockvec"] == 32
+        assert np.max(np.abs(r32["d"] - r["d"]) / r["d"]) < 1e-9
+        for c in (0, k - 1):
+            u = np.ascontiguousarray(r32["U"][:, c])
+            res = np.linalg.norm(op.perform_op(u) / P - r32["d"][c] * u)
+            assert res <= 1e-6 * r32["d"][c], (c, res)
+
+
+def test_config3_wide_blocks_vs_oracle(fp, orc):
+    """svdwide.cpp:71-118 (perform_op_mat) at 500,000 x 100,000 on 32-COLUMN blocks, in both arithmetics.  fpca_apply_xxt
+    pads to a multiple of 16 columns, so 1-2 column probes only ever reach the 16-column kernels; bench.py also times the
+    32-column instantiation (I8Cfg with 7 column tiles, k_xt_b<double,2,4>), which must meet the oracle at size too:
+    oracle perform_op on columns 0, 17 and 31 entry by entry, every column against the 16-column path, and the two halves
+    of the operator alone (crossprod svdwide.cpp:122-153, prod svdwide.cpp:193-226)."""
+    N, P, b = 500000, 100000, 32
+    nt = orc.host_threads()
+    rng = np.random.default_rng(32)
+    B = rng.standard_normal((N, b))
+    Tin = rng.standard_normal((P, b))
+    got = {}
+    packed = None
+    for accum in ("auto", "fp64"):
+        with fp.Context.synthetic(N, P, accum=accum) as ctx:
+            if packed is None:
+                packed = ctx.download_packed()
+            Z = ctx.apply_xxt(B)
+            Z16 = np.hstack([ctx.apply_xxt(B[:, :16]), ctx.apply_xxt(B[:, 16:])])
+            assert np.max(np.abs(Z - Z16)) <= 1e-12 * np.max(np.abs(Z)), accum  # 32-column kernels == 16-column kernels
+            got[accum] = (Z, ctx.apply_xt(B), ctx.apply_x(Tin))
+    od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+    op = orc.OracleOp(od, 1000, nthreads=nt)
+    for c in (0, 17, 31):
+        y = op.perform_op(np.ascontiguousarray(B[:, c]))
+        for accum in got:
+            assert np.max(np.abs(got[accum][0][:, c] - y)) <= 1e-11 * np.max(np.abs(y)), (accum, c)
+    t = op.crossprod(np.ascontiguousarray(B[:, 17]))
+    y = op.prod(np.ascontiguousarray(Tin[:, 17]))
+    for accum in got:
+        assert np.max(np.abs(got[accum][1][:, 17] - t)) <= 1e-11 * np.max(np.abs(t)), accum
+        assert np.max(np.abs(got[accum][2][:, 17] - y)) <= 1e-11 * np.max(np.abs(y)), accum
+    # all 32 columns of the two arithmetics against each other
+    for i in range(3):
+        a, f = got["auto"][i], got["fp64"][i]
+        assert np.max(np.abs(a - f)) <= 1e-12 * np.max(np.abs(f)), i
+
+
+def test_config5_shard_widest_blocks_vs_oracle(fp, orc):
+    """One GPU's shard of BASELINE configs[4] (1,000,000 samples x 25,000 of 200,000 SNPs) on 64-COLUMN blocks: the K2 plan
+    with two column blocks per row tile and the 64-wide partial planes (`bench.py --workload cfg5 / cfg5shard` times them)
+    meet the oracle at N = 10^6: one column entry by entry through perform_op / crossprod / prod, all 64 columns of the
+    exact-integer path against the fp64 kernels and against the 16-column path."""
+    N, Pg, b = 1000000, 25000, 64
+    nt = orc.host_threads()
+    rng = np.random.default_rng(64)
+    B = rng.standard_normal((N, b))
+    Tin = rng.standard_normal((Pg, b))
+    got = {}
+    packed = None
+    for accum in ("auto", "fp64"):
+        with fp.Context.synthetic(N, Pg, snp_begin=3 * Pg, n_pop=64, accum=accum) as ctx:
+            if packed is None:
+                packed = ctx.download_packed()
+            Z = ctx.apply_xxt(B)
+            Z16 = np.hstack([ctx.apply_xxt(B[:, j:j + 16]) for j in range(0, b, 16)])
+            assert np.max(np.abs(Z - Z16)) <= 1e-12 * np.max(np.abs(Z)), accum
+            got[accum] = (Z, ctx.apply_xt(B), ctx.apply_x(Tin))
+    od = orc.OracleData(packed=packed, N=N, P=Pg, stand="binom2")
+    op = orc.OracleOp(od, 1000, nthreads=nt)
+    for c in (0, 37, 63):
+        y = op.perform_op(np.ascontiguousarray(B[:, c]))
+        for accum in got:
+            assert np.max(np.abs(got[accum][0][:, c] - y)) <= 1e-11 * np.max(np.abs(y)), (accum, c)
+    t = op.crossprod(np.ascontiguousarray(B[:, 37]))
+    y = op.prod(np.ascontiguousarray(Tin[:, 37]))
+    for accum in got:
+        assert np.max(np.abs(got[accum][1][:, 37] - t)) <= 1e-11 * np.max(np.abs(t)), accum
+        assert np.max(np.abs(got[accum][2][:, 37] - y)) <= 1e-11 * np.max(np.abs(y)), accum
+    for i in range(3):
+        a, f = got["auto"][i], got["fp64"][i]
+        assert np.max(np.abs(a - f)) <= 1e-12 * np.max(np.abs(f)), i
 
 
 @pytest.mark.parametrize("k,accum", [(100, "auto"), (200, "fp64"), (478, "auto")])
@@ -302,13 +385,17 @@ def test_config5_full_size_properties(fp):
     eigenvalues the tail of the spectrum sits in the bulk and ANY Krylov method needs hundreds of passes."""
     N, P, k = 1000000, 200000, 50
     rng = np.random.default_rng(5)
-    u = rng.standard_normal((N, 2))
+    u = rng.standard_normal((N, 64))  # 64 columns: the b = 64 kernels `bench.py --workload cfg5` times, at full size
     with fp.Context.synthetic(N, P, n_pop=64, accum="fp64") as c64:
         A64 = c64.apply_xxt(u)
     with fp.Context.synthetic(N, P, n_pop=64, accum="auto") as ctx:
         assert ctx.accum == "i8x7"
         Au = ctx.apply_xxt(u)
         assert np.max(np.abs(Au - A64)) <= 1e-12 * np.max(np.abs(A64))
+        A2 = ctx.apply_xxt(u[:, :2])  # the 16-column kernels on the same vectors
+        assert np.max(np.abs(A2 - Au[:, :2])) <= 1e-12 * np.max(np.abs(Au[:, :2]))
+        r64 = ctx.pca(ndim=k, blockvec=64)
+        assert r64["info"]["converged"] == 1 and r64["info"]["blockvec"] == 64
         s1, s2 = u[:, 0] @ Au[:, 1], Au[:, 0] @ u[:, 1]
         assert abs(s1 - s2) <= 1e-10 * np.linalg.norm(Au[:, 0]) * np.linalg.norm(u[:, 1])
         r = ctx.pca(ndim=k)
@@ -317,6 +404,7 @@ def test_config5_full_size_properties(fp):
         err, mse, rmse = ctx.check(r["U"], r["d"])
         assert np.all(np.sqrt(err) <= 1.01e-6 * r["d"])
         d8, U8 = r["d"], r["U"]
+        assert np.max(np.abs(r64["d"] - d8) / d8) < 1e-9  # 5 passes of 64 columns == 9 passes of 16
     # configs[4] names "fp32 accumulate (tolerance study)": the mixed fp32 mode at FULL size -- eigenvalues against the
     # exact-integer result (north_star: 1e-6 relative), the operator's entry-wise error on a probe, and the --check quantity
     with fp.Context.synthetic(N, P, n_pop=64, accum="fp32") as c32:
