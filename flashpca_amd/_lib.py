@@ -10,7 +10,13 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FPCA_LIB") or os.path.join(HERE, "_build", "libfpca.so")  # FPCA_LIB: A/B-test another build
+if LIB_PATH == "testhooks":  # shorthand used by the scripts that drive an environment switch
+    LIB_PATH = os.path.join(HERE, "_build", "testhooks", "libfpca.so")
 CLI_PATH = os.path.join(HERE, "_build", "flashpca")
+# the same sources compiled with -DFPCA_TEST_HOOKS: the only binaries in which the FPCA_I8_MODE / FPCA_AR_CHUNKS /
+# FPCA_DEBUG_* / FPCA_CLI_TEST_* environment switches exist (csrc/common.hpp).  Tests that need a switch load these.
+HOOKS_LIB_PATH = os.path.join(HERE, "_build", "testhooks", "libfpca.so")
+HOOKS_CLI_PATH = os.path.join(HERE, "_build", "testhooks", "flashpca")
 CSRC = os.path.join(HERE, "csrc")
 
 STANDARDISE = {"binom": 2, "binom2": 3}
@@ -32,6 +38,7 @@ class PcaOpts(C.Structure):
         ("max_blocks", C.c_int),
         ("verbose", C.c_int),
         ("seed", C.c_uint64),
+        ("max_applies", C.c_int),
     ]
 
 
@@ -110,6 +117,38 @@ SIGNATURES = {
 }
 
 _lib = None
+_loaded = {}
+
+
+def _load(path):
+    if path not in _loaded:
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "%s not found -- build it with `make -C flashpca_amd/csrc` (or __graft_entry__.build()); this package has "
+                "no CPU fallback" % path
+            )
+        L = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _loaded[path] = L
+    return _loaded[path]
+
+
+class test_hooks:
+    """Context manager: inside it lib() -- and with it every Context / flashpca() call -- goes to the -DFPCA_TEST_HOOKS build
+    of the library, where the environment test switches exist.  Contexts must be created AND closed inside the block."""
+
+    def __enter__(self):
+        global _lib
+        self._prev = _lib
+        _lib = _load(HOOKS_LIB_PATH)
+        return _lib
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self._prev
 
 
 def build(verbose=False):
@@ -125,17 +164,7 @@ def lib():
     """Load the C-ABI library; raises if it has not been built (no fallback of any kind)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                "libfpca.so not found at %s -- build it with `make -C flashpca_amd/csrc` "
-                "(or __graft_entry__.build()); this package has no CPU fallback" % LIB_PATH
-            )
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _load(LIB_PATH)
     return _lib
 
 

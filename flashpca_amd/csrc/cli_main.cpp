@@ -32,6 +32,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "../../include/fpca.h"
+#include "common.hpp"
 #include "plink_io.hpp"
 
 #define FLASHPCA_VERSION "2.1-mi355x (" FPCA_VERSION ")"
@@ -54,6 +55,8 @@ struct OptSpec {
    char shortname;
    bool has_value;
    const char *help;
+   bool ext = false; // an option this build adds: matched by its full name only, so that every abbreviation the reference
+                     // accepts (boost::program_options guesses unambiguous prefixes, flashpca.cpp:97) still means what it meant
 };
 
 const OptSpec OPTS[] = {
@@ -76,8 +79,12 @@ const OptSpec OPTS[] = {
    {"standy", 0, true, "standardization method for phenotypes (CCA only; ignored)"},
    {"div", 0, true, "whether to divide the eigenvalues by p, n - 1, or don't divide [p | n1 | none]"},
    {"outpc", 0, true, "PC output file"},
+   {"outpcx", 0, true, "X PC output file, for CCA (ignored)"},
+   {"outpcy", 0, true, "Y PC output file, for CCA (ignored)"},
    {"outvec", 0, true, "eigenvector output file"},
    {"outload", 0, true, "SNP loadings"},
+   {"outvecx", 0, true, "X eigenvector output file, for CCA (ignored)"},
+   {"outvecy", 0, true, "Y eigenvector output file, for CCA (ignored)"},
    {"outval", 0, true, "Eigenvalue output file"},
    {"outpve", 0, true, "proportion of variance explained output file"},
    {"outmeansd", 0, true, "mean+SD (used to standardize SNPs) output file"},
@@ -87,24 +94,42 @@ const OptSpec OPTS[] = {
    {"inmaf", 0, true, "MAF input file"},
    {"verbose", 'v', false, "verbose"},
    {"tol", 0, true, "tolerance for PCA iterations"},
-   {"maxiter", 0, true, "maximum number of iterations (block applies)"},
+   {"lambda1", 0, true, "1st penalty for CCA/SCCA (ignored)"},
+   {"lambda2", 0, true, "2nd penalty for CCA/SCCA (ignored)"},
+   {"maxiter", 0, true, "maximum number of iterations: restarts of the reference's 2 ndim + 1 vector Lanczos factorisation, i.e. a budget of 2 ndim + 1 + maxiter (ndim + 1) operator applications"},
+   {"debug", 0, false, "debug (no effect)"},
    {"suffix", 'f', true, "suffix for all output files"},
    {"check", 'c', false, "check eigenvalues/eigenvectors"},
    {"precision", 0, true, "digits of precision for output"},
    {"notime", 0, false, "don't print timestamp in output"},
+   {"save-vinit", 0, false, "saves the initial v eigenvector for SCCA (no effect)"},
    {"version", 0, false, "version"},
-   {"device", 0, true, "HIP device index [0] (with --gpus G: the first of G consecutive devices)"},
-   {"gpus", 0, true, "number of GPUs for PCA [1]: the SNPs are split into that many contiguous shards, one process per GPU, partial products summed by an RCCL all-reduce"},
-   {"blockvec", 0, true, "block width of the eigensolver: 16, 32, 48 or 64 [16; 32 / 64 for ndim > 64 / > 128]"},
-   {"maxblocks", 0, true, "basis cap (in blocks) before a thick restart [automatic]"},
-   {"accum", 0, true, "arithmetic of the two genotype GEMMs [auto | fp64 | fp32 | i8 | i8xS]: i8 = exact-integer int8 MFMA on S = 7 (i8xS: S = 2..8) byte slices of the fp64 operand, results equal to fp64; fp32 = fp32 MFMA products, fp64 long accumulation; auto (default) = i8, or fp64 if the int8 buffers do not fit"},
+   {"device", 0, true, "HIP device index [0] (with --gpus G: the first of G consecutive devices)", true},
+   {"gpus", 0, true, "number of GPUs for PCA [1]: the SNPs are split into that many contiguous shards, one process per GPU, partial products summed by an RCCL all-reduce", true},
+   {"blockvec", 0, true, "block width of the eigensolver: 16, 32, 48 or 64 [16; 32 / 64 for ndim > 64 / > 128]", true},
+   {"maxblocks", 0, true, "basis cap (in blocks) before a thick restart [automatic]", true},
+   {"accum", 0, true, "arithmetic of the two genotype GEMMs [auto | fp64 | fp32 | i8 | i8xS]: i8 = exact-integer int8 MFMA on S = 7 (i8xS: S = 2..8) byte slices of the fp64 operand, results equal to fp64; fp32 = fp32 MFMA products, fp64 long accumulation; auto (default) = i8, or fp64 if the int8 buffers do not fit", true},
 };
 
-const OptSpec *find_long(const std::string &n)
+// Long options like po::parse_command_line with its default style (flashpca.cpp:97; allow_guessing is part of
+// command_line_style::default_style): the full name wins; otherwise an abbreviation that is a prefix of exactly one of the
+// reference's options selects it (--nd 10, --outl f), and one that fits several is refused with boost's "ambiguous" error.
+const OptSpec *find_long(const std::string &n, const std::string &as_typed)
 {
    for (const auto &o : OPTS)
       if (n == o.name) return &o;
-   return nullptr;
+   std::vector<const OptSpec *> hits;
+   if (!n.empty())
+      for (const auto &o : OPTS)
+         if (!o.ext && std::string(o.name).compare(0, n.size(), n) == 0) hits.push_back(&o);
+   if (hits.size() == 1) return hits[0];
+   if (hits.empty()) throw std::runtime_error("unrecognised option '" + as_typed + "'");
+   std::string msg = "option '--" + n + "' is ambiguous and matches ";
+   for (size_t i = 0; i < hits.size(); i++) {
+      if (i) msg += i + 1 == hits.size() ? (hits.size() > 2 ? ", and " : " and ") : ", ";
+      msg += std::string("'--") + hits[i]->name + "'";
+   }
+   throw std::runtime_error(msg);
 }
 const OptSpec *find_short(char c)
 {
@@ -132,8 +157,7 @@ VarMap parse_command_line(int argc, char *argv[])
             have_val = true;
             body = body.substr(0, eq);
          }
-         o = find_long(body);
-         if (!o) throw std::runtime_error("unrecognised option '" + a + "'");
+         o = find_long(body, a);
       } else if (a.size() >= 2 && a[0] == '-') {
          o = find_short(a[1]);
          if (!o) throw std::runtime_error("unrecognised option '" + a + "'");
@@ -204,6 +228,7 @@ void fpca_ok(int rc)
 // algebra is replicated and deterministic, the only data-path exchange is the all-reduce inside the block apply
 // (DESIGN section 5).  Eigenvectors / eigenvalues are identical on every rank; the loadings and mean/sd rows of each shard
 // are deposited in the shared region and rank 0 writes every file.
+static_assert(std::atomic<int>::is_always_lock_free, "the SIGCHLD handler touches these atomics: they must be lock-free");
 struct MultiShared {
    std::atomic<int> created, failed, id_ready, bar_count, bar_sense;
    uint8_t id[FPCA_UNIQUE_ID_BYTES];
@@ -329,9 +354,11 @@ bool multi_barrier(Multi &m)
    return sh->failed.load() == 0;
 }
 
-// Test transport (FPCA_CLI_TEST_TRANSPORT=shm): every rank on the SAME device, the sum staged through host shared
-// memory in rank order -- exercises the launcher, the sharding and the gather of the outputs on a one-GPU box, where RCCL
-// refuses two ranks on one device.  Not a product path.
+// Test transport (FPCA_CLI_TEST_TRANSPORT=shm; only in builds with -DFPCA_TEST_HOOKS, i.e. _build/testhooks/flashpca):
+// every rank on the SAME device, the sum staged through host shared memory in rank order -- exercises the launcher, the
+// sharding and the gather of the outputs on a one-GPU box, where RCCL refuses two ranks on one device.  The shipped CLI
+// has no such path: its only transport is RCCL.
+#ifdef FPCA_TEST_HOOKS
 int shm_allreduce(void *user, double *dbuf, uint64_t count, void *stream)
 {
    Multi &m = *static_cast<Multi *>(user);
@@ -347,6 +374,7 @@ int shm_allreduce(void *user, double *dbuf, uint64_t count, void *stream)
    if (!multi_barrier(m)) return -1; // nobody overwrites a slot before everyone has read it
    return hipMemcpy(dbuf, sum.data(), count * sizeof(double), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
 }
+#endif
 
 int main(int argc, char *argv[])
 {
@@ -601,7 +629,7 @@ int main(int argc, char *argv[])
          const uint64_t np = (N + 3) / 4;
          const uint64_t P_file = (uint64_t)st.st_size > 3 ? ((uint64_t)st.st_size - 3) / np : 0; // data.cpp:165-170
          if (P_file < (uint64_t)ngpus) throw std::runtime_error("fewer SNPs than GPUs");
-         const char *tt = std::getenv("FPCA_CLI_TEST_TRANSPORT");
+         const char *tt = FPCA_TEST_ENV("FPCA_CLI_TEST_TRANSPORT");
          mg.test_transport = tt && std::string(tt) == "shm";
          if (mg.test_transport)
             std::cerr << "[fpca-cli] FPCA_CLI_TEST_TRANSPORT=shm: all ranks share one device and exchange through host memory -- a test "
@@ -634,6 +662,12 @@ int main(int argc, char *argv[])
             sigaction(SIGALRM, &sa, nullptr);
          }
          const pid_t parent = getpid();
+         // SIGCHLD stays blocked until every child pid is registered: a child that dies at once is then still found by the
+         // handler (a pending SIGCHLD is delivered on unblocking; the handler polls every registered child)
+         sigset_t chld, oldmask;
+         sigemptyset(&chld);
+         sigaddset(&chld, SIGCHLD);
+         sigprocmask(SIG_BLOCK, &chld, &oldmask);
          for (int r = 1; r < ngpus; r++) { // nothing has touched HIP yet: the children initialise their own runtime
             const pid_t pid = fork();
             if (pid < 0) {
@@ -646,6 +680,7 @@ int main(int argc, char *argv[])
                if (getppid() != parent) _exit(1);
                signal(SIGCHLD, SIG_DFL);
                signal(SIGALRM, SIG_DFL);
+               sigprocmask(SIG_SETMASK, &oldmask, nullptr);
                mg.rank = r;
                g_nchildren = 0;
                g_child_rank = r;
@@ -656,6 +691,7 @@ int main(int argc, char *argv[])
             g_child_done[g_nchildren] = 0;
             g_children[g_nchildren++] = pid;
          }
+         if (mg.rank == 0) sigprocmask(SIG_SETMASK, &oldmask, nullptr);
          snp_begin = P_file * (uint64_t)mg.rank / (uint64_t)ngpus;
          snp_count = P_file * (uint64_t)(mg.rank + 1) / (uint64_t)ngpus - snp_begin;
       }
@@ -682,15 +718,18 @@ int main(int argc, char *argv[])
                multi_fail(mg, fpca_last_error());
          }
          if (!multi_barrier(mg)) return multi_abort();
+#ifdef FPCA_TEST_HOOKS
          if (mg.test_transport) {
             // failure injection for tests/test_cli.py (test transport only): rank R kills itself / rank 0 throws after the
             // fork -- the run must end with a message and a non-zero status instead of hanging
-            if (const char *kr = std::getenv("FPCA_CLI_TEST_KILL_RANK")) {
+            if (const char *kr = FPCA_TEST_ENV("FPCA_CLI_TEST_KILL_RANK")) {
                if (atoi(kr) == mg.rank && mg.rank > 0) raise(SIGKILL);
                if (atoi(kr) == 0 && mg.rank == 0) throw std::runtime_error("injected failure of rank 0 after the fork");
             }
             if (fpca_set_allreduce(ctx, shm_allreduce, &mg) != FPCA_OK) multi_fail(mg, fpca_last_error());
-         } else {
+         } else
+#endif
+         {
             if (mg.rank == 0) {
                if (fpca_comm_unique_id(mg.sh->id) != FPCA_OK) multi_fail(mg, fpca_last_error());
                mg.sh->id_ready.store(1);

@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -21,6 +22,16 @@ constexpr int X_KC = 64;     // K3: SNPs per LDS chunk
 constexpr int MAX_BLOCKVEC = 64; // widest block the kernels are instantiated for (NT <= 4)
 
 inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+// Test and diagnostic switches -- forced missing-indicator modes and split plans, allocation-failure injection, the
+// host-memory test transport and the failure injection of the CLI launcher -- exist only in builds compiled with
+// -DFPCA_TEST_HOOKS (flashpca_amd/_build/testhooks/, used by tests/ and scripts/).  In the shipped library and CLI the
+// macro is a null pointer: no environment variable can change what they compute, and the names are not in the binaries.
+#ifdef FPCA_TEST_HOOKS
+#define FPCA_TEST_ENV(name) std::getenv(name)
+#else
+#define FPCA_TEST_ENV(name) (static_cast<const char *>(nullptr))
+#endif
 
 struct Error : std::runtime_error {
    int code;

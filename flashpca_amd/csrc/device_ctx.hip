@@ -135,6 +135,7 @@ struct fpca_ctx {
    double *d_eplane = nullptr; // E'Q of the current stage, [max(N_pad, P_pad)][b]
    size_t eplane_cap = 0;
    bool sparse_ready = false;
+   bool sparse_failed = false; // the index lists did not fit in device memory: the dense missing-indicator route is used
    hipStream_t aux_stream = nullptr; // the gather-sums run here, under the (MFMA-bound) GEMM of the same stage
    hipEvent_t ev_aux_go = nullptr, ev_aux_done = nullptr;
    // Krylov basis blocks of finished solves, kept for the next one (bytes, pointer): allocating and freeing a dozen
@@ -345,7 +346,7 @@ bool ensure_i8(fpca_ctx *c, int b)
 void ensure_i8_alloc(fpca_ctx *c, int b)
 {
    hipStream_t s = c->stream;
-   if (getenv("FPCA_DEBUG_I8_NOMEM")) throw Error(FPCA_ENOMEM, "FPCA_DEBUG_I8_NOMEM is set"); // exercises the fallback in the tests
+   if (FPCA_TEST_ENV("FPCA_DEBUG_I8_NOMEM")) throw Error(FPCA_ENOMEM, "FPCA_DEBUG_I8_NOMEM is set"); // exercises the fallback in the tests
    // exact int32 accumulation: |sum| <= 2 * 128 * K must stay below 2^31
    if (std::max(c->N_pad, c->P_pad) > (uint64_t)8380000)
       throw Error(FPCA_EINVAL, "the int8-sliced mode supports up to 8,380,000 samples and SNPs per GPU (int32 accumulation)");
@@ -409,8 +410,8 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
 constexpr int I8M_FULL = 0, I8M_SKIP = 1, I8M_NONE = 2, I8M_SPARSE = 3;
 int i8_mode(const fpca_ctx *c, int b)
 {
-   const char *env = getenv("FPCA_I8_MODE"); // force (tests; 2 is wrong unless nothing is missing); read on every call
-   const bool sparse_ok = c->missing_known && c->n_missing < (1ull << 31) && (b == 16 || b == 32 || b == 64);
+   const char *env = FPCA_TEST_ENV("FPCA_I8_MODE"); // force (tests; 2 is wrong unless nothing is missing); read on every call
+   const bool sparse_ok = c->missing_known && !c->sparse_failed && c->n_missing < (1ull << 31) && (b == 16 || b == 32 || b == 64);
    if (env) return (atoi(env) == I8M_SPARSE && !sparse_ok) ? I8M_FULL : atoi(env);
    if (!c->missing_known) return I8M_FULL;
    if (c->n_missing == 0) return I8M_NONE;
@@ -429,7 +430,7 @@ int i8_mode(const fpca_ctx *c, int b)
 // FPCA_SPARSE_SIDE_BYTES overrides the threshold (bytes gathered per stage).
 bool sparse_on_side_stream(const fpca_ctx *c, int b)
 {
-   static const double thr = getenv("FPCA_SPARSE_SIDE_BYTES") ? atof(getenv("FPCA_SPARSE_SIDE_BYTES")) : 2e9;
+   static const double thr = FPCA_TEST_ENV("FPCA_SPARSE_SIDE_BYTES") ? atof(FPCA_TEST_ENV("FPCA_SPARSE_SIDE_BYTES")) : 2e9;
    return (double)c->n_missing * b * 8.0 > thr;
 }
 
@@ -438,30 +439,32 @@ void ensure_sparse(fpca_ctx *c, int b)
 {
    hipStream_t s = c->stream;
    const size_t need = (size_t)std::max(c->N_pad, c->P_pad) * b;
+   if (FPCA_TEST_ENV("FPCA_DEBUG_SPARSE_NOMEM")) throw Error(FPCA_ENOMEM, "FPCA_DEBUG_SPARSE_NOMEM is set"); // exercises the fallback
    if (need > c->eplane_cap) {
       if (c->d_eplane) HIP_CHECK(hipFree(c->d_eplane));
       c->d_eplane = nullptr;
-      HIP_CHECK(hipMalloc(&c->d_eplane, need * sizeof(double)));
+      c->eplane_cap = 0;
+      HIP_ALLOC(hipMalloc(&c->d_eplane, need * sizeof(double)));
       c->eplane_cap = need;
    }
    if (c->sparse_ready) return;
-   {
+   if (!c->aux_stream) {
       int lo = 0, hi = 0; // lowest priority: the gather-sums should only fill what the GEMM's workgroups leave free
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       HIP_CHECK(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, lo));
+      HIP_CHECK(hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming));
    }
-   HIP_CHECK(hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming));
-   HIP_CHECK(hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming));
    const uint64_t nnz = c->n_missing;
    std::vector<uint32_t> ptr(c->P_g + 1, 0);
    for (uint64_t j = 0; j < c->P_g; j++) ptr[j + 1] = ptr[j] + c->h_nmiss[j];
-   HIP_CHECK(hipMalloc(&c->d_snp_ptr, (c->P_g + 1) * sizeof(uint32_t)));
-   HIP_CHECK(hipMalloc(&c->d_snp_idx, std::max<uint64_t>(nnz, 1) * sizeof(uint32_t)));
+   HIP_ALLOC(hipMalloc(&c->d_snp_ptr, (c->P_g + 1) * sizeof(uint32_t)));
+   HIP_ALLOC(hipMalloc(&c->d_snp_idx, std::max<uint64_t>(nnz, 1) * sizeof(uint32_t)));
    HIP_CHECK(hipMemcpyAsync(c->d_snp_ptr, ptr.data(), (c->P_g + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
    kern::fill_missing(c->d_packed, c->pitch, c->N, c->P_g, c->d_snp_ptr, c->d_snp_idx, s);
    HIP_CHECK(hipStreamSynchronize(s)); // ptr is reused below
    uint32_t *d_cnt = nullptr;
-   HIP_CHECK(hipMalloc(&d_cnt, c->N * sizeof(uint32_t)));
+   HIP_ALLOC(hipMalloc(&d_cnt, c->N * sizeof(uint32_t)));
    kern::count_missing(c->d_packedT, c->pitchT, c->P_g, c->N, d_cnt, s);
    std::vector<uint32_t> cnt(c->N);
    HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, c->N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -470,12 +473,37 @@ void ensure_sparse(fpca_ctx *c, int b)
    ptr.assign(c->N + 1, 0);
    for (uint64_t i = 0; i < c->N; i++) ptr[i + 1] = ptr[i] + cnt[i];
    if (ptr[c->N] != nnz) throw Error(FPCA_EHIP, "missing-call counts by sample and by SNP disagree");
-   HIP_CHECK(hipMalloc(&c->d_smp_ptr, (c->N + 1) * sizeof(uint32_t)));
-   HIP_CHECK(hipMalloc(&c->d_smp_idx, std::max<uint64_t>(nnz, 1) * sizeof(uint32_t)));
+   HIP_ALLOC(hipMalloc(&c->d_smp_ptr, (c->N + 1) * sizeof(uint32_t)));
+   HIP_ALLOC(hipMalloc(&c->d_smp_idx, std::max<uint64_t>(nnz, 1) * sizeof(uint32_t)));
    HIP_CHECK(hipMemcpyAsync(c->d_smp_ptr, ptr.data(), (c->N + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
    kern::fill_missing(c->d_packedT, c->pitchT, c->P_g, c->N, c->d_smp_ptr, c->d_smp_idx, s);
    HIP_CHECK(hipStreamSynchronize(s));
    c->sparse_ready = true;
+}
+
+// The sparse route needs 8 bytes per missing call (1.8 GB at 500k x 100k and 0.45 %) plus one N x b plane.  If that does not
+// fit, the context takes the dense missing-indicator route (both integer matrices on the matrix cores) from here on --
+// out-of-memory only; any other failure is reported.  Returns the mode to use.
+int sparse_or_dense(fpca_ctx *c, int b)
+{
+   try {
+      ensure_sparse(c, b);
+      return I8M_SPARSE;
+   } catch (const Error &e) {
+      if (e.code != FPCA_ENOMEM) throw;
+      (void)hipGetLastError();
+      std::fprintf(stderr, "[fpca] the missing-call index lists do not fit in device memory (%s); using the dense missing-indicator route\n", e.what());
+      void **ptrs[] = {(void **)&c->d_snp_ptr, (void **)&c->d_snp_idx, (void **)&c->d_smp_ptr, (void **)&c->d_smp_idx, (void **)&c->d_eplane};
+      for (void **p : ptrs)
+         if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+         }
+      c->eplane_cap = 0;
+      c->sparse_ready = false;
+      c->sparse_failed = true;
+      return i8_mode(c, b);
+   }
 }
 
 kern::SliceOp i8_op_b(fpca_ctx *c)
@@ -505,9 +533,9 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipE
    hipEvent_t wait = nullptr;
    kern::i8_colmax(dB, c->N, b, 1, &ob, s);
    kern::i8_slice(dB, c->N_pad, c->N, b, c->i8_S, 1, &ob, s);
+   if (mode == I8M_SPARSE) mode = sparse_or_dense(c, b);
    if (mode == I8M_SPARSE) { // E'B: for every SNP the sum of the B rows of its missing samples, on the (low-priority) side
-      ensure_sparse(c, b);  // stream, released together with the GEMM
-      if (sparse_on_side_stream(c, b)) {
+      if (sparse_on_side_stream(c, b)) { // stream, released together with the GEMM
          HIP_CHECK(hipEventRecord(c->ev_aux_go, s));
          HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_aux_go, 0));
          kern::sparse_rows_sum(c->d_snp_ptr, c->d_snp_idx, dB, nullptr, b, c->P_g, c->P_pad, c->d_eplane, c->aux_stream);
@@ -530,7 +558,7 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipE
 int ar_chunks(const fpca_ctx *c)
 {
    if (!c->comm || c->ar_fn || !c->comm_stream) return 1;
-   const char *env = getenv("FPCA_AR_CHUNKS"); // read on every call: the tests switch it between contexts
+   const char *env = FPCA_TEST_ENV("FPCA_AR_CHUNKS"); // read on every call: the tests switch it between contexts
    int n = c->N_pad >= 400000 ? 4 : c->N_pad >= 200000 ? 2 : 1;
    if (env && atoi(env) >= 1) n = std::min(atoi(env), 4);
    while (n > 1 && c->N_pad / n < 512) n--;
@@ -549,11 +577,11 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_
    kern::SliceOp ot[2];
    i8_ops_t(c, ot);
    int mode = i8_mode(c, b);
+   if (mode == I8M_SPARSE) mode = sparse_or_dense(c, b);
    if (do_slice) {
       if (!have_max) kern::i8_colmax(c->d_T, c->P_g, b, 2, ot, s);
       kern::i8_slice(c->d_T, c->P_pad, c->P_g, b, c->i8_S, 2, ot, s);
       if (mode == I8M_SPARSE) { // E (mean T / sd): for every sample the sum of the scaled T rows of its missing SNPs
-         ensure_sparse(c, b);
          if (sparse_on_side_stream(c, b)) {
             HIP_CHECK(hipEventRecord(c->ev_aux_go, s)); // T is complete on s here (and the K2 combine has consumed the plane)
             HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_aux_go, 0));

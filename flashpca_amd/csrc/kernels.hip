@@ -242,11 +242,7 @@ __device__ __forceinline__ void lds_put2(float *base, int idx, d2 v)
    reinterpret_cast<f2 *>(base)[idx] = (f2){(float)v.x, (float)v.y};
 }
 
-static int env_int(const char *name, int dflt)
-{
-   const char *e = getenv(name);
-   return e && *e ? atoi(e) : dflt;
-}
+#define FPCA_ENV_INT(name, dflt) ((FPCA_TEST_ENV(name) && *FPCA_TEST_ENV(name)) ? atoi(FPCA_TEST_ENV(name)) : (dflt))
 
 // ------------------------------------------------------------------------------------------------
 // K2 xt_b:  T[snp][c] = sum_s X[s][snp] B[s][c]
@@ -398,7 +394,7 @@ int xt_b_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32)
 {
    const int kc = b <= 32 ? 128 : 64;
    const int tile = (fp32 && b >= 48) ? 128 : 256;
-   static const int forced = env_int("FPCA_XT_SPLITS", 0);
+   static const int forced = FPCA_ENV_INT("FPCA_XT_SPLITS", 0);
    if (forced > 0) return (int)std::min<uint64_t>(forced, N_pad / kc);
    // fp64 with b <= 32 needs 145 VGPRs and 40 KB of LDS: three workgroups per CU are resident
    const uint64_t slots = (!fp32 && b <= 32) ? 768 : 512;
@@ -586,7 +582,7 @@ static inline int x_t_kc(int b, bool fp32) { return (fp32 && b >= 48) ? 32 : 64;
 
 int x_t_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32)
 {
-   static const int forced = env_int("FPCA_X_SPLITS", 0);
+   static const int forced = FPCA_ENV_INT("FPCA_X_SPLITS", 0);
    if (forced > 0) return (int)std::min<uint64_t>(forced, P_pad / x_t_kc(b, fp32));
    return pick_splits(N_pad / (64 * x_t_mt(b, fp32)), P_pad / x_t_kc(b, fp32), 4, 64, 512);
 }

@@ -706,7 +706,7 @@ struct I8Plan {
 
 static I8Plan i8_plan(uint64_t rows_pad, uint64_t k_pad, const I8Shape &sh, int bw)
 {
-   static const char *env_s = getenv("FPCA_I8_SPLITS"); // force plain split-K with this factor
+   static const char *env_s = FPCA_TEST_ENV("FPCA_I8_SPLITS"); // force plain split-K with this factor
    static int ncu = 0;
    if (!ncu) {
       hipDeviceProp_t prop;
@@ -747,7 +747,7 @@ static I8Plan i8_plan(uint64_t rows_pad, uint64_t k_pad, const I8Shape &sh, int 
    p.rowB0 = std::min<uint64_t>((uint64_t)qA * 8 * sh.rows, rows_pad);
    p.rowsB = rows_pad - p.rowB0;
    p.grid = (unsigned)(p.nA + (ids - p.nA) * p.sB);
-   static const bool verbose = getenv("FPCA_I8_VERBOSE") != nullptr;
+   static const bool verbose = FPCA_TEST_ENV("FPCA_I8_VERBOSE") != nullptr;
    if (verbose)
       std::fprintf(stderr, "[fpca] int8 GEMM plan: rows %llu K %llu tile %dx%d zb %d -> %d tile ids, %d chunks; %d unsplit + %d tiles x %d splits (%d chunks each), %u workgroups, est %.3f ms\n",
                    (unsigned long long)rows_pad, (unsigned long long)k_pad, sh.rows, sh.cols, sh.zb, ids, chunks, p.nA, ids - p.nA, p.sB, p.cpsB, p.grid,
@@ -824,7 +824,7 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
       }
    } else if (mode == I8_NO_MISSING) {
 #ifdef FPCA_I8_ABLATION
-      static const char *abl = getenv("FPCA_I8_ABL");
+      static const char *abl = FPCA_TEST_ENV("FPCA_I8_ABL");
       const int ab = abl ? atoi(abl) : 0;
 #define FPCA_I8_AB(A_) launch_i8<I8Cfg<false, 2, 7, 4, 1, 256, 1, I8_NO_MISSING, A_>>(FPCA_I8_ARGS)
       if (ab && sh.nt == 7) {
@@ -1080,7 +1080,7 @@ void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, 
    // factor per entry), nothing off the K2 one and costs it 6-50 us at the small sizes -- so K3 (rowscale given) takes the
    // batched kernel, K2 the plain one.  Both sit at ~7 TB/s out of the Infinity Cache; with the gathered matrix resident in
    // L2 the same kernel reaches 9.4 TB/s (scripts/gather_l2_probe.py), which is all an L2-blocked gather order could win.
-   static const int forced = getenv("FPCA_GATHER") ? atoi(getenv("FPCA_GATHER")) : 0; // 1 / 2 force one kernel (A/B)
+   static const int forced = FPCA_TEST_ENV("FPCA_GATHER") ? atoi(FPCA_TEST_ENV("FPCA_GATHER")) : 0; // 1 / 2 force one kernel (A/B)
    const int variant = forced ? forced : (rowscale ? 2 : 1);
 #define FPCA_GATHER_CASE(B_)                                                                                                    \
    case B_:                                                                                                                     \

@@ -39,7 +39,18 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
    const int k = o.ndim;
    SolverOpts so;
    so.k = k;
-   so.max_applies = o.maxiter > 0 ? o.maxiter : 500;
+   // --maxiter counts what the reference counts: restarts of Spectra's ncv = 2k+1 factorisation (flashpca.cpp:423-433,
+   // randompca.cpp:178).  Its budget of operator applications -- 2k+1 for the first factorisation, at most k+1 per restart
+   // (op count = 1 + (ncv-1) + sum over restarts of (ncv - nev_adjusted)) -- is spent here b at a time.
+   {
+      const long long mi = o.maxiter > 0 ? o.maxiter : 500;
+      const long long ops = 2LL * k + 1 + mi * (k + 1LL), b = be.width();
+      so.max_applies = (int)std::min<long long>((ops + b - 1) / b, 1LL << 30);
+      if (o.max_applies > 0) so.max_applies = o.max_applies; // explicit cap in block applies (tests, bench warm-up)
+      if ((long long)so.max_applies * b < k)
+         throw Error(FPCA_EINVAL, "max_applies = " + std::to_string(so.max_applies) + " block applies of " + std::to_string((int)b) +
+                                      " columns give fewer basis vectors than the " + std::to_string(k) + " eigenpairs asked for");
+   }
    so.tol = o.tol > 0 ? o.tol : 1e-6;
    so.max_blocks = o.max_blocks;
    // basis cap when the caller leaves it open: the projected eigenproblem costs O((cap b)^3) on the host at every restart

@@ -179,8 +179,8 @@ SolverResult dense_small(BlockBackend &be, const SolverOpts &o)
    }
    res.converged = true;
    res.seconds_host = since(t0);
-   if (o.verbose) std::fprintf(stderr, "[fpca] %llu samples < 3 x block width %d: dense eigendecomposition of X X' (%d applies)\n",
-                               (unsigned long long)N, b, res.block_applies);
+   if (o.verbose) std::fprintf(stderr, "[fpca] %llu samples leave no room for a Krylov basis of %d-column blocks holding %d Ritz vectors: dense eigendecomposition of X X' (%d applies)\n",
+                               (unsigned long long)N, b, k, res.block_applies);
    return res;
 }
 

@@ -174,13 +174,19 @@ typedef struct fpca_pca_opts {
                      * narrowest block gives the shortest time to solution (pca_driver.cpp).  ndim may exceed b -- up to the
                      * reference's (min(N,P)-1)/2 --: the solver then carries ceil(ndim/b) + 1 blocks of Ritz vectors across
                      * restarts */
-   int maxiter;     /* maximum block applies (reference: 500 restarts, flashpca.cpp:426) */
+   int maxiter;     /* --maxiter, counted like the reference counts it: restarts of Spectra's ncv = 2 ndim + 1 Lanczos
+                     * factorisation (flashpca.cpp:423-433 default 500, randompca.cpp:178 compute(maxiter, tol)).  A restart
+                     * re-applies the operator to at most ndim + 1 vectors, so the reference's budget is
+                     * 2 ndim + 1 + maxiter (ndim + 1) operator applications; the block solver stops after
+                     * ceil(that / b) block applies (b vector operations each) -- the same budget in the same unit */
    double tol;      /* --tol (flashpca.cpp:440 default 1e-6) */
    int divisor;     /* FPCA_DIVISOR_* (flashpca.cpp:484 default p) */
    int do_loadings; /* --outload given */
    int max_blocks;  /* basis cap in blocks before a thick restart; 0 = automatic */
    int verbose;
    uint64_t seed;   /* start block seed; the reference ignores --seed for PCA (randompca.cpp:168-218) */
+   int max_applies; /* hard cap on block applies, overriding the budget derived from maxiter; 0 = none.  Must allow at least
+                     * ceil(ndim / b) of them (FPCA_EINVAL otherwise: fewer basis vectors than wanted pairs) */
 } fpca_pca_opts;
 
 typedef struct fpca_pca_info {

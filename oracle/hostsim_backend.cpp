@@ -128,6 +128,7 @@ class HostSimBackend : public fpca::BlockBackend {
 extern "C" {
 
 /* Runs the product's block Krylov-Schur driver on this rank's shard `d` (an oracle Data object).
+ * maxiter > 0: --maxiter as the reference counts it (fpca_pca_opts.maxiter); maxiter < 0: fpca_pca_opts.max_applies = -maxiter.
  * info_out: [converged, block_applies, restarts, blockvec].  Returns FPCA_OK / FPCA_ENOTCONVERGED / <0. */
 int hostsim_pca(orc_data *d, int ndim, int blockvec, int maxiter, double tol, int divisor, int max_blocks,
                 uint64_t seed, int verbose, uint64_t P_total, hostsim_allreduce_fn ar, void *user, double *U,
@@ -140,7 +141,11 @@ int hostsim_pca(orc_data *d, int ndim, int blockvec, int maxiter, double tol, in
       std::memset(&o, 0, sizeof(o));
       o.ndim = ndim;
       o.blockvec = b;
-      o.maxiter = maxiter;
+      o.maxiter = maxiter; // the reference's unit (restarts); a NEGATIVE value is a hard cap of -maxiter block applies
+      if (maxiter < 0) {
+         o.maxiter = 500;
+         o.max_applies = -maxiter;
+      }
       o.tol = tol;
       o.divisor = divisor;
       o.max_blocks = max_blocks;

@@ -1,5 +1,6 @@
 """Cost of computing K3 in row chunks with the all-reduce on a second stream (nranks = 1: the all-reduce is a copy)."""
 import json, os, subprocess, sys
+os.environ.setdefault("FPCA_LIB", "testhooks")  # the environment switches this script drives exist only in the -DFPCA_TEST_HOOKS build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
 import sys, json

@@ -1,6 +1,7 @@
 """Randomised parity sweep (GPU): exact-integer path vs fp64 MFMA path vs dense numpy on random shapes, block widths,
 slice counts, missing-call rates and forced missing-indicator modes.  python scripts/fuzz_parity.py [cases] [seed]"""
 import os, sys, time
+os.environ.setdefault("FPCA_LIB", "testhooks")  # the environment switches this script drives exist only in the -DFPCA_TEST_HOOKS build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import flashpca_amd as fp

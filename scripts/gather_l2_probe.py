@@ -2,6 +2,7 @@
 sparse route forced: the K2 gather reads rows of B (L2-resident), the K3 gather rows of T (256 MB: Infinity Cache / HBM).  Run under
 rocprofv3 --kernel-trace --stats and compare the two k_sparse_rows_sum averages (same number of gathered rows each)."""
 import os, sys
+os.environ.setdefault("FPCA_LIB", "testhooks")  # the environment switches this script drives exist only in the -DFPCA_TEST_HOOKS build
 os.environ["FPCA_I8_MODE"] = "3"
 sys.path.insert(0, ".")
 import flashpca_amd as fp

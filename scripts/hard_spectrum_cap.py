@@ -7,7 +7,7 @@ for name in (sys.argv[1:] or ["cfg3"]):
     N, P = cfgs[name]
     with fp.Context.synthetic(N, P, n_pop=4, accum="auto") as ctx:
         ctx.stats()
-        ctx.pca(ndim=20, allow_unconverged=True, maxiter=2)
+        ctx.pca(ndim=20, allow_unconverged=True, max_applies=4)
         for mb in [int(x) for x in __import__("os").environ.get("MBS", "0,8,12,16,24,32,48").split(",")]:
             t0 = time.perf_counter()
             r = ctx.pca(ndim=20, allow_unconverged=True, max_blocks=mb)

@@ -8,7 +8,7 @@ for name in (sys.argv[1:] or ["cfg3"]):
     with fp.Context.synthetic(N, P, n_pop=4, accum="auto") as ctx:
         ctx.stats()
         for bv in [int(x) for x in __import__("os").environ.get("BVS", "32,64,48").split(",")]:
-            ctx.pca(ndim=20, allow_unconverged=True, maxiter=2, blockvec=bv)
+            ctx.pca(ndim=20, allow_unconverged=True, max_applies=4, blockvec=bv)
             t0 = time.perf_counter()
             r = ctx.pca(ndim=20, allow_unconverged=True, blockvec=bv)
             dt = time.perf_counter() - t0

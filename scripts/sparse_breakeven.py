@@ -2,6 +2,7 @@
 0.1 ... 4 %, route forced sparse (FPCA_I8_MODE=3) and dense (0); each point in its own process (the mode is read per call,
 the context set-up is not)."""
 import os, subprocess, sys
+os.environ.setdefault("FPCA_LIB", "testhooks")  # the environment switches this script drives exist only in the -DFPCA_TEST_HOOKS build
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import flashpca_amd as fp

@@ -1,6 +1,7 @@
 """Kernel tuning harness: time K2 (xt_b) and K3 (x_t) separately through fpca_bench_apply under env-var variants."""
 import json
 import os
+os.environ.setdefault("FPCA_LIB", "testhooks")  # the environment switches this script drives exist only in the -DFPCA_TEST_HOOKS build
 import subprocess
 import sys
 

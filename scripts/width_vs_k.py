@@ -11,7 +11,7 @@ for name in (sys.argv[1:] or ["cfg3"]):
             with fp.Context.synthetic(N, P, n_pop=(min(2 * k, 64) if npop == 0 else npop), accum="auto") as ctx:
                 ctx.stats()
                 for bv in (16, 32, 64):
-                    ctx.pca(ndim=k, allow_unconverged=True, maxiter=2, blockvec=bv)
+                    ctx.pca(ndim=k, allow_unconverged=True, max_applies=4, blockvec=bv)
                     t0 = time.perf_counter()
                     r = ctx.pca(ndim=k, allow_unconverged=True, blockvec=bv)
                     dt = time.perf_counter() - t0

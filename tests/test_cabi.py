@@ -56,6 +56,29 @@ def test_product_never_touches_the_oracle():
     assert "oracle" not in out and "hostsim" not in out
 
 
+def test_shipped_binaries_carry_no_test_switches(built_lib):
+    """The environment switches the tests drive (forced missing-indicator modes and split plans, allocation-failure
+    injection, the CLI launcher's host-memory transport and failure injection) are compiled into the -DFPCA_TEST_HOOKS build
+    only (csrc/common.hpp: FPCA_TEST_ENV): their names must not even occur in the shipped library / CLI."""
+    import flashpca_amd as fp
+
+    names = [b"FPCA_CLI_TEST", b"FPCA_DEBUG_", b"FPCA_I8_MODE", b"FPCA_I8_SPLITS", b"FPCA_I8_ABL", b"FPCA_GATHER", b"FPCA_AR_CHUNKS",
+             b"FPCA_SPARSE_SIDE_BYTES", b"FPCA_XT_SPLITS", b"FPCA_X_SPLITS", b"FPCA_I8_VERBOSE"]
+    for path in (fp.LIB_PATH, fp.CLI_PATH):
+        if os.environ.get("FPCA_LIB"):
+            pytest.skip("FPCA_LIB overrides the shipped library")
+        blob = open(path, "rb").read()
+        for n in names:
+            assert n not in blob, (path, n)
+    hooks = open(fp.HOOKS_LIB_PATH, "rb").read() + open(fp.HOOKS_CLI_PATH, "rb").read()
+    for n in (b"FPCA_CLI_TEST_TRANSPORT", b"FPCA_CLI_TEST_KILL_RANK", b"FPCA_I8_MODE", b"FPCA_AR_CHUNKS", b"FPCA_DEBUG_I8_NOMEM"):
+        assert n in hooks, n
+    # both builds export the same ABI
+    L = C.CDLL(fp.HOOKS_LIB_PATH)
+    for n in declared_functions():
+        assert hasattr(L, n), n
+
+
 def test_no_cpu_fallback(built_lib):
     """Without a usable gfx950 device every constructor fails loudly with FPCA_ENODEVICE."""
     import flashpca_amd as fp
@@ -80,6 +103,7 @@ def test_default_opts_match_reference_cli(built_lib):
     fp.lib().fpca_pca_default_opts(C.byref(o))
     # flashpca.cpp:325 (ndim 10), :426 (maxiter 500), :440 (tol 1e-6), :484 (div p), :276 (seed 1)
     assert (o.ndim, o.maxiter, o.tol, o.divisor, o.seed) == (10, 500, 1e-6, 2, 1)
+    assert o.max_applies == 0  # no cap beyond the budget --maxiter implies
 
 
 def test_gemm_kernels_do_not_spill():

@@ -44,6 +44,34 @@ def test_cli_flag_errors(built_lib):
     assert r.stdout.startswith("arguments: flashpca ")
 
 
+def test_cli_option_prefixes(built_lib):
+    """po::parse_command_line (flashpca.cpp:97) runs with boost's default style, which includes allow_guessing: an
+    unambiguous prefix of a long option selects it, the full name always wins, an ambiguous prefix is a parse error
+    (reported like every parse error: message, "Use --help", exit status 0 -- flashpca.cpp:100-106)."""
+    r = run(["--bf", DATA, "--notime", "--nd", "0"])  # --bfile, --ndim
+    assert r.returncode == 1 and "--ndim can't be less than 1" in r.stderr
+    r = run(["--bfile", DATA, "--not", "--outl", "l.txt", "--prec", "1"])  # --notime, --outload, --precision
+    assert r.returncode == 1 and "output --precision too low" in r.stderr
+    r = run(["--bfile", DATA, "--notime", "--outp", "x"])  # outpc, outpcx, outpcy, outpve, outproj
+    assert r.returncode == 0 and "Use --help to get more help" in r.stderr
+    assert "option '--outp' is ambiguous and matches '--outpc', '--outpcx', '--outpcy', '--outpve', and '--outproj'" in r.stderr
+    r = run(["--bfile", DATA, "--notime", "--outpc", "x", "--nd", "0"])  # a full name is never ambiguous (outpc / outpcx / outpcy)
+    assert r.returncode == 1 and "--ndim can't be less than 1" in r.stderr
+    r = run(["--b", DATA])  # batch, blocksize, bed, bim, bfile
+    assert r.returncode == 0 and "is ambiguous and matches '--batch', '--blocksize', '--bed', '--bim', and '--bfile'" in r.stderr
+    r = run(["--stand", "binom"])
+    assert r.returncode == 0 and "ambiguous and matches '--standx' and '--standy'" in r.stderr
+    # options this build adds are matched by their full names only, so that the reference's abbreviations keep their
+    # meaning: --de is the reference's --debug, --max its --maxiter (not --device / --maxblocks)
+    r = run(["--bfile", DATA, "--notime", "--de", "--max", "0"])
+    assert r.returncode == 1 and "--maxiter can't be less than 1" in r.stderr
+    r = run(["--bfile", DATA, "--notime", "--dev", "0"])
+    assert r.returncode == 0 and "unrecognised option '--dev'" in r.stderr
+    # CCA-only options of the reference are accepted (and ignored) like any other registered option
+    r = run(["--bfile", DATA, "--notime", "--lambda1", "0.1", "--outpcx", "a", "--save-vinit", "--ndim", "0"])
+    assert r.returncode == 1 and "--ndim can't be less than 1" in r.stderr
+
+
 @pytest.mark.gpu
 def test_cli_end_to_end(tmp_path, built_lib):
     g = json.load(open(DATA.replace("data_chr1", "golden_data_chr1_binom2.json")))
@@ -139,7 +167,8 @@ def test_cli_gpus_launcher(tmp_path, built_lib, golden_dir):
     for g, env_extra in ((1, {}), (2, {"FPCA_CLI_TEST_TRANSPORT": "shm"}), (3, {"FPCA_CLI_TEST_TRANSPORT": "shm"})):
         d = tmp_path / ("g%d" % g)
         d.mkdir()
-        args = [fp.CLI_PATH] + base + (["--gpus", str(g)] if g > 1 else [])
+        # (the host-memory transport exists only in the -DFPCA_TEST_HOOKS build of the CLI; g = 1 is the shipped binary)
+        args = [fp.HOOKS_CLI_PATH if g > 1 else fp.CLI_PATH] + base + (["--gpus", str(g)] if g > 1 else [])
         r = subprocess.run(args, cwd=d, capture_output=True, text=True, env=dict(os.environ, **env_extra), timeout=300)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         assert r.stdout.count("Goodbye!") == 1 and r.stdout.count("PCA done") == 1  # only rank 0 talks
@@ -176,13 +205,13 @@ def test_cli_gpus_launcher_failures_do_not_hang(tmp_path, built_lib, golden_dir)
     env = dict(os.environ, FPCA_CLI_TEST_TRANSPORT="shm")
     for victim, text in (("1", "died unexpectedly"), ("2", "died unexpectedly"), ("0", "injected failure of rank 0")):
         t0 = time.time()
-        r = subprocess.run([fp.CLI_PATH, "--bfile", data, "--ndim", "5", "--gpus", "3"], cwd=tmp_path, capture_output=True, text=True,
+        r = subprocess.run([fp.HOOKS_CLI_PATH, "--bfile", data, "--ndim", "5", "--gpus", "3"], cwd=tmp_path, capture_output=True, text=True,
                            env=dict(env, FPCA_CLI_TEST_KILL_RANK=victim), timeout=120)
         assert r.returncode == 1 and text in r.stderr, (victim, r.stdout[-800:], r.stderr[-800:])
         assert time.time() - t0 < 60
         assert not os.path.exists(tmp_path / "eigenvalues.txt")
     # refused before the fork: ndim limit, .bim / .bed mismatch when a file with SNP row names is asked for
-    r = subprocess.run([fp.CLI_PATH, "--bfile", data, "--ndim", "500", "--gpus", "3"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=60)
+    r = subprocess.run([fp.HOOKS_CLI_PATH, "--bfile", data, "--ndim", "500", "--gpus", "3"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=60)
     assert r.returncode == 1 and "You asked for 500 dimensions, but only 478allowed" in r.stderr
     import shutil
 
@@ -191,7 +220,7 @@ def test_cli_gpus_launcher_failures_do_not_hang(tmp_path, built_lib, golden_dir)
     lines = open(data + ".bim").read().splitlines(True)
     open(tmp_path / "mm.bim", "w").writelines(lines[:-7])
     for extra in ([], ["--gpus", "2"]):
-        r = subprocess.run([fp.CLI_PATH, "--bfile", str(tmp_path / "mm"), "--ndim", "5", "--outload", "l.txt"] + extra, cwd=tmp_path,
+        r = subprocess.run([fp.HOOKS_CLI_PATH, "--bfile", str(tmp_path / "mm"), "--ndim", "5", "--outload", "l.txt"] + extra, cwd=tmp_path,
                            capture_output=True, text=True, env=env, timeout=60)
         assert r.returncode == 1 and "different number of SNPs" in r.stderr
         assert not os.path.exists(tmp_path / "eigenvalues.txt")  # nothing was computed or written first

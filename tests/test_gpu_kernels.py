@@ -363,14 +363,36 @@ def test_auto_mode_falls_back_to_fp64_when_buffers_do_not_fit(fp, monkeypatch):
     with fp.Context.synthetic(N, P, n_pop=6, accum="fp64") as ref:
         Z0 = ref.apply_xxt(B)
     monkeypatch.setenv("FPCA_DEBUG_I8_NOMEM", "1")
-    with fp.Context.synthetic(N, P, n_pop=6, accum="auto") as c:
-        assert c.accum == "i8x7"
+    with fp.Context.synthetic(N, P, n_pop=6, accum="auto") as c:  # the shipped library has no such switch
         Z = c.apply_xxt(B)
-        assert c.accum == "fp64"
-        assert np.array_equal(Z, Z0)
-    with fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:
-        with pytest.raises(fp.FpcaError):
-            c.apply_xxt(B)
+        assert c.accum == "i8x7"
+    with fp.test_hooks():  # the -DFPCA_TEST_HOOKS build of the same sources
+        with fp.Context.synthetic(N, P, n_pop=6, accum="auto") as c:
+            assert c.accum == "i8x7"
+            Z = c.apply_xxt(B)
+            assert c.accum == "fp64"
+            assert np.array_equal(Z, Z0)
+        with fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:
+            with pytest.raises(fp.FpcaError):
+                c.apply_xxt(B)
+
+
+def test_sparse_missing_route_falls_back_when_its_lists_do_not_fit(golden_dir, fp, orc, monkeypatch):
+    """The sparse missing-indicator route needs 8 bytes per missing call; if those lists do not fit the context switches to
+    the dense route (both integer matrices on the matrix cores) and says so, instead of failing the apply."""
+    N = fp.count_fam_rows(os.path.join(golden_dir, "hapmap3_data.fam"))
+    bed = os.path.join(golden_dir, "hapmap3_data.bed")
+    X = orc.OracleData(bed, N, "binom2").dense()
+    B = np.random.default_rng(9).standard_normal((N, 16))
+    Z_ref = X @ (X.T @ B)
+    monkeypatch.setenv("FPCA_DEBUG_SPARSE_NOMEM", "1")
+    with fp.test_hooks(), fp.Context.from_bed(bed, N, accum="i8") as ctx:
+        assert ctx.missing_mode(16) == 3  # 0.15 % missing calls: the sparse route is the automatic choice
+        Z = ctx.apply_xxt(B)
+        assert ctx.missing_mode(16) in (0, 1) and ctx.accum == "i8x7"  # still the exact-integer path, dense indicator
+        assert np.max(np.abs(Z - Z_ref) / np.max(np.abs(Z_ref), axis=0)) <= 1e-11
+        Y = ctx.apply_x(X.T @ B)
+        assert np.max(np.abs(Y - Z_ref) / np.max(np.abs(Z_ref), axis=0)) <= 1e-11
 
 
 @pytest.mark.parametrize("nch", [1, 2, 3, 4])
@@ -381,7 +403,7 @@ def test_overlapped_allreduce_row_chunks(fp, monkeypatch, nch):
     with fp.Context.synthetic(N, P, n_pop=6, accum="i8") as ref:
         Z0 = ref.apply_xxt(B)
     monkeypatch.setenv("FPCA_AR_CHUNKS", str(nch))
-    with fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:
+    with fp.test_hooks(), fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:
         c.comm_init_rank(1, 0, fp.Context.comm_unique_id())
         assert c.allreduce_chunks() == nch  # the setting reached the library (it is read per call, not cached)
         for _ in range(3):
@@ -423,20 +445,21 @@ def test_i8_forced_missing_modes(golden_dir, fp, orc, monkeypatch, mode):
     monkeypatch.setenv("FPCA_I8_MODE", mode)
     N = fp.count_fam_rows(os.path.join(golden_dir, "hapmap3_data.fam"))
     bed = os.path.join(golden_dir, "hapmap3_data.bed")
-    ctx = fp.Context.from_bed(bed, N, accum="i8")
     od = orc.OracleData(bed, N, "binom2")
     X = od.dense()
-    for b in (32, 64, 16, 5):
-        assert ctx.missing_mode(b) == int(mode)  # HapMap3 has 0.15 % missing calls: every forced path applies
-        B = np.random.default_rng(3).standard_normal((N, b))
-        T_ref = X.T @ B
-        assert np.max(np.abs(ctx.apply_xt(B) - T_ref) / np.max(np.abs(T_ref), axis=0)) <= 1e-11
-        Z_ref = X @ T_ref
-        assert np.max(np.abs(ctx.apply_xxt(B) - Z_ref) / np.max(np.abs(Z_ref), axis=0)) <= 1e-11
-    Tin = np.random.default_rng(4).standard_normal((ctx.P, 32))
-    Y_ref = X @ Tin
-    assert np.max(np.abs(ctx.apply_x(Tin) - Y_ref) / np.max(np.abs(Y_ref), axis=0)) <= 1e-11
-    ctx.close()
+    with fp.Context.from_bed(bed, N, accum="i8") as shipped:  # the product ignores the variable: its own choice (sparse)
+        assert shipped.missing_mode(32) == 3
+    with fp.test_hooks(), fp.Context.from_bed(bed, N, accum="i8") as ctx:
+        for b in (32, 64, 16, 5):
+            assert ctx.missing_mode(b) == int(mode)  # HapMap3 has 0.15 % missing calls: every forced path applies
+            B = np.random.default_rng(3).standard_normal((N, b))
+            T_ref = X.T @ B
+            assert np.max(np.abs(ctx.apply_xt(B) - T_ref) / np.max(np.abs(T_ref), axis=0)) <= 1e-11
+            Z_ref = X @ T_ref
+            assert np.max(np.abs(ctx.apply_xxt(B) - Z_ref) / np.max(np.abs(Z_ref), axis=0)) <= 1e-11
+        Tin = np.random.default_rng(4).standard_normal((ctx.P, 32))
+        Y_ref = X @ Tin
+        assert np.max(np.abs(ctx.apply_x(Tin) - Y_ref) / np.max(np.abs(Y_ref), axis=0)) <= 1e-11
 
 
 def test_randomised_parity_sweep(built_lib):

@@ -203,8 +203,17 @@ def test_more_components_than_the_block_width_few_samples():
 def test_not_converged_is_reported(golden_dir):
     N = O.count_fam_rows(os.path.join(golden_dir, "data_chr1.fam"))
     d = O.OracleData(os.path.join(golden_dir, "data_chr1.bed"), N, "binom2")
-    rc, r = run_pca(d, 10, maxiter=2)
+    rc, r = run_pca(d, 10, maxiter=-2)  # (negative: a hard cap in block applies, fpca_pca_opts.max_applies)
     assert rc == -5 and r["converged"] == 0 and r["applies"] == 2  # FPCA_ENOTCONVERGED (randompca.cpp:212-217)
+    assert r["d"][0] > 0 and np.all(np.diff(r["d"]) <= 0)  # outputs hold the current Ritz pairs (pca_driver.hpp)
+    # --maxiter counts the reference's restarts (flashpca.cpp:423-433): a budget of 2k+1 + maxiter (k+1) operator
+    # applications = ceil(that / b) block applies -- k = 10, b = 16: maxiter 1 -> 32 -> 2, maxiter 2 -> 43 -> 3
+    for mi, applies in ((1, 2), (2, 3)):
+        rc, r = run_pca(d, 10, maxiter=mi)
+        assert rc == -5 and r["applies"] == applies, (mi, r["applies"])
+    # a cap that cannot even hold k basis vectors is refused up front (nothing half-filled comes back)
+    rc, r = run_pca(d, 40, blockvec=16, maxiter=-2)
+    assert rc == -1 and r["applies"] == 0 and not r["d"].any()
     rc, r = run_pca(d, 10, blockvec=24)
     assert rc == -1  # FPCA_EINVAL
 
