@@ -55,6 +55,8 @@ class PcaInfo(C.Structure):
         ("seconds_ortho", C.c_double),
         ("seconds_host", C.c_double),
         ("seconds_total", C.c_double),
+        ("seconds_download", C.c_double),
+        ("seconds_post", C.c_double),
     ]
 
 
@@ -114,6 +116,7 @@ SIGNATURES = {
     "fpca_debug_mfma_i8_probe": (_I, [_P, _P, _P]),
     "fpca_debug_mfma_peak": (_I, [_I, _I, _I, C.POINTER(_D)]),
     "fpca_debug_census": (_I, [_I, _U64, _P]),
+    "fpca_debug_k4": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P]),
 }
 
 _lib = None

@@ -7,6 +7,7 @@
 // solver and the multi-rank sharding logic on machines without a GPU (gloo tests); it is never linked
 // into libfpca.so.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 
 namespace fpca {
@@ -32,6 +33,19 @@ class BlockBackend {
    // first ncols columns of a block <-> host column-major N x ncols
    virtual void download(int h, int ncols, double *host, int64_t ld) = 0;
    virtual void upload(int h, int ncols, const double *host, int64_t ld) = 0;
+   // download with the Px pass fused in: column c of the block goes to host[:, c] (if host) and, scaled by scale[c], to
+   // host2[:, c] (if host2) -- RandomPCA::Px = U diag(sqrt(d)) (randompca.cpp:207) without a second pass over U
+   virtual void download2(int h, int ncols, double *host, int64_t ld, double *host2, int64_t ld2, const double *scale)
+   {
+      const uint64_t N = nrows();
+      double *dst = host ? host : host2;
+      const int64_t ldd = host ? ld : ld2;
+      if (!dst) return;
+      download(h, ncols, dst, ldd);
+      if (host2)
+         for (int c = ncols - 1; c >= 0; c--) // (in place when host == nullptr)
+            for (uint64_t i = 0; i < N; i++) host2[i + (std::size_t)c * ld2] = dst[i + (std::size_t)c * ldd] * scale[c];
+   }
 
    // sum over ranks of the shard traces sum X^2 (svdwide.cpp:44-45, 60-61)
    virtual double trace() = 0;

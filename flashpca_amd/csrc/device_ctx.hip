@@ -147,7 +147,8 @@ struct fpca_ctx {
    double *be_C = nullptr, *be_gpart = nullptr;
    size_t be_C_cap = 0, be_gpart_cap = 0, be_pin_cap = 0;
    void *be_pin = nullptr;
-   void *dl_pin = nullptr; // pinned landing zone for small downloads (HipBackend::download)
+   void *dl_pin = nullptr; // pinned landing zone of every download (HipBackend::download2): 4 slots of 8 MB
+   hipEvent_t dl_ev[4] = {nullptr, nullptr, nullptr, nullptr};
    // communication
    ncclComm_t comm = nullptr;
    int nranks = 1, rank = 0;
@@ -265,6 +266,8 @@ void ctx_free(fpca_ctx *c)
    if (c->be_gpart) (void)hipFree(c->be_gpart);
    if (c->be_pin) (void)hipHostFree(c->be_pin);
    if (c->dl_pin) (void)hipHostFree(c->dl_pin);
+   for (hipEvent_t e : c->dl_ev)
+      if (e) (void)hipEventDestroy(e);
    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
    for (hipEvent_t e : c->ev_chunk)
       if (e) (void)hipEventDestroy(e);
@@ -731,7 +734,83 @@ void ensure_io(fpca_ctx *c)
 }
 
 // ---- HIP backend for the eigensolver ---------------------------------------------------------------
-constexpr size_t DL_PIN_BYTES = (size_t)32 << 20;
+constexpr size_t DL_CHUNK = (size_t)8 << 20, DL_SLOTS = 4, DL_PIN_BYTES = DL_CHUNK * DL_SLOTS;
+
+// Every result leaves the device through pinned memory of our own -- a direct copy into the caller's pageable buffer makes
+// the runtime register those pages for DMA, and when the caller later frees them (a Python loop dropping the previous
+// result) the invalidation stalls the next submission by 20-30 ms.  Large results (U: 80 MB at 500,000 x 20) are
+// pipelined: the column-major image is cut into DL_CHUNK-byte pieces that cycle through DL_SLOTS pinned slots; while piece
+// i+1 is on the wire, worker threads scatter piece i into the caller's U (memcpy) and Px (scaled copy, randompca.cpp:207)
+// -- first-touch page faults of fresh output arrays included, which is what a single-threaded copy spends its time on.
+// d_img: device, column-major N x ncols with leading dimension N.
+void staged_download(fpca_ctx *c_, const double *d_img, uint64_t N, int ncols, double *host, int64_t ld, double *host2, int64_t ld2,
+                  const double *scale)
+{
+   if ((!host && !host2) || N == 0 || ncols <= 0) return;
+   const size_t total = (size_t)N * ncols; // doubles
+   if (!c_->dl_pin) HIP_CHECK(hipHostMalloc(&c_->dl_pin, DL_PIN_BYTES, hipHostMallocDefault));
+   const double *pin = static_cast<const double *>(c_->dl_pin);
+   // flat range [lo, hi) of the image, whose first element sits at src: column by column into the caller's matrices
+   auto scatter = [&](size_t lo, size_t hi, const double *src) {
+      for (size_t i = lo; i < hi;) {
+         const size_t col = i / N, row = i - col * N, n = std::min(hi - i, (size_t)N - row);
+         if (host) std::memcpy(host + col * (size_t)ld + row, src, n * sizeof(double));
+         if (host2) {
+            const double sc = scale[col];
+            double *o = host2 + col * (size_t)ld2 + row;
+            for (size_t j = 0; j < n; j++) o[j] = src[j] * sc;
+         }
+         src += n;
+         i += n;
+      }
+   };
+   constexpr size_t CH = DL_CHUNK / sizeof(double);
+   if (total <= CH) {
+      HIP_CHECK(hipMemcpyAsync(c_->dl_pin, d_img, total * sizeof(double), hipMemcpyDeviceToHost, c_->stream));
+      HIP_CHECK(hipStreamSynchronize(c_->stream));
+      scatter(0, total, pin);
+      return;
+   }
+   for (hipEvent_t &e : c_->dl_ev)
+      if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+   const size_t nch = (total + CH - 1) / CH;
+   const int T = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+   std::atomic<size_t> ready(0); // pieces [0, ready) have landed in their slots
+   std::vector<std::atomic<int>> done(nch);
+   for (auto &x : done) x.store(0);
+   std::vector<std::thread> workers;
+   for (int t = 0; t < T; t++)
+      workers.emplace_back([&, t] {
+         for (size_t c = 0; c < nch; c++) {
+            while (ready.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+            const size_t c0 = c * CH, len = std::min(CH, total - c0);
+            const size_t lo = c0 + len * t / T, hi = c0 + len * (t + 1) / T;
+            scatter(lo, hi, pin + (c % DL_SLOTS) * CH + (lo - c0));
+            done[c].fetch_add(1, std::memory_order_release);
+         }
+      });
+   try {
+      for (size_t c = 0; c < nch; c++) {
+         const size_t slot = c % DL_SLOTS, c0 = c * CH, len = std::min(CH, total - c0);
+         if (c >= DL_SLOTS)
+            while (done[c - DL_SLOTS].load(std::memory_order_acquire) < T) std::this_thread::yield();
+         HIP_CHECK(hipMemcpyAsync(static_cast<char *>(c_->dl_pin) + slot * DL_CHUNK, d_img + c0, len * sizeof(double), hipMemcpyDeviceToHost,
+                                  c_->stream));
+         HIP_CHECK(hipEventRecord(c_->dl_ev[slot], c_->stream));
+         if (c >= 1) {
+            HIP_CHECK(hipEventSynchronize(c_->dl_ev[(c - 1) % DL_SLOTS]));
+            ready.store(c, std::memory_order_release);
+         }
+      }
+      HIP_CHECK(hipEventSynchronize(c_->dl_ev[(nch - 1) % DL_SLOTS]));
+   } catch (...) {
+      ready.store(nch, std::memory_order_release); // let the workers run out (what they copy is discarded with the error)
+      for (auto &w : workers) w.join();
+      throw;
+   }
+   ready.store(nch, std::memory_order_release);
+   for (auto &w : workers) w.join();
+}
 
 class HipBackend : public BlockBackend {
  public:
@@ -848,25 +927,13 @@ class HipBackend : public BlockBackend {
       kern::block_gemm(d_ptrs_, nq, d_C_, init >= 0 ? blocks_[init] : nullptr, blocks_[out], c_->N_pad, b_, c_->stream);
       sec_other_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
    }
-   void download(int h, int ncols, double *host, int64_t ld) override
+   void download(int h, int ncols, double *host, int64_t ld) override { download2(h, ncols, host, ld, nullptr, 0, nullptr); }
+   void download2(int h, int ncols, double *host, int64_t ld, double *host2, int64_t ld2, const double *scale) override
    {
+      if (!host && !host2) return;
       c_->ensure(c_->d_stage, c_->stage_cap, (size_t)c_->N * ncols);
       kern::block_to_colmajor(blocks_[h], c_->N, b_, ncols, c_->d_stage, c_->N, c_->stream);
-      const size_t bytes = (size_t)c_->N * ncols * sizeof(double);
-      if (bytes <= DL_PIN_BYTES) {
-         // small results go through a pinned buffer of our own: a direct copy makes the runtime register the caller's
-         // pages for DMA, and when the caller later frees them (a Python loop dropping the previous result) the
-         // invalidation stalls the next submission by 20-30 ms -- more than a whole solve at this size
-         if (!c_->dl_pin) HIP_CHECK(hipHostMalloc(&c_->dl_pin, DL_PIN_BYTES, hipHostMallocDefault));
-         HIP_CHECK(hipMemcpyAsync(c_->dl_pin, c_->d_stage, bytes, hipMemcpyDeviceToHost, c_->stream));
-         HIP_CHECK(hipStreamSynchronize(c_->stream));
-         for (int c = 0; c < ncols; c++)
-            std::memcpy(host + (size_t)c * ld, static_cast<const double *>(c_->dl_pin) + (size_t)c * c_->N, c_->N * sizeof(double));
-         return;
-      }
-      HIP_CHECK(hipMemcpy2DAsync(host, (size_t)ld * sizeof(double), c_->d_stage, c_->N * sizeof(double),
-                                 c_->N * sizeof(double), ncols, hipMemcpyDeviceToHost, c_->stream));
-      HIP_CHECK(hipStreamSynchronize(c_->stream));
+      staged_download(c_, c_->d_stage, c_->N, ncols, host, ld, host2, ld2, scale);
    }
    void upload(int h, int ncols, const double *host, int64_t ld) override
    {
@@ -1234,9 +1301,7 @@ int fpca_apply_xxt(fpca_ctx *ctx, const double *B, int64_t ldb, int b, double *Y
          kern::colmajor_to_block(ctx->d_stage, ctx->N, ctx->N, ctx->N_pad, bw, nc, ctx->d_io_a, ctx->stream);
          apply_xxt_dev(ctx, ctx->d_io_a, bw, ctx->d_io_b, ctx->stream, nullptr);
          kern::block_to_colmajor(ctx->d_io_b, ctx->N, bw, nc, ctx->d_stage, ctx->N, ctx->stream);
-         HIP_CHECK(hipMemcpy2DAsync(Y + (size_t)c0 * ldy, (size_t)ldy * sizeof(double), ctx->d_stage, ctx->N * sizeof(double),
-                                    ctx->N * sizeof(double), nc, hipMemcpyDeviceToHost, ctx->stream));
-         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+         staged_download(ctx, ctx->d_stage, ctx->N, nc, Y + (size_t)c0 * ldy, ldy, nullptr, 0, nullptr); // (synchronises)
       }
    });
 }
@@ -1255,9 +1320,7 @@ int fpca_apply_xt(fpca_ctx *ctx, const double *B, int64_t ldb, int b, double *T,
          kern::colmajor_to_block(ctx->d_stage, ctx->N, ctx->N, ctx->N_pad, bw, nc, ctx->d_io_a, ctx->stream);
          xt_dev(ctx, ctx->d_io_a, bw, ctx->stream);
          kern::t_to_colmajor(ctx->d_T, ctx->P_g, bw, nc, nullptr, ctx->d_stage, ctx->P_g, ctx->stream);
-         HIP_CHECK(hipMemcpy2DAsync(T + (size_t)c0 * ldt, (size_t)ldt * sizeof(double), ctx->d_stage, ctx->P_g * sizeof(double),
-                                    ctx->P_g * sizeof(double), nc, hipMemcpyDeviceToHost, ctx->stream));
-         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+         staged_download(ctx, ctx->d_stage, ctx->P_g, nc, T + (size_t)c0 * ldt, ldt, nullptr, 0, nullptr); // (synchronises)
       }
    });
 }
@@ -1277,9 +1340,7 @@ int fpca_apply_x(fpca_ctx *ctx, const double *T, int64_t ldt, int b, double *Y, 
          kern::colmajor_to_t(ctx->d_stage, ctx->P_g, ctx->P_g, ctx->P_pad, bw, nc, ctx->d_T, ctx->stream);
          x_dev(ctx, bw, ctx->d_io_b, ctx->stream);
          kern::block_to_colmajor(ctx->d_io_b, ctx->N, bw, nc, ctx->d_stage, ctx->N, ctx->stream);
-         HIP_CHECK(hipMemcpy2DAsync(Y + (size_t)c0 * ldy, (size_t)ldy * sizeof(double), ctx->d_stage, ctx->N * sizeof(double),
-                                    ctx->N * sizeof(double), nc, hipMemcpyDeviceToHost, ctx->stream));
-         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+         staged_download(ctx, ctx->d_stage, ctx->N, nc, Y + (size_t)c0 * ldy, ldy, nullptr, 0, nullptr); // (synchronises)
       }
    });
 }
@@ -1397,6 +1458,7 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
       if (!out.d) out.d = dloc.data();
       solver_rc = run_pca(be, *opts, ctx->P_total, out, info, &ritz, &div);
       lap("run_pca");
+      const auto tpost = std::chrono::steady_clock::now();
       if (opts->do_loadings && V) {
          // randompca.cpp:191-204: V[:, j] = X' u_j / sqrt(d_j) / sqrt(div); one K2 pass for all k columns
          // (b eigenvectors per Ritz block; ndim > b takes several)
@@ -1409,15 +1471,18 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
             for (int j = 0; j < nc; j++) sc[j] = (1.0 / std::sqrt(out.d[j0 + j])) / std::sqrt(div);
             HIP_CHECK(hipMemcpyAsync(ctx->d_small, sc.data(), b * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
             kern::t_to_colmajor(ctx->d_T, ctx->P_g, b, nc, ctx->d_small, ctx->d_stage, ctx->P_g, ctx->stream);
-            HIP_CHECK(hipMemcpyAsync(V + (size_t)j0 * ctx->P_g, ctx->d_stage, (size_t)ctx->P_g * nc * sizeof(double), hipMemcpyDeviceToHost,
-                                     ctx->stream));
-            HIP_CHECK(hipStreamSynchronize(ctx->stream)); // sc / d_stage are reused by the next block
+            staged_download(ctx, ctx->d_stage, ctx->P_g, nc, V + (size_t)j0 * ctx->P_g, (int64_t)ctx->P_g, nullptr, 0, nullptr); // (synchronises:
+                                                                                               // sc / d_stage are reused by the next block)
          }
       }
       for (int h : ritz) be.free_block(h);
       if (mean_sd && ctx->P_g) {
-         HIP_CHECK(hipMemcpy(mean_sd, ctx->d_mean, ctx->P_g * sizeof(double), hipMemcpyDeviceToHost));
-         HIP_CHECK(hipMemcpy(mean_sd + ctx->P_g, ctx->d_sd, ctx->P_g * sizeof(double), hipMemcpyDeviceToHost));
+         staged_download(ctx, ctx->d_mean, ctx->P_g, 1, mean_sd, (int64_t)ctx->P_g, nullptr, 0, nullptr);
+         staged_download(ctx, ctx->d_sd, ctx->P_g, 1, mean_sd + ctx->P_g, (int64_t)ctx->P_g, nullptr, 0, nullptr);
+      }
+      if (info) {
+         info->seconds_post = std::chrono::duration<double>(std::chrono::steady_clock::now() - tpost).count();
+         info->seconds_total += info->seconds_post;
       }
       lap("loadings, mean/sd");
    });
@@ -1626,6 +1691,34 @@ int fpca_debug_mfma_i8_probe(const int8_t *A, const int8_t *Bt, int32_t *D)
       (void)hipFree(dA);
       (void)hipFree(dB);
       (void)hipFree(dD);
+   });
+}
+
+int fpca_debug_k4(fpca_ctx *ctx, int b, int nq, const double *V, const double *W, double *C_gram, const double *C_in, int use_init,
+                  double *Out)
+{
+   return guarded([&] {
+      if (!ctx || !V || !W || nq < 1 || nq > 1000 || (b != 16 && b != 32 && b != 48 && b != 64)) throw Error(FPCA_EINVAL, "bad argument to fpca_debug_k4");
+      if (Out && !C_in) throw Error(FPCA_EINVAL, "fpca_debug_k4: Out needs C_in");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      HipBackend be(ctx, b);
+      const int64_t N = (int64_t)ctx->N;
+      std::vector<int> hv(nq);
+      for (int q = 0; q < nq; q++) {
+         hv[q] = be.alloc_block();
+         be.upload(hv[q], b, V + (size_t)q * b * N, N);
+      }
+      const int hw = be.alloc_block();
+      be.upload(hw, b, W, N);
+      if (C_gram) be.gram(hv.data(), nq, hw, C_gram);
+      if (Out) {
+         const int ho = be.alloc_block();
+         be.gemm(hv.data(), nq, C_in, use_init ? hw : -1, ho);
+         be.download(ho, b, Out, N);
+         be.free_block(ho);
+      }
+      be.free_block(hw);
+      for (int h : hv) be.free_block(h);
    });
 }
 

@@ -87,35 +87,19 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
       for (int j = 0; j < k; j++) out.d[j] = d[j];
    if (out.pve)
       for (int j = 0; j < k; j++) out.pve[j] = d[j] / trace; // :206
+   double sec_download = 0;
    if (out.U || out.Px) {
-      std::vector<double> tmp;
-      double *U = out.U;
-      if (!U) {
-         tmp.resize((size_t)N * k);
-         U = tmp.data();
-      }
       lap("trace, eigenvalues");
+      const auto td = std::chrono::steady_clock::now();
+      // U and Px = U diag(sqrt(d)) (:207) leave the device in one pipelined pass: pinned chunks, the host side of each chunk
+      // (copy into U, scaled copy into Px) running while the next chunk is on the wire (HipBackend::download2)
+      std::vector<double> sq(k);
+      for (int j = 0; j < k; j++) sq[j] = std::sqrt(d[j]);
       for (int j0 = 0, q = 0; j0 < k; j0 += be.width(), q++)
-         be.download(r.ritz_blocks[q], std::min(be.width(), k - j0), U + (size_t)j0 * N, (int64_t)N);
-      lap("download U");
-      if (out.Px) { // :207  Px = U diag(sqrt(d)); a memory-bound N x k pass, one column per thread when it is big
-         auto column = [&](int j) {
-            const double sq = std::sqrt(d[j]);
-            for (uint64_t i = 0; i < N; i++) out.Px[i + (size_t)j * N] = U[i + (size_t)j * N] * sq;
-         };
-         if ((uint64_t)N * k < (1u << 20)) {
-            for (int j = 0; j < k; j++) column(j);
-         } else {
-            const int nt = std::min(k, 8);
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; t++)
-               th.emplace_back([&, t] {
-                  for (int j = t; j < k; j += nt) column(j);
-               });
-            for (auto &x : th) x.join();
-         }
-      }
-      lap("Px = U sqrt(d)");
+         be.download2(r.ritz_blocks[q], std::min(be.width(), k - j0), out.U ? out.U + (size_t)j0 * N : nullptr, (int64_t)N,
+                      out.Px ? out.Px + (size_t)j0 * N : nullptr, (int64_t)N, sq.data() + j0);
+      sec_download = std::chrono::duration<double>(std::chrono::steady_clock::now() - td).count();
+      lap("download U, Px = U sqrt(d)");
    }
    if (ritz_blocks)
       *ritz_blocks = r.ritz_blocks;
@@ -132,6 +116,8 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
       info->seconds_apply = be.seconds_apply();
       info->seconds_ortho = be.seconds_other();
       info->seconds_host = r.seconds_host;
+      info->seconds_download = sec_download;
+      info->seconds_post = 0; // (loadings / mean-sd: filled in by fpca_pca)
       info->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
    }
    return r.converged ? FPCA_OK : FPCA_ENOTCONVERGED;

@@ -201,6 +201,8 @@ typedef struct fpca_pca_info {
    double seconds_ortho;  /* device time in basis orthogonalisation / Ritz rotation */
    double seconds_host;   /* host time in the projected eigenproblem */
    double seconds_total;
+   double seconds_download; /* U and Px to the caller's memory (pinned, pipelined; Px = U sqrt(d) fused into the host side) */
+   double seconds_post;     /* loadings (one K2 pass per block of eigenvectors) + mean/sd download */
 } fpca_pca_info;
 
 void fpca_pca_default_opts(fpca_pca_opts *opts);
@@ -257,6 +259,13 @@ int fpca_debug_mfma_i8_probe(const int8_t *A, const int8_t *Bt, int32_t *D);
  * practical ceiling to read the GEMM kernels' roofline fraction against (72-74 TFLOP/s at 2 waves/SIMD vs 78.6 datasheet).
  * pattern 10 / 11: v_mfma_i32_32x32x32_i8 in TOP/s with zero / pseudo-random operands. */
 int fpca_debug_mfma_peak(int waves_per_simd, int iters, int pattern, double *tflops);
+/* diagnostic (tests/test_gpu_kernels.py): the K4 helpers the eigensolver runs on its HBM-resident basis, on caller data and
+ * through the very backend object the solver drives (HipBackend::gram incl. its split-K plane reduction, HipBackend::gemm).
+ * V: N x (nq b) fp64 column-major with leading dimension N, basis block q = columns [q b, (q+1) b); W: N x b.
+ *   C_gram (may be NULL): [q][p][c] = sum_s V_q[s][p] W[s][c]                       nq b b doubles
+ *   Out (may be NULL), N x b: (use_init ? W : 0) + sum_q V_q C_in[q]                C_in: [q][p][c], nq b b doubles */
+int fpca_debug_k4(fpca_ctx *ctx, int b, int nq, const double *V, const double *W, double *C_gram, const double *C_in, int use_init,
+                  double *Out);
 /* diagnostic: placement census of an nwg-workgroup grid (256 threads, lds_bytes dynamic LDS each): out[2i] = HW_ID,
  * out[2i+1] = XCC_ID of workgroup i */
 int fpca_debug_census(int nwg, uint64_t lds_bytes, uint32_t *out);

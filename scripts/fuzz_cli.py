@@ -61,8 +61,8 @@ for case in range(ncases):
                 "--outmeansd", "ms.txt", "--tol", "1e-9"]
         G = int(rng.choice([1, 1, 2, 3, 4]))  # --gpus G through the host-shared-memory test transport (one GPU here)
         env = dict(os.environ)
-        if G > 1:
-            args += ["--gpus", str(G)]
+        if G > 1:  # (that transport exists only in the -DFPCA_TEST_HOOKS build of the CLI)
+            args = [fp.HOOKS_CLI_PATH] + args[1:] + ["--gpus", str(G)]
             env["FPCA_CLI_TEST_TRANSPORT"] = "shm"
         r = subprocess.run(args, cwd=td, capture_output=True, text=True, env=env)
         desc = dict(N=N, P=P, k=k, stand=stand, div=div, prec=prec, gpus=G)

@@ -474,3 +474,44 @@ def test_randomised_parity_sweep(built_lib):
                        timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all 30 cases ok" in r.stdout
+
+
+@pytest.mark.parametrize("b,nq", [(16, 1), (16, 12), (16, 24), (32, 1), (32, 12), (32, 24), (64, 1), (64, 12)])
+def test_k4_gram_and_block_gemm_at_full_height(fp, b, nq):
+    """K4 (SURVEY 8 row K4) directly, not through the solver: HipBackend::gram (k_gram + the plane-parallel split-K reduction,
+    k_reduce_tall) and HipBackend::gemm (k_block_gemm) at N = 500,000 rows with 1, 12 and 24 basis blocks -- the basis at its
+    16-column cap is 24 blocks -- against numpy.  N is not a multiple of the 512-row padding on purpose."""
+    import ctypes as C
+
+    N = 500000 - 77
+    rng = np.random.default_rng(1000 * b + nq)
+    V = np.asfortranarray(rng.standard_normal((N, nq * b)))
+    W = np.asfortranarray(rng.standard_normal((N, b)))
+    Cin = rng.standard_normal((nq, b, b))
+    Cg = np.empty((nq, b, b))
+    Out = np.empty((N, b), order="F")
+    with fp.Context.synthetic(N, 256, n_pop=4, accum="fp64") as ctx:
+        for use_init in (1, 0):
+            fp._lib.check(fp.lib().fpca_debug_k4(ctx.h, b, nq, V.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p),
+                                                 Cg.ctypes.data_as(C.c_void_p), Cin.ctypes.data_as(C.c_void_p), use_init,
+                                                 Out.ctypes.data_as(C.c_void_p)))
+            ref = V @ Cin.reshape(nq * b, b) + (W if use_init else 0.0)
+            assert np.max(np.abs(Out - ref)) <= 1e-12 * np.max(np.abs(ref)), (use_init,)
+    Gref = (V.T @ W).reshape(nq, b, b)
+    # sums of 500,000 products of O(1) numbers: |error| ~ eps sqrt(N) per entry at worst for a blocked summation
+    assert np.max(np.abs(Cg - Gref)) <= 2e-13 * np.sqrt(N), np.max(np.abs(Cg - Gref))
+
+
+def test_thick_restart_at_full_height_keeps_an_orthonormal_basis(fp):
+    """A forced thick restart (basis cap of 4 blocks) at N = 500,000: the compressed basis (Ritz rotation through
+    k_block_gemm) must stay orthonormal and give the eigenpairs of the unrestricted solve; judged by a dense U'U on the host
+    and by the reference's --check quantity."""
+    N, P, k = 500000, 4000, 20
+    with fp.Context.synthetic(N, P, n_pop=8, accum="auto") as ctx:  # 7 structured eigenvalues: k = 20 reaches into the bulk
+        free = ctx.pca(ndim=k, tol=1e-7)
+        r = ctx.pca(ndim=k, tol=1e-7, max_blocks=4)
+        assert r["info"]["converged"] == 1 and r["info"]["restarts"] >= 2 and free["info"]["converged"] == 1
+        assert np.max(np.abs(r["U"].T @ r["U"] - np.eye(k))) < 1e-10
+        assert np.max(np.abs(r["d"] - free["d"]) / free["d"]) < 1e-9
+        err, mse, rmse = ctx.check(r["U"], r["d"])
+        assert np.all(np.sqrt(err) <= 1.01e-7 * r["d"])
