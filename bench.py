@@ -4,14 +4,14 @@
   python bench.py --gpus N --steps K --warmup W          (N=1 directly; N>1 under torch.distributed.run)
 
 A "step" is ONE pass of the hot path over the resident genotype matrix: the block operator
-Y = sum_g X_g X_g' B on b = 32 columns, i.e. K2 (xt_b) + K3 (x_t) + the all-reduce of the N x b product when N > 1.  That is b
+Y = sum_g X_g X_g' B on b columns, i.e. K2 (xt_b) + K3 (x_t) + the all-reduce of the N x b product when N > 1.  That is b
 single-vector applications of the reference's perform_op (svdwide.cpp:21-68), so
 value = N_samples * P_total * b * K / time   [genotype cells / s], the metric BASELINE.json names ("N x P x iters" with iters =
-single-vector operator applications).  b = 32 is the width at which the operator has its best throughput (7 byte slices x 32
-columns = exactly 7 column tiles of the int8 GEMM) and the width round 1 measured.  Since round 2 the SOLVER picks 16-column
-blocks by default (the k wanted Ritz vectors may span several blocks): fewer cells/s per pass -- `apply_at_solver_width` in the
-same line -- but fewer, cheaper passes and a 20-60 % shorter time to solution, which is the `pca` object (wall-clock of
-fpca_pca with its default options) -- the honest end-to-end figure.
+single-vector operator applications).  b IS THE WIDTH THE SOLVER RUNS for this k (`--blockvec 0`, the default: 16 columns for
+k <= 64, flashpca_amd/csrc/pca_driver.cpp choose_blockvec) -- so `value` is the throughput of the pass `flashpca --ndim k`
+actually makes (round 2 quoted the 32-column pass, whose 7 x 32 slice-columns fill the int8 GEMM's column tiles exactly and
+which is 20 % faster per cell; that figure is the `apply_at_b32` side block now).  `pca` is the wall-clock of fpca_pca with its
+default options -- the end-to-end figure: passes, time to the converged k, cells/s over the whole solve.
 
 Workload (default, BASELINE.json configs[2]/[3] -- the configuration the metric is quoted on): synthetic 500,000 samples x
 100,000 SNPs, k = 20, generated directly in HBM; with N > 1 ranks the SNP columns are sharded N ways (strong scaling,
@@ -45,19 +45,24 @@ HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
     # name: (N samples, SNPs, k, block width, sharding)
-    "cfg2": dict(N=50000, P=20000, k=20, b=32, scaling="weak",
+    "cfg2": dict(N=50000, P=20000, k=20, scaling="weak",
                  desc="synthetic .bed-layout matrix, 50000 samples x 20000 SNPs per GPU, k=20 (BASELINE configs[1])"),
-    "cfg3": dict(N=500000, P=100000, k=20, b=32, scaling="strong",
+    "cfg3": dict(N=500000, P=100000, k=20, scaling="strong",
                  desc="synthetic 500000 samples x 100000 SNPs total, SNP-sharded across GPUs, k=20 (BASELINE configs[2]/[3])"),
-    "cfg5": dict(N=1000000, P=200000, k=50, b=64, scaling="strong",
+    "cfg5": dict(N=1000000, P=200000, k=50, scaling="strong",
                  desc="synthetic 1000000 samples x 200000 SNPs total, SNP-sharded across GPUs, k=50 (BASELINE configs[4]; use --accum fp32)"),
-    "cfg4shard": dict(N=500000, P=12500, k=20, b=32, scaling="weak", shards=8,
+    "cfg4shard": dict(N=500000, P=12500, k=20, scaling="weak", shards=8,
                       desc="one GPU's shard of BASELINE configs[3]: 500000 samples x 12500 of 100000 SNPs (1/8), k=20"),
-    "cfg5shard": dict(N=1000000, P=25000, k=50, b=64, scaling="weak", shards=8,
+    "cfg5shard": dict(N=1000000, P=25000, k=50, scaling="weak", shards=8,
                       desc="one GPU's shard of BASELINE configs[4]: 1000000 samples x 25000 of 200000 SNPs (1/8), k=50 (use --accum fp32)"),
-    "tiny": dict(N=4000, P=3000, k=20, b=32, scaling="weak", desc="smoke-size workload"),
+    "tiny": dict(N=4000, P=3000, k=20, scaling="weak", desc="smoke-size workload"),
 }
-STEPS = {"cfg2": 400, "tiny": 400, "cfg3": 60, "cfg5": 12, "cfg4shard": 200, "cfg5shard": 40}
+STEPS = {"cfg2": 400, "tiny": 400, "cfg3": 80, "cfg5": 24, "cfg4shard": 200, "cfg5shard": 60}
+
+
+def solver_blockvec(k):
+    """fpca::choose_blockvec (pca_driver.cpp): the width fpca_pca picks when the caller leaves it open."""
+    return 16 if k <= 64 else 32 if k <= 128 else 64
 WARMUP = {"cfg2": 20, "tiny": 20, "cfg3": 5, "cfg5": 2, "cfg4shard": 10, "cfg5shard": 4}
 # untimed clock spin-up applies before the caller's warm-up (reported in the JSON line as spinup_applies)
 SPINUP = {"cfg2": 150, "tiny": 300, "cfg3": 4, "cfg5": 1, "cfg4shard": 20, "cfg5shard": 4}
@@ -75,8 +80,8 @@ def measure_traffic(args, dom):
     for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):  # KiB; FETCH_SIZE counts 64 of every 128 B on gfx950
         with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
-                   os.path.abspath(__file__), "--workload", args.workload, "--accum", args.accum, "--steps", "2", "--warmup", "1",
-                   "--no-cpu-baseline", "--no-pca", "--no-alt", "--traffic", "none"]
+                   os.path.abspath(__file__), "--workload", args.workload, "--accum", args.accum, "--blockvec", str(args.blockvec),
+                   "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pca", "--no-alt", "--traffic", "none"]
             subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True,
                            env={k: v for k, v in dict(os.environ, TMPDIR="/tmp").items() if k != "LD_PRELOAD"})
             fs = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
@@ -103,6 +108,8 @@ def main():
                                                              "two of device time -- the first ~50 ms after idle run at ramping clocks]")
     ap.add_argument("--warmup", type=int, default=None, help="untimed block applies before them [5 / 20 / 2]")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--blockvec", type=int, default=0, choices=[0, 16, 32, 48, 64],
+                    help="block width of the timed applies [0 = the width the solver picks for this k: 16 for k <= 64]")
     ap.add_argument("--accum", default="i8", choices=["fp64", "fp32", "i8"] + ["i8x%d" % s for s in range(4, 9)],
                     help="i8[xS] (default: the product's default mode) = exact-integer int8 MFMA on S (default 7) byte slices of the "
                          "fp64 operand, results equal to the fp64 path; fp64 = v_mfma_f64; fp32 = v_mfma_f32 products, fp64 long "
@@ -152,7 +159,8 @@ def main():
     if args.warmup is None:
         args.warmup = WARMUP[args.workload]
     steps_alt = min(args.steps, max(4, STEPS[args.workload] // 4))  # the other-mode comparison run
-    N, k, b = w["N"], w["k"], w["b"]
+    N, k = w["N"], w["k"]
+    b = args.blockvec or solver_blockvec(k)
     if w["scaling"] == "weak":
         # (the shard workloads keep the divisor of the full matrix they are a shard of)
         P_rank, P_total, snp_begin = w["P"], w["P"] * max(world, w.get("shards", 1)), rank * w["P"]
@@ -245,6 +253,24 @@ def main():
     cells = float(N) * float(P_done) * b * args.steps
     value = cells / elapsed
 
+    _peaks = {}
+
+    def mfma_stream_peak(pattern):
+        """sustained rate of a bare MFMA stream with nothing else going on (fpca_debug_mfma_peak; ~50 ms): v_mfma_f64_16x16x4 in
+        TFLOP/s (pattern 0, two waves per SIMD) or v_mfma_i32_32x32x32_i8 on random bytes in TOP/s (pattern 11, one wave per SIMD)
+        -- the practical ceiling of the GEMM kernels: the int8 stream is itself limited by the package power cap"""
+        if pattern not in _peaks:
+            import ctypes
+
+            v = ctypes.c_double(0)
+            best = 0.0
+            for _ in range(2):
+                # ~50 ms per launch: long enough for the power governor to settle (a 3 ms launch reads 3-5 % high)
+                fp._lib.check(fp.lib().fpca_debug_mfma_peak(1 if pattern >= 10 else 2, 300000 if pattern >= 10 else 100000, pattern, ctypes.byref(v)))
+                best = max(best, v.value)
+            _peaks[pattern] = best
+        return _peaks[pattern]
+
     # roofline of the dominant kernel (both GEMMs carry 2 N P_g b flops per launch; the slower one dominates)
     # dominant kernel = the slower of the two GEMM kernels; its own launch duration from HIP events recorded around that
     # launch inside the timed region (ms_gemm_*); ms_xt_b / ms_x_t are the whole K2 / K3 stages (slicing, sparse gathers,
@@ -268,12 +294,12 @@ def main():
                         integer_matrices_on_mfma=nmat,
                         missing_call_path={0: "dense (MFMA)", 1: "dense, empty blocks skipped", 2: "none missing", 3: "sparse fp64 gathers"}[mm],
                         ops_per_launch=ops_launch, fp64_equivalent_tflops=flops_launch / (ms_dom * 1e-3) / 1e12,
-                        peak_measured_pure_mfma_stream=3576.0)  # profiles/r01_mfma_i8_microbench.txt (random operands; power-limited)
+                        peak_measured_pure_mfma_stream=mfma_stream_peak(11))  # random operands; power-limited (measured in this run)
         del roofline["flops_per_launch"]
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
     roofline["hip_events_on_steps"] = "%d of %d (every %d%s step of the timed region)" % (prof["nsteps"], args.steps, stride, "th" if stride > 3 else "")
     if args.accum == "fp64":
-        roofline["peak_measured_pure_mfma_stream"] = 74.3  # profiles/r01_mfma_f64_microbench.txt (2 waves/SIMD)
+        roofline["peak_measured_pure_mfma_stream"] = mfma_stream_peak(0)  # v_mfma_f64 stream, 2 waves/SIMD (measured in this run)
     # HBM traffic per launch of the dominant kernel: hardware counters serialise the kernels, so they cannot be read inside
     # the timed region.  `measure`: right after it, this process runs itself twice more under rocprofv3 --pmc (FETCH_SIZE,
     # then WRITE_SIZE: separate passes, as the guide prescribes; 2 block applies each, nothing else) and reads the dominant
@@ -322,43 +348,59 @@ def main():
                                "agrees with the f64 kernels to ~3e-15, see fp64_mode)"),
                data="synthetic",
                config=dict(workload=args.workload + ": " + w["desc"], samples=N, snps_total=P_total, snps_per_gpu=P_rank,
-                           k=k, blockvec=b, solver_default_blockvec=(16 if k <= 64 else 32 if k <= 128 else 64), missing_call_rate=0.001, parallelism="snp-shard x%d + all-reduce(N x b) [%s]" % (world, transport),
+                           k=k, blockvec=b, solver_default_blockvec=solver_blockvec(k), missing_call_rate=0.001, parallelism="snp-shard x%d + all-reduce(N x b) [%s]" % (world, transport),
                            iters_per_step=b, generate_s=round(t_gen, 3)),
                roofline=roofline)
 
-    # ---- the same block apply at the width the SOLVER picks by default for this k (16 columns since round 2: the shortest
-    # time to solution), beside `value`'s width (the widest tile-exact one, S b = 224 = 7 column tiles): fewer
-    # columns per pass and 12.5 % of the last column tile empty, so fewer cells/s -- and still the faster PCA -------------
-    b_solver = 16 if k <= 64 else 32 if k <= 128 else 64
-    if b_solver != b and not args.no_pca:
-        Bs = torch.zeros((rows, b_solver), dtype=torch.float64, device="cuda")
-        Bs[:N] = torch.rand((N, b_solver), dtype=torch.float64, device="cuda", generator=g) - 0.5
-        Ys = torch.zeros((rows, b_solver), dtype=torch.float64, device="cuda")
-        steps_s = max(4, args.steps // 3)
+    # ---- side measurements of the same operator, each a bounded number of block applies -----------------------------------
+    def side_apply(c, bw, steps_s):
+        """steps_s timed block applies of width bw on context c (random block, warm): wall, cells/s, GEMM kernel times, roofline"""
+        Bs = torch.zeros((rows, bw), dtype=torch.float64, device="cuda")
+        Bs[:N] = torch.rand((N, bw), dtype=torch.float64, device="cuda", generator=g) - 0.5
+        Ys = torch.zeros((rows, bw), dtype=torch.float64, device="cuda")
         for _ in range(max(2, args.warmup)):
-            ctx.apply_xxt_dev(Bs.data_ptr(), b_solver, Ys.data_ptr())
-        ctx.synchronize()
+            c.apply_xxt_dev(Bs.data_ptr(), bw, Ys.data_ptr())
+        c.synchronize()
         barrier()
-        ctx.profile_begin(steps_s, sample_every=stride if steps_s >= 8 else 1)
+        c.profile_begin(steps_s, sample_every=stride if steps_s >= 8 else 1)
         t1 = time.perf_counter()
         for _ in range(steps_s):
-            ctx.apply_xxt_dev(Bs.data_ptr(), b_solver, Ys.data_ptr())
-        ctx.synchronize()
+            c.apply_xxt_dev(Bs.data_ptr(), bw, Ys.data_ptr())
+        c.synchronize()
         barrier()
         el_s = time.perf_counter() - t1
-        ps = ctx.profile_end(b_solver)
+        ps = c.profile_end(bw)
         ms_s = max(ps["ms_gemm_xt"], ps["ms_gemm_x"])
-        sw = dict(blockvec=b_solver, steps=steps_s, ms_per_step=el_s / steps_s * 1e3, value=float(N) * P_done * b_solver * steps_s / el_s,
-                  unit="cells/s", ms_gemm_kernel_xt_b=ps["ms_gemm_xt"], ms_gemm_kernel_x_t=ps["ms_gemm_x"])
+        sw = dict(blockvec=bw, steps=steps_s, ms_per_step=el_s / steps_s * 1e3, value=float(N) * P_done * bw * steps_s / el_s,
+                  unit="cells/s", ms_xt_b=ps["ms_xt"], ms_x_t=ps["ms_x"], ms_gemm_kernel_xt_b=ps["ms_gemm_xt"], ms_gemm_kernel_x_t=ps["ms_gemm_x"])
         if args.accum.startswith("i8"):
             S = int(args.accum[3:]) if len(args.accum) > 2 else 7
-            nm = 1 if ctx.missing_mode(b_solver) in (2, 3) else 2
-            ops = nm * 2.0 * N * P_rank * b_solver * S
+            mm = c.missing_mode(bw)
+            nm = 1 if mm in (2, 3) else 2
+            ops = nm * 2.0 * N * P_rank * bw * S
+            sw["missing_call_path"] = {0: "dense (MFMA)", 1: "dense, empty blocks skipped", 2: "none missing", 3: "sparse fp64 gathers"}[mm]
             sw["roofline"] = dict(bound="mfma", achieved=ops / (ms_s * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s",
-                                  frac=ops / (ms_s * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, ops_per_launch=ops,
-                                  note="S b = %d slice-columns fill %.1f of %d column tiles" % (S * b_solver, S * b_solver / 32.0, -(-S * b_solver // 32)))
-        out["apply_at_solver_width"] = sw
+                                  frac=ops / (ms_s * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, ops_per_launch=ops, integer_matrices_on_mfma=nm,
+                                  note="S b = %d slice-columns fill %.1f of %d column tiles" % (S * bw, S * bw / 32.0, -(-S * bw // 32)))
         del Bs, Ys
+        return sw
+
+    # (a) the widest tile-exact pass: 32 columns (7 x 32 slice-columns = exactly 7 column tiles of the int8 GEMM) -- what round 2
+    #     quoted as `value`; more cells/s per pass, but a k = 20 solve needs 5 of them against 7 of the 16-column ones (DESIGN 4)
+    b_wide = 32 if k <= 64 else 64
+    if b_wide != b and not args.no_pca:
+        out["apply_at_b%d" % b_wide] = side_apply(ctx, b_wide, max(4, args.steps // 4))
+    # (b) the same matrix with 2 % missing calls (real array data carries 1-2 %; the synthetic spec says 0.1 %): above 0.45 % the
+    #     missing-call indicator takes the dense route, a second integer matrix on the matrix cores instead of sparse gathers
+    if world == 1 and not args.no_alt and args.accum.startswith("i8"):
+        with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=min(2 * k, 64), missing_rate=0.02, device=local_rank,
+                                  accum=args.accum) as cm:
+            cm.set_total_snps(P_total)
+            cm.stats()
+            sm = side_apply(cm, b, max(4, args.steps // 4))
+            sm["missing_call_rate"] = 0.02
+            sm["slowdown_vs_value"] = sm["ms_per_step"] / (elapsed / args.steps * 1e3)
+            out["apply_at_missing_2pct"] = sm
 
     # ---- one full PCA solve to convergence (reported, not the timed region) -------------------------------
     if not args.no_pca:
@@ -370,6 +412,12 @@ def main():
         ctx.synchronize()
         barrier()
         wall_first = time.perf_counter() - t1
+        # (the first call's 160 MB of results are dropped BEFORE the clock starts: returning touched pages to the OS costs this
+        # process ~10 ms on these boxes -- the harness's own housekeeping, not part of a solve)
+        del r
+        import gc
+
+        gc.collect()
         t1 = time.perf_counter()
         r = ctx.pca(ndim=k, allow_unconverged=True)
         ctx.synchronize()
@@ -381,7 +429,9 @@ def main():
                           vector_ops=info["vector_ops"], restarts=info["restarts"],
                           cells_per_s=float(N) * P_done * info["vector_ops"] / wall,
                           seconds_apply=info["seconds_apply"], seconds_ortho=info["seconds_ortho"],
-                          seconds_host=info["seconds_host"], eigenvalue_1=float(r["d"][0]), eigenvalue_k=float(r["d"][-1]),
+                          seconds_host=info["seconds_host"], seconds_download=info["seconds_download"], seconds_post=info["seconds_post"],
+                          wall_minus_apply_s=wall - info["seconds_apply"],
+                          eigenvalue_1=float(r["d"][0]), eigenvalue_k=float(r["d"][-1]),
                           max_rel_residual=info["max_residual"])
 
     # ---- the same solve on a slowly converging spectrum: 4 sub-populations, so that 17 of the 20 wanted eigenvalues sit in
@@ -391,7 +441,7 @@ def main():
         with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=4, device=local_rank, accum=args.accum) as ch:
             ch.set_total_snps(P_total)
             ch.stats()
-            ch.pca(ndim=k, allow_unconverged=True, maxiter=3)  # one-off set-up of the arithmetic mode, untimed like above
+            ch.pca(ndim=k, allow_unconverged=True, max_applies=-(-k // solver_blockvec(k)) + 1)  # one-off set-up of the arithmetic mode, untimed like above
             ch.synchronize()
             t1 = time.perf_counter()
             rh = ch.pca(ndim=k, allow_unconverged=True)
@@ -426,10 +476,10 @@ def main():
             if other == "i8":
                 ops = (1 if c2.missing_mode(b) in (2, 3) else 2) * flops_launch * 7
                 rf = dict(bound="mfma", achieved=ops / (ms2 * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s",
-                          frac=ops / (ms2 * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, peak_measured_pure_mfma_stream=3576.0)
+                          frac=ops / (ms2 * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, peak_measured_pure_mfma_stream=mfma_stream_peak(11))
             else:
                 rf = dict(bound="mfma", achieved=flops_launch / (ms2 * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                          frac=flops_launch / (ms2 * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, peak_measured_pure_mfma_stream=74.3)
+                          frac=flops_launch / (ms2 * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, peak_measured_pure_mfma_stream=mfma_stream_peak(0))
             alt = dict(accum=other, value=cells / args.steps * steps_alt / el2, unit="cells/s", steps=steps_alt, ms_per_step=el2 / steps_alt * 1e3, ms_xt_b=p2["ms_xt"],
                        ms_x_t=p2["ms_x"], max_abs_diff_between_modes_over_max_abs=diff / scale, roofline=rf)
             if not args.no_pca:
@@ -499,7 +549,7 @@ def main():
             N2, P2 = WORKLOADS["cfg2"]["N"], WORKLOADS["cfg2"]["P"]
             with fp.Context.synthetic(N2, P2, snp_begin=0, n_pop=min(2 * k, 64), device=local_rank) as c2g:
                 packed2 = c2g.download_packed()
-                c2g.pca(ndim=k, allow_unconverged=True, maxiter=2)  # untimed set-up
+                c2g.pca(ndim=k, allow_unconverged=True, max_applies=-(-k // solver_blockvec(k)) + 1)  # untimed set-up
                 t1 = time.perf_counter()
                 rg = c2g.pca(ndim=k)
                 c2g.synchronize()
@@ -522,6 +572,21 @@ def main():
                 one_thread_s_per_op=s_per_op_1t, one_thread_total_wall_s_extrapolated=s_per_op_1t * rc["nops"],
                 gpu_wall_s_same_matrix=gpu_wall, gpu_block_applies=rg["info"]["block_applies"],
                 max_rel_eigenvalue_diff_gpu_vs_cpu=float(np.max(np.abs(rg["d"] - rc["d"]) / np.abs(rc["d"]))))
+            # "for cfg 3+ time >= 3 ops and extrapolate; state that".  The reference path's time to solution on THIS
+            # workload = (operator applications of its IRLM) x (seconds per application at this size).  The applications are
+            # those of the real solve above on the 50,000 x 20,000 matrix of the same generator (same 2k sub-populations, same k,
+            # ncv, tol: the count depends on the spectrum's shape, not on the size -- 57 there, 51-58 on HapMap3); the seconds
+            # per application are this run's measured samples (nops and na applications above) scaled to all P SNPs.
+            s_op_1 = float(N) * P_done / out["cpu_baseline"]["value"]
+            s_op_all = float(N) * P_done / out["cpu_baseline_allcores"]["value"]
+            out["cpu_baseline"]["time_to_solution_extrapolated"] = dict(
+                workload=args.workload, operator_applications_assumed=int(rc["nops"]),
+                seconds_per_application_1_thread=s_op_1, seconds_per_application_all_cores=s_op_all, cores_all=ncore,
+                total_s_1_thread=s_op_1 * rc["nops"], total_s_all_cores=s_op_all * rc["nops"],
+                gpu_pca_wall_s=out.get("pca", {}).get("wall_s"),
+                how="extrapolated: ops of the restated Spectra IRLM measured on the 50000 x 20000 matrix of the same generator x "
+                    "seconds per operator application measured here on a %d-SNP (1 thread) / %d-SNP (%d threads) sample of this "
+                    "matrix, scaled to its %d SNPs" % (P_s, P_a, ncore, P_done))
 
     if rank == 0:
         # anything the C side buffered on stdout (RCCL prints a version banner there under NCCL_DEBUG=VERSION) goes out first:
