@@ -204,6 +204,7 @@ def main():
                 return 0
 
             ctx.set_allreduce(allreduce)
+            ctx.set_rank(world, rank)  # (lets fpca_pca row-shard the solver over this transport too)
 
     rows = ctx.block_rows()
     g = torch.Generator(device="cuda")

@@ -38,6 +38,7 @@ class PcaOpts(C.Structure):
         ("max_blocks", C.c_int),
         ("verbose", C.c_int),
         ("seed", C.c_uint64),
+        ("replicated_solver", C.c_int),
         ("max_applies", C.c_int),
     ]
 
@@ -104,6 +105,8 @@ SIGNATURES = {
     "fpca_comm_init_rank": (_I, [_P, _I, _I, _P]),
     "fpca_set_allreduce": (_I, [_P, ALLREDUCE_FN, _P]),
     "fpca_set_total_snps": (_I, [_P, _U64]),
+    "fpca_set_rank": (_I, [_P, _I, _I]),
+    "fpca_collective_stats": (_I, [_P, C.POINTER(_U64), C.POINTER(_U64)]),
     "fpca_pca_default_opts": (None, [C.POINTER(PcaOpts)]),
     "fpca_pca": (_I, [_P, C.POINTER(PcaOpts), _P, _P, _P, _P, _P, _P, C.POINTER(PcaInfo)]),
     "fpca_check": (_I, [_P, _P, C.c_int64, _P, _I, _I, _P, C.POINTER(_D), C.POINTER(_D)]),

@@ -152,6 +152,15 @@ class Context:
         self._keep.append(cb)
         check(lib().fpca_set_allreduce(self.h, cb, None))
 
+    def set_rank(self, nranks, rank):
+        """rank / size beside a caller-supplied all-reduce: lets fpca_pca row-shard the solver (fpca_set_rank)."""
+        check(lib().fpca_set_rank(self.h, nranks, rank))
+
+    def collective_stats(self):
+        calls, nbytes = C.c_uint64(0), C.c_uint64(0)
+        check(lib().fpca_collective_stats(self.h, C.byref(calls), C.byref(nbytes)))
+        return int(calls.value), int(nbytes.value)
+
     def comm_init_rank(self, nranks, rank, unique_id):
         buf = (C.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
         check(lib().fpca_comm_init_rank(self.h, nranks, rank, buf))
@@ -164,12 +173,13 @@ class Context:
 
     # ---- driver ---------------------------------------------------------------------------------------
     def pca(self, ndim=10, tol=1e-6, maxiter=500, div="p", do_loadings=False, blockvec=0, max_blocks=0, seed=1, verbose=0,
-            allow_unconverged=False, max_applies=0):
+            allow_unconverged=False, max_applies=0, replicated_solver=False):
         o = PcaOpts()
         lib().fpca_pca_default_opts(C.byref(o))
         o.ndim, o.tol, o.maxiter, o.divisor = ndim, tol, maxiter, DIVISOR[div]
         o.do_loadings, o.blockvec, o.max_blocks, o.seed, o.verbose = int(do_loadings), blockvec, max_blocks, seed, verbose
         o.max_applies = max_applies
+        o.replicated_solver = int(replicated_solver)
         U = np.empty((self.N, ndim), order="F")
         d = np.empty(ndim)
         Px = np.empty((self.N, ndim), order="F")

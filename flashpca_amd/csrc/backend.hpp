@@ -12,6 +12,33 @@
 
 namespace fpca {
 
+// Row-sharded solver state (multi-GPU).  The operator needs the whole N x b block on every rank (K2 sums over
+// all samples), but nothing else does: between two applies every N-sized object of the eigensolver -- the Krylov basis, W,
+// the Ritz blocks -- lives as a ROW SLICE on each rank.  The rows are cut into `nch` chunks of L = G plen rows (the chunks
+// of the overlapped K3 / reduce-scatter pipeline); rank r keeps rows [c L + r plen, c L + (r+1) plen) of every chunk c, stored
+// back to back: slice-local row c plen + j.  Orthogonalisation = local Gram + an all-reduce of (m+1) b^2 doubles + local
+// update; the apply = all-gather -> K2, K3 -> reduce-scatter, the same bytes on the wire as the one all-reduce it replaces.
+struct RowShard {
+   int G = 1, rank = 0, nch = 1;
+   uint64_t L = 0, plen = 0;
+   bool on() const { return G > 1 || L > 0; }
+   uint64_t slice_rows() const { return (uint64_t)nch * plen; }
+   uint64_t full_rows() const { return (uint64_t)nch * L; }
+   uint64_t global_row(uint64_t rho) const { return (rho / plen) * L + (uint64_t)rank * plen + rho % plen; }
+   // rows: the (padded) height of a block; align: granularity of plen (512 for the HIP kernels, 1 on the host)
+   static RowShard make(uint64_t rows, int G, int rank, int nch, uint64_t align)
+   {
+      RowShard s;
+      s.G = G < 1 ? 1 : G;
+      s.rank = rank;
+      s.nch = nch < 1 ? 1 : nch;
+      const uint64_t parts = (uint64_t)s.G * s.nch;
+      s.plen = ((rows + parts - 1) / parts + align - 1) / align * align;
+      s.L = s.plen * s.G;
+      return s;
+   }
+};
+
 class BlockBackend {
  public:
    virtual ~BlockBackend() {}

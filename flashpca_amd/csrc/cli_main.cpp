@@ -634,7 +634,7 @@ int main(int argc, char *argv[])
          if (mg.test_transport)
             std::cerr << "[fpca-cli] FPCA_CLI_TEST_TRANSPORT=shm: all ranks share one device and exchange through host memory -- a test "
                          "hook for one-GPU boxes, not a way to run" << std::endl;
-         mg.slot_cap = mg.test_transport ? (size_t)(N + 1024) * 64 : 0;
+         mg.slot_cap = mg.test_transport ? (size_t)(N + 1024 + 512 * (size_t)ngpus) * 64 : 0; // the row-sharded solver's padded blocks
          const size_t head = (sizeof(MultiShared) + 63) / 64 * 64;
          const size_t bytes = head + ((size_t)P_file * (n_dim + 2) + (size_t)ngpus * mg.slot_cap) * sizeof(double);
          void *mem = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
@@ -726,7 +726,8 @@ int main(int argc, char *argv[])
                if (atoi(kr) == mg.rank && mg.rank > 0) raise(SIGKILL);
                if (atoi(kr) == 0 && mg.rank == 0) throw std::runtime_error("injected failure of rank 0 after the fork");
             }
-            if (fpca_set_allreduce(ctx, shm_allreduce, &mg) != FPCA_OK) multi_fail(mg, fpca_last_error());
+            if (fpca_set_allreduce(ctx, shm_allreduce, &mg) != FPCA_OK || fpca_set_rank(ctx, ngpus, mg.rank) != FPCA_OK)
+               multi_fail(mg, fpca_last_error());
          } else
 #endif
          {

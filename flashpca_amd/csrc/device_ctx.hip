@@ -44,6 +44,8 @@ struct RcclApi {
    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+   ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
    const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -61,9 +63,11 @@ static RcclApi &rccl()
       api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
       api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
       api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
+      api.ReduceScatter = (decltype(api.ReduceScatter))dlsym(api.handle, "ncclReduceScatter");
+      api.AllGather = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
       api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
-      if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy)
+      if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.ReduceScatter || !api.AllGather || !api.CommDestroy)
          throw Error(FPCA_ECOMM, "librccl is missing expected symbols");
    }
    return api;
@@ -156,6 +160,11 @@ struct fpca_ctx {
    hipEvent_t ev_chunk[4] = {nullptr, nullptr, nullptr, nullptr}, ev_comm_done = nullptr;
    fpca_allreduce_fn ar_fn = nullptr;
    void *ar_user = nullptr;
+   bool rank_known = false; // nranks / rank are meaningful (fpca_comm_init_rank, or fpca_set_rank beside a caller's all-reduce)
+   // row-sharded solver (backend.hpp RowShard): whole [full_rows][b] blocks either side of the operator
+   double *d_full_in = nullptr, *d_full_out = nullptr;
+   size_t full_in_cap = 0, full_out_cap = 0;
+   uint64_t coll_calls = 0, coll_bytes = 0; // data-path collectives issued by this context (calls, payload bytes)
    // live profiling (fpca_profile_begin/end)
    std::vector<hipEvent_t> prof_ev;
    int prof_used = 0, prof_calls = 0, prof_stride = 1; // every prof_stride-th apply carries the events
@@ -171,8 +180,45 @@ struct fpca_ctx {
       cap = need;
    }
    bool multi() const { return comm != nullptr || ar_fn != nullptr; }
+   // slice [sh.slice_rows()][b] -> full [sh.full_rows()][b] on every rank
+   void all_gather(const RowShard &sh, const double *slice, double *full, int b, hipStream_t s)
+   {
+      const size_t piece = (size_t)sh.plen * b, chunk = (size_t)sh.L * b;
+      if (comm && !ar_fn) {
+         for (int c = 0; c < sh.nch; c++) {
+            RCCL_CHECK(rccl().AllGather(slice + c * piece, full + c * chunk, piece, ncclDouble, comm, s));
+            coll_calls++;
+            coll_bytes += piece * sizeof(double);
+         }
+         return;
+      }
+      // a caller-supplied transport only sums: every rank contributes its rows, zeros elsewhere
+      HIP_CHECK(hipMemsetAsync(full, 0, (size_t)sh.full_rows() * b * sizeof(double), s));
+      for (int c = 0; c < sh.nch; c++)
+         HIP_CHECK(hipMemcpyAsync(full + c * chunk + (size_t)sh.rank * piece, slice + c * piece, piece * sizeof(double), hipMemcpyDeviceToDevice, s));
+      allreduce(full, (uint64_t)sh.full_rows() * b, s);
+   }
+   // sum over ranks of full [sh.full_rows()][b]; rank r keeps its rows in slice.  chunk >= 0: that chunk only.
+   void reduce_scatter(const RowShard &sh, double *full, double *slice, int b, hipStream_t s, int only_chunk = -1)
+   {
+      const size_t piece = (size_t)sh.plen * b, chunk = (size_t)sh.L * b;
+      if (comm && !ar_fn) {
+         for (int c = 0; c < sh.nch; c++) {
+            if (only_chunk >= 0 && c != only_chunk) continue;
+            RCCL_CHECK(rccl().ReduceScatter(full + c * chunk, slice + c * piece, piece, ncclDouble, ncclSum, comm, s));
+            coll_calls++;
+            coll_bytes += piece * sizeof(double);
+         }
+         return;
+      }
+      allreduce(full, (uint64_t)sh.full_rows() * b, s);
+      for (int c = 0; c < sh.nch; c++)
+         HIP_CHECK(hipMemcpyAsync(slice + c * piece, full + c * chunk + (size_t)sh.rank * piece, piece * sizeof(double), hipMemcpyDeviceToDevice, s));
+   }
    void allreduce(double *dbuf, uint64_t count, hipStream_t s)
    {
+      coll_calls++;
+      coll_bytes += count * sizeof(double);
       if (ar_fn) { // a caller-supplied hook wins over the built-in communicator (set after a failed / partial RCCL init)
          if (ar_fn(ar_user, dbuf, count, (void *)s) != 0) throw Error(FPCA_ECOMM, "caller-supplied all-reduce failed");
       } else if (comm)
@@ -257,7 +303,8 @@ void ctx_free(fpca_ctx *c)
    }
    void *ptrs[] = {c->d_Xd, c->d_packed, c->d_lut, c->d_mean, c->d_sd,   c->d_sumsq, c->d_T,
                    c->d_part,   c->d_stage, c->d_io_a, c->d_io_b, c->d_small, c->d_packedT, c->d_inv_sd, c->d_mu_inv_sd,
-                   c->d_i8w, c->d_Qb, c->d_Qg, c->d_Qm, c->d_i8ws, c->d_snp_ptr, c->d_snp_idx, c->d_smp_ptr, c->d_smp_idx, c->d_eplane};
+                   c->d_i8w, c->d_Qb, c->d_Qg, c->d_Qm, c->d_i8ws, c->d_snp_ptr, c->d_snp_idx, c->d_smp_ptr, c->d_smp_idx, c->d_eplane,
+                   c->d_full_in, c->d_full_out};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (auto &pb : c->block_pool) (void)hipFree(pb.second);
@@ -397,6 +444,16 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
          if (rows)
             need = std::max(need, std::max(kern::gemm_i8_workspace_doubles(rows, c->P_pad, c->i8_S, b, true),
                                            kern::gemm_i8_workspace_doubles(rows, c->P_pad, c->i8_S, b, false)));
+      }
+   if (c->rank_known && c->nranks > 1) // K3 in the row chunks of the row-sharded solver (apply_sharded)
+      for (int nch = 2; nch <= 4; nch++) {
+         const RowShard sh = RowShard::make(c->N_pad, c->nranks, c->rank, nch, 512);
+         for (int i = 0; i < nch; i++) {
+            const uint64_t r0 = std::min<uint64_t>((uint64_t)i * sh.L, c->N_pad), r1 = std::min<uint64_t>((uint64_t)(i + 1) * sh.L, c->N_pad);
+            if (r1 > r0)
+               need = std::max(need, std::max(kern::gemm_i8_workspace_doubles(r1 - r0, c->P_pad, c->i8_S, b, true),
+                                              kern::gemm_i8_workspace_doubles(r1 - r0, c->P_pad, c->i8_S, b, false)));
+         }
       }
    if (need > c->i8ws_cap) {
       if (c->d_i8ws) HIP_CHECK(hipFree(c->d_i8ws));
@@ -628,7 +685,7 @@ void allreduce_rows(fpca_ctx *c, double *dY, int b, hipStream_t s)
 
 // the operator on device-resident blocks: dY = X_g X_g' dB (+ all-reduce).  ev (optional): 4 events recorded
 // at [start, after K2(+reduce), after K3(+reduce), after all-reduce].
-void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t s, hipEvent_t *ev)
+void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t s, hipEvent_t *ev, bool reduce = true)
 {
    ensure_stats(c);
    if (c->i8_S && ensure_i8(c, b)) {
@@ -637,7 +694,7 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
       i8_zero_meta(c, s);
       xt_i8(c, dB, b, s, true, ev ? ev + 4 : nullptr);
       if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
-      const int nch = ar_chunks(c);
+      const int nch = reduce ? ar_chunks(c) : 1;
       if (nch > 1) {
          if (ev) HIP_CHECK(hipEventRecord(ev[6], s)); // (chunked: the "GEMM kernel" interval spans all chunks, slicing included)
          for (int i = 0; i < nch; i++) {
@@ -657,7 +714,7 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
       }
       x_i8(c, b, dY, s, true, true, 0, 0, ev ? ev + 6 : nullptr);
       if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
-      allreduce_rows(c, dY, b, s);
+      if (reduce) allreduce_rows(c, dY, b, s);
       if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
       return;
    }
@@ -685,8 +742,38 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
    if (ev) HIP_CHECK(hipEventRecord(ev[7], s));
    if (s3 > 1) kern::reduce_sum(c->d_part, dY, (uint64_t)c->N_pad * b, s3, s);
    if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
-   allreduce_rows(c, dY, b, s);
+   if (reduce) allreduce_rows(c, dY, b, s);
    if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
+}
+
+// The operator on a ROW-SHARDED block (the eigensolver's view, backend.hpp RowShard): all-gather the rows of the input block
+// (K2 sums over all samples), K2, K3 on the whole block, reduce-scatter the partial products -- the same bytes on the wire
+// as the all-reduce of apply_xxt_dev, but every rank ends up with only ITS rows of the sum, which is all the
+// orthogonalisation that follows needs.  With the built-in communicator and more than one chunk, K3 runs chunk by chunk
+// and the reduce-scatter of chunk i rides on the communication stream under the computation of chunk i + 1.
+void apply_sharded(fpca_ctx *c, const RowShard &sh, const double *in_slice, int b, double *out_slice, hipStream_t s)
+{
+   c->all_gather(sh, in_slice, c->d_full_in, b, s);
+   if (sh.nch > 1 && c->comm && !c->ar_fn && c->comm_stream) {
+      ensure_stats(c);
+      if (c->i8_S && ensure_i8(c, b)) {
+         c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
+         i8_zero_meta(c, s);
+         xt_i8(c, c->d_full_in, b, s, true);
+         for (int i = 0; i < sh.nch; i++) {
+            const uint64_t r0 = std::min<uint64_t>((uint64_t)i * sh.L, c->N_pad), r1 = std::min<uint64_t>((uint64_t)(i + 1) * sh.L, c->N_pad);
+            x_i8(c, b, c->d_full_out, s, true, i == 0, r0, r1); // (rows >= N_pad of d_full_out stay zero: nothing writes them)
+            HIP_CHECK(hipEventRecord(c->ev_chunk[i], s));
+            HIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_chunk[i], 0));
+            c->reduce_scatter(sh, c->d_full_out, out_slice, b, c->comm_stream, i);
+         }
+         HIP_CHECK(hipEventRecord(c->ev_comm_done, c->comm_stream));
+         HIP_CHECK(hipStreamWaitEvent(s, c->ev_comm_done, 0));
+         return;
+      }
+   }
+   apply_xxt_dev(c, c->d_full_in, b, c->d_full_out, s, nullptr, false);
+   c->reduce_scatter(sh, c->d_full_out, out_slice, b, s);
 }
 
 void xt_dev(fpca_ctx *c, const double *dB, int b, hipStream_t s)
@@ -814,12 +901,31 @@ void staged_download(fpca_ctx *c_, const double *d_img, uint64_t N, int ncols, d
 
 class HipBackend : public BlockBackend {
  public:
-   HipBackend(fpca_ctx *c, int b)
+   HipBackend(fpca_ctx *c, int b, bool replicated = false)
       : c_(c), b_(b), d_ptrs_(c->be_ptrs), d_C_(c->be_C), d_gpart_(c->be_gpart), C_cap_(c->be_C_cap), gpart_cap_(c->be_gpart_cap),
         h_pin_(c->be_pin), pin_cap_(c->be_pin_cap)
    {
       HIP_CHECK(hipSetDevice(c->device));
       ensure_stats(c);
+      rows_ = c->N_pad;
+      // several ranks whose rank / size are known: the solver's N-sized objects are row slices (backend.hpp RowShard);
+      // `replicated` keeps every rank's copy whole, as in round 2 (A/B, and contexts that only have an all-reduce hook
+      // without fpca_set_rank).  FPCA_FORCE_ROWSHARD (test builds): the sharded code path with a single rank.
+      const bool force = FPCA_TEST_ENV("FPCA_FORCE_ROWSHARD") != nullptr;
+      if (!replicated && ((c->multi() && c->rank_known && c->nranks > 1) || force)) {
+         const int G = (c->multi() && c->rank_known) ? c->nranks : 1;
+         const int nch = (c->comm && !c->ar_fn && c->comm_stream && c->i8_S) ? ar_chunks(c) : 1;
+         sh_ = RowShard::make(c->N_pad, G, (c->multi() && c->rank_known) ? c->rank : 0, nch, 512);
+         rows_ = sh_.slice_rows();
+         const size_t need = (size_t)sh_.full_rows() * b;
+         if (need > c->full_in_cap || need > c->full_out_cap) {
+            c->ensure(c->d_full_in, c->full_in_cap, need);
+            c->ensure(c->d_full_out, c->full_out_cap, need);
+         }
+         // rows >= N_pad of the whole blocks are never written by the kernels and must read as zero in the collectives
+         HIP_CHECK(hipMemsetAsync(c->d_full_in, 0, c->full_in_cap * sizeof(double), c->stream));
+         HIP_CHECK(hipMemsetAsync(c->d_full_out, 0, c->full_out_cap * sizeof(double), c->stream));
+      }
       if (!d_ptrs_) HIP_CHECK(hipMalloc(&d_ptrs_, 1024 * sizeof(double *)));
       HIP_CHECK(hipEventCreate(&e0_));
       HIP_CHECK(hipEventCreate(&e1_));
@@ -837,7 +943,9 @@ class HipBackend : public BlockBackend {
    }
    uint64_t nrows() const override { return c_->N; }
    int width() const override { return b_; }
-   size_t block_bytes() const { return (size_t)c_->N_pad * b_ * sizeof(double); }
+   size_t block_bytes() const { return (size_t)rows_ * b_ * sizeof(double); }
+   bool sharded() const { return sh_.on(); }
+   const RowShard &shard() const { return sh_; }
    int alloc_block() override
    {
       for (size_t i = 0; i < used_.size(); i++)
@@ -858,12 +966,30 @@ class HipBackend : public BlockBackend {
       return (int)blocks_.size() - 1;
    }
    void free_block(int h) override { used_[h] = 0; }
-   double *ptr(int h) { return blocks_[h]; }
-   void fill_random(int h, uint64_t seed) override { kern::fill_random(blocks_[h], c_->N, c_->N_pad, b_, seed, c_->stream); }
+   // the WHOLE block h as the operator wants it ([N_pad][b] on this device): the block itself, or -- row-sharded -- its rows
+   // gathered from all ranks into the context's scratch (a collective: every rank calls it)
+   double *full_ptr(int h)
+   {
+      if (!sharded()) return blocks_[h];
+      c_->all_gather(sh_, blocks_[h], c_->d_full_in, b_, c_->stream);
+      return c_->d_full_in;
+   }
+   void fill_random(int h, uint64_t seed) override
+   {
+      if (!sharded()) {
+         kern::fill_random(blocks_[h], c_->N, c_->N_pad, b_, seed, c_->stream);
+         return;
+      }
+      for (int c = 0; c < sh_.nch; c++) // the rows this rank keeps of the block every rank would have generated
+         kern::fill_random(blocks_[h] + (size_t)c * sh_.plen * b_, c_->N, sh_.plen, b_, seed, c_->stream, (uint64_t)c * sh_.L + (uint64_t)sh_.rank * sh_.plen);
+   }
    void apply(int in, int out) override
    {
       HIP_CHECK(hipEventRecord(e0_, c_->stream));
-      apply_xxt_dev(c_, blocks_[in], b_, blocks_[out], c_->stream, nullptr);
+      if (sharded())
+         apply_sharded(c_, sh_, blocks_[in], b_, blocks_[out], c_->stream);
+      else
+         apply_xxt_dev(c_, blocks_[in], b_, blocks_[out], c_->stream, nullptr);
       HIP_CHECK(hipEventRecord(e1_, c_->stream));
       HIP_CHECK(hipEventSynchronize(e1_));
       float ms = 0;
@@ -899,14 +1025,15 @@ class HipBackend : public BlockBackend {
    {
       auto t0 = std::chrono::steady_clock::now();
       const size_t cnt = (size_t)nq * b_ * b_;
-      const int rows = kern::gram_rows(c_->N_pad, nq);
-      const int ns = kern::gram_splits(c_->N_pad, rows) * 4;
+      const int rows = kern::gram_rows(rows_, nq);
+      const int ns = kern::gram_splits(rows_, rows) * 4;
       grow(d_gpart_, gpart_cap_, cnt * ns);
       grow(d_C_, C_cap_, std::max(cnt, (size_t)1024 * b_ * 4));
       double *hc = pin_coeff(cnt);
       push_ptrs(a, nq);
-      kern::gram(d_ptrs_, nq, blocks_[w], d_gpart_, c_->N_pad, b_, rows, c_->stream);
+      kern::gram(d_ptrs_, nq, blocks_[w], d_gpart_, rows_, b_, rows, c_->stream);
       kern::reduce_sum(d_gpart_, d_C_, cnt, ns, c_->stream);
+      if (sharded() && sh_.G > 1) c_->allreduce(d_C_, cnt, c_->stream); // row slices: the only collective of the orthogonalisation
       HIP_CHECK(hipMemcpyAsync(hc, d_C_, cnt * sizeof(double), hipMemcpyDeviceToHost, c_->stream));
       HIP_CHECK(hipStreamSynchronize(c_->stream));
       std::memcpy(C, hc, cnt * sizeof(double));
@@ -924,15 +1051,17 @@ class HipBackend : public BlockBackend {
       HIP_CHECK(hipEventRecord(ev_pin_, c_->stream));
       pin_busy_ = true;
       // not drained: d_C_ / d_ptrs_ are only rewritten by later copies on this same stream, i.e. after the kernel
-      kern::block_gemm(d_ptrs_, nq, d_C_, init >= 0 ? blocks_[init] : nullptr, blocks_[out], c_->N_pad, b_, c_->stream);
+      kern::block_gemm(d_ptrs_, nq, d_C_, init >= 0 ? blocks_[init] : nullptr, blocks_[out], rows_, b_, c_->stream);
       sec_other_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
    }
    void download(int h, int ncols, double *host, int64_t ld) override { download2(h, ncols, host, ld, nullptr, 0, nullptr); }
    void download2(int h, int ncols, double *host, int64_t ld, double *host2, int64_t ld2, const double *scale) override
    {
+      if (!host && !host2 && !sharded()) return;
+      const double *whole = full_ptr(h); // (row-sharded: a collective -- every rank comes here, whether it wants the result or not)
       if (!host && !host2) return;
       c_->ensure(c_->d_stage, c_->stage_cap, (size_t)c_->N * ncols);
-      kern::block_to_colmajor(blocks_[h], c_->N, b_, ncols, c_->d_stage, c_->N, c_->stream);
+      kern::block_to_colmajor(whole, c_->N, b_, ncols, c_->d_stage, c_->N, c_->stream);
       staged_download(c_, c_->d_stage, c_->N, ncols, host, ld, host2, ld2, scale);
    }
    void upload(int h, int ncols, const double *host, int64_t ld) override
@@ -940,7 +1069,14 @@ class HipBackend : public BlockBackend {
       c_->ensure(c_->d_stage, c_->stage_cap, (size_t)c_->N * ncols);
       HIP_CHECK(hipMemcpy2DAsync(c_->d_stage, c_->N * sizeof(double), host, (size_t)ld * sizeof(double),
                                  c_->N * sizeof(double), ncols, hipMemcpyHostToDevice, c_->stream));
-      kern::colmajor_to_block(c_->d_stage, c_->N, c_->N, c_->N_pad, b_, ncols, blocks_[h], c_->stream);
+      if (!sharded())
+         kern::colmajor_to_block(c_->d_stage, c_->N, c_->N, c_->N_pad, b_, ncols, blocks_[h], c_->stream);
+      else { // the whole block into the scratch, this rank's rows out of it
+         kern::colmajor_to_block(c_->d_stage, c_->N, c_->N, c_->N_pad, b_, ncols, c_->d_full_out, c_->stream);
+         for (int c = 0; c < sh_.nch; c++)
+            HIP_CHECK(hipMemcpyAsync(blocks_[h] + (size_t)c * sh_.plen * b_, c_->d_full_out + ((size_t)c * sh_.L + (size_t)sh_.rank * sh_.plen) * b_,
+                                     (size_t)sh_.plen * b_ * sizeof(double), hipMemcpyDeviceToDevice, c_->stream));
+      }
       HIP_CHECK(hipStreamSynchronize(c_->stream));
    }
    double trace() override
@@ -970,6 +1106,8 @@ class HipBackend : public BlockBackend {
    }
    fpca_ctx *c_;
    int b_;
+   uint64_t rows_ = 0; // rows of a block as THIS rank stores it: N_pad, or its slice of the row-sharded solver
+   RowShard sh_;
    std::vector<double *> blocks_;
    std::vector<unsigned char> used_;
    const double **&d_ptrs_; // scratch owned by the context (kept across solves)
@@ -1379,6 +1517,7 @@ int fpca_comm_init_rank(fpca_ctx *ctx, int nranks, int rank, const uint8_t id[FP
       RCCL_CHECK(rccl().CommInitRank(&ctx->comm, nranks, u, rank));
       ctx->nranks = nranks;
       ctx->rank = rank;
+      ctx->rank_known = true;
       if (!ctx->comm_stream) {
          HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
          for (hipEvent_t &e : ctx->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1399,6 +1538,23 @@ int fpca_set_allreduce(fpca_ctx *ctx, fpca_allreduce_fn fn, void *user)
    if (!ctx) return FPCA_EINVAL;
    ctx->ar_fn = fn;
    ctx->ar_user = user;
+   return FPCA_OK;
+}
+
+int fpca_set_rank(fpca_ctx *ctx, int nranks, int rank)
+{
+   if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return FPCA_EINVAL;
+   ctx->nranks = nranks;
+   ctx->rank = rank;
+   ctx->rank_known = true;
+   return FPCA_OK;
+}
+
+int fpca_collective_stats(const fpca_ctx *ctx, uint64_t *calls, uint64_t *bytes)
+{
+   if (!ctx) return FPCA_EINVAL;
+   if (calls) *calls = ctx->coll_calls;
+   if (bytes) *bytes = ctx->coll_bytes;
    return FPCA_OK;
 }
 
@@ -1445,7 +1601,7 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
          if (timing) std::fprintf(stderr, "[fpca] %-28s %8.3f ms\n", what, std::chrono::duration<double>(now - tp0).count() * 1e3);
          tp0 = now;
       };
-      HipBackend be(ctx, b);
+      HipBackend be(ctx, b, opts->replicated_solver != 0);
       lap("backend setup");
       PcaOutputs out;
       out.U = U;
@@ -1466,7 +1622,7 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
          std::vector<double> sc(b);
          for (int j0 = 0, q = 0; j0 < k; j0 += b, q++) {
             const int nc = std::min(b, k - j0);
-            xt_dev(ctx, be.ptr(ritz[q]), b, ctx->stream);
+            xt_dev(ctx, be.full_ptr(ritz[q]), b, ctx->stream); // (row-sharded solver: gathers the rows of the block from all ranks)
             std::fill(sc.begin(), sc.end(), 0.0);
             for (int j = 0; j < nc; j++) sc[j] = (1.0 / std::sqrt(out.d[j0 + j])) / std::sqrt(div);
             HIP_CHECK(hipMemcpyAsync(ctx->d_small, sc.data(), b * sizeof(double), hipMemcpyHostToDevice, ctx->stream));

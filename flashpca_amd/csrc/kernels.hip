@@ -1113,25 +1113,28 @@ void block_gemm(const double *const *blocks, int nq, const double *C, const doub
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void k_fill_random(double *blk, uint64_t N, uint64_t total, int b, uint64_t seed)
+__global__ void k_fill_random(double *blk, uint64_t N, uint64_t total, int b, uint64_t seed, uint64_t row0)
 {
-   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+   for (uint64_t il = (uint64_t)blockIdx.x * 256 + threadIdx.x; il < total; il += (uint64_t)gridDim.x * 256) {
+      const uint64_t i = il + row0 * b; // element index in the WHOLE block: a row slice gets the values the whole block would
       const uint64_t s = i / b;
       double v = 0.0;
       if (s < N) {
          const uint64_t h = synth::mix64(synth::mix64(seed ^ 0x5851F42D4C957F2Dull) ^ (i * 0x9E3779B97F4A7C15ull));
          v = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
       }
-      blk[i] = v;
+      blk[il] = v;
    }
 }
 
-void fill_random(double *blk, uint64_t N, uint64_t N_pad, int b, uint64_t seed, hipStream_t stream)
+// rows [row0, row0 + rows) of the random N x b block with this seed (rows >= N are zero), written to blk[0 .. rows*b)
+void fill_random(double *blk, uint64_t N, uint64_t rows, int b, uint64_t seed, hipStream_t stream, uint64_t row0)
 {
-   const uint64_t total = N_pad * b;
+   const uint64_t total = rows * b;
+   if (!total) return;
    uint64_t blocks = (total + 255) / 256;
    if (blocks > 8192) blocks = 8192;
-   hipLaunchKernelGGL(k_fill_random, dim3((unsigned)blocks), dim3(256), 0, stream, blk, N, total, b, seed);
+   hipLaunchKernelGGL(k_fill_random, dim3((unsigned)blocks), dim3(256), 0, stream, blk, N, total, b, seed, row0);
    HIP_CHECK_LAUNCH();
 }
 

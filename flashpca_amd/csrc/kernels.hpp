@@ -57,7 +57,7 @@ int gram_splits(uint64_t N_pad, int rows);
 void block_gemm(const double *const *blocks, int nq, const double *C, const double *Init, double *Out, uint64_t N_pad,
                 int b, hipStream_t stream);
 // uniform(-0.5, 0.5) entries for rows < N, zero for rows in [N, N_pad)
-void fill_random(double *blk, uint64_t N, uint64_t N_pad, int b, uint64_t seed, hipStream_t stream);
+void fill_random(double *blk, uint64_t N, uint64_t rows, int b, uint64_t seed, hipStream_t stream, uint64_t row0 = 0);
 // row-major [N_pad][b] block <-> column-major N x ncols (ld) device staging buffer
 void block_to_colmajor(const double *blk, uint64_t N, int b, int ncols, double *out, uint64_t ld, hipStream_t stream);
 void colmajor_to_block(const double *in, uint64_t ld, uint64_t N, uint64_t N_pad, int b, int ncols, double *blk,

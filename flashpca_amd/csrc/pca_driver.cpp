@@ -88,7 +88,8 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
    if (out.pve)
       for (int j = 0; j < k; j++) out.pve[j] = d[j] / trace; // :206
    double sec_download = 0;
-   if (out.U || out.Px) {
+   { // (always: with a row-sharded backend the download starts with an all-gather, which every rank must join -- a rank
+     //  that passes no U / Px just takes part in it)
       lap("trace, eigenvalues");
       const auto td = std::chrono::steady_clock::now();
       // U and Px = U diag(sqrt(d)) (:207) leave the device in one pipelined pass: pinned chunks, the host side of each chunk

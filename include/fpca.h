@@ -158,6 +158,14 @@ int fpca_comm_init_rank(fpca_ctx *ctx, int nranks, int rank, const uint8_t id[FP
  * (e.g. torch.distributed over RCCL).  Must return 0 on success. */
 typedef int (*fpca_allreduce_fn)(void *user, double *dbuf, uint64_t count, void *stream);
 int fpca_set_allreduce(fpca_ctx *ctx, fpca_allreduce_fn fn, void *user);
+/* rank / size of this context among the shards when the transport is a caller's all-reduce (fpca_comm_init_rank sets
+ * them itself).  Once they are known and nranks > 1, fpca_pca ROW-SHARDS the eigensolver's N-sized work: the operator becomes
+ * all-gather -> K2, K3 -> reduce-scatter (the bytes of the one all-reduce, built from the caller's all-reduce if that is all
+ * there is), every rank keeps and orthogonalises N / nranks rows of the Krylov basis, and the only other collective is the
+ * all-reduce of the (m+1) b^2 Gram coefficients.  Without this call a hook-only context keeps round 2's replicated solver. */
+int fpca_set_rank(fpca_ctx *ctx, int nranks, int rank);
+/* data-path collectives this context has issued so far: number of calls and payload bytes (tests, scale model) */
+int fpca_collective_stats(const fpca_ctx *ctx, uint64_t *calls, uint64_t *bytes);
 /* total SNP count over all shards (the divisor "p", randompca.cpp:183) -- defaults to the shard's P_g */
 int fpca_set_total_snps(fpca_ctx *ctx, uint64_t P_total);
 
@@ -185,6 +193,8 @@ typedef struct fpca_pca_opts {
    int max_blocks;  /* basis cap in blocks before a thick restart; 0 = automatic */
    int verbose;
    uint64_t seed;   /* start block seed; the reference ignores --seed for PCA (randompca.cpp:168-218) */
+   int replicated_solver; /* multi-GPU only: 1 = every rank keeps whole copies of the Krylov basis and repeats the
+                     * orthogonalisation (round 2's scheme: one all-reduce per apply); 0 (default) = row-sharded, see fpca_set_rank */
    int max_applies; /* hard cap on block applies, overriding the budget derived from maxiter; 0 = none.  Must allow at least
                      * ceil(ndim / b) of them (FPCA_EINVAL otherwise: fewer basis vectors than wanted pairs) */
 } fpca_pca_opts;

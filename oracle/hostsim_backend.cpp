@@ -30,10 +30,22 @@ typedef int (*hostsim_allreduce_fn)(void *user, double *buf, uint64_t count);
 
 class HostSimBackend : public fpca::BlockBackend {
  public:
-   HostSimBackend(orc_data *d, int b, uint32_t block_size, hostsim_allreduce_fn ar, void *user)
+   // nranks > 1 (with an all-reduce callback): the row-sharded solver of backend.hpp RowShard, on host memory -- every block
+   // is this rank's slice of rows, the operator is all-gather -> oracle operator on the SNP shard -> reduce-scatter (both
+   // built from the callback's sum, like the HIP backend does over a caller-supplied all-reduce), the Gram coefficients are
+   // all-reduced.  nranks <= 1: whole blocks, one all-reduce of the N x b product per apply (round 2's scheme).
+   HostSimBackend(orc_data *d, int b, uint32_t block_size, hostsim_allreduce_fn ar, void *user, int nranks = 1, int rank = 0)
        : d_(d), b_(b), N_(orc_N(d)), ar_(ar), user_(user)
    {
       op_ = orc_op_new(d, block_size ? block_size : (uint32_t)orc_nsnps(d), 1);
+      rows_ = N_;
+      if (ar && nranks > 1) {
+         sh_ = fpca::RowShard::make(N_, nranks, rank, 1, 1);
+         rows_ = sh_.slice_rows();
+         row0_ = (uint64_t)rank * sh_.plen;
+         full_in_.assign((size_t)N_ * b_, 0.0);
+         full_out_.assign((size_t)N_ * b_, 0.0);
+      }
    }
    ~HostSimBackend() override { orc_op_free(op_); }
    uint64_t nrows() const override { return N_; }
@@ -45,25 +57,34 @@ class HostSimBackend : public fpca::BlockBackend {
             used_[i] = 1;
             return (int)i;
          }
-      blocks_.emplace_back((size_t)N_ * b_, 0.0);
+      blocks_.emplace_back((size_t)rows_ * b_, 0.0);
       used_.push_back(1);
       return (int)blocks_.size() - 1;
    }
    void free_block(int h) override { used_[h] = 0; }
    void fill_random(int h, uint64_t seed) override
    {
+      std::vector<double> whole((size_t)N_ * b_);
       uint64_t s = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
-      for (auto &v : blocks_[h]) {
+      for (auto &v : whole) {
          s ^= s << 13;
          s ^= s >> 7;
          s ^= s << 17;
          v = (double)(s >> 11) * (1.0 / 9007199254740992.0) - 0.5;
       }
+      take_rows(whole, blocks_[h]); // (sharded: the rows this rank keeps of the block every rank would have generated)
    }
    void apply(int in, int out) override
    {
-      orc_perform_op_mat(op_, blocks_[in].data(), b_, blocks_[out].data());
-      if (ar_ && ar_(user_, blocks_[out].data(), N_ * (uint64_t)b_) != 0) throw fpca::Error(-6, "allreduce failed");
+      if (!sh_.on()) {
+         orc_perform_op_mat(op_, blocks_[in].data(), b_, blocks_[out].data());
+         sum(blocks_[out].data(), N_ * (uint64_t)b_);
+         return;
+      }
+      all_gather(blocks_[in], full_in_);
+      orc_perform_op_mat(op_, full_in_.data(), b_, full_out_.data());
+      sum(full_out_.data(), N_ * (uint64_t)b_); // reduce-scatter = sum + keep my rows
+      take_rows(full_out_, blocks_[out]);
    }
    void gram(const int *a, int nq, int w, double *C) override
    {
@@ -72,16 +93,17 @@ class HostSimBackend : public fpca::BlockBackend {
          const double *A = blocks_[a[q]].data();
          for (int p = 0; p < b_; p++)
             for (int c = 0; c < b_; c++) {
-               const double *ap = A + (size_t)p * N_, *wc = W + (size_t)c * N_;
+               const double *ap = A + (size_t)p * rows_, *wc = W + (size_t)c * rows_;
                double s = 0;
-               for (uint64_t i = 0; i < N_; i++) s += ap[i] * wc[i];
+               for (uint64_t i = 0; i < rows_; i++) s += ap[i] * wc[i];
                C[((size_t)q * b_ + p) * b_ + c] = s;
             }
       }
+      if (sh_.on()) sum(C, (uint64_t)nq * b_ * b_); // row slices: the only collective of the orthogonalisation
    }
    void gemm(const int *a, int nq, const double *C, int init, int out) override
    {
-      std::vector<double> res((size_t)N_ * b_, 0.0);
+      std::vector<double> res((size_t)rows_ * b_, 0.0);
       if (init >= 0) res = blocks_[init];
       for (int q = 0; q < nq; q++) {
          const double *A = blocks_[a[q]].data();
@@ -89,38 +111,77 @@ class HostSimBackend : public fpca::BlockBackend {
             for (int p = 0; p < b_; p++) {
                const double cv = C[((size_t)q * b_ + p) * b_ + c];
                if (cv == 0.0) continue;
-               const double *ap = A + (size_t)p * N_;
-               double *rc = res.data() + (size_t)c * N_;
-               for (uint64_t i = 0; i < N_; i++) rc[i] += ap[i] * cv;
+               const double *ap = A + (size_t)p * rows_;
+               double *rc = res.data() + (size_t)c * rows_;
+               for (uint64_t i = 0; i < rows_; i++) rc[i] += ap[i] * cv;
             }
       }
       blocks_[out] = res;
    }
    void download(int h, int ncols, double *host, int64_t ld) override
    {
-      for (int c = 0; c < ncols; c++) std::memcpy(host + (size_t)c * ld, blocks_[h].data() + (size_t)c * N_, sizeof(double) * N_);
+      const std::vector<double> *src = &blocks_[h];
+      if (sh_.on()) { // a collective: every rank comes here (pca_driver.cpp calls download2 on every rank)
+         all_gather(blocks_[h], full_in_);
+         src = &full_in_;
+      }
+      if (!host) return;
+      for (int c = 0; c < ncols; c++) std::memcpy(host + (size_t)c * ld, src->data() + (size_t)c * N_, sizeof(double) * N_);
+   }
+   void download2(int h, int ncols, double *host, int64_t ld, double *host2, int64_t ld2, const double *scale) override
+   {
+      if (!host && !host2) {
+         if (sh_.on()) download(h, ncols, nullptr, 0);
+         return;
+      }
+      fpca::BlockBackend::download2(h, ncols, host, ld, host2, ld2, scale);
    }
    void upload(int h, int ncols, const double *host, int64_t ld) override
    {
-      std::fill(blocks_[h].begin(), blocks_[h].end(), 0.0);
-      for (int c = 0; c < ncols; c++) std::memcpy(blocks_[h].data() + (size_t)c * N_, host + (size_t)c * ld, sizeof(double) * N_);
+      std::vector<double> whole((size_t)N_ * b_, 0.0);
+      for (int c = 0; c < ncols; c++) std::memcpy(whole.data() + (size_t)c * N_, host + (size_t)c * ld, sizeof(double) * N_);
+      take_rows(whole, blocks_[h]);
    }
    double trace() override
    {
       double t = orc_op_trace(op_);
-      if (ar_ && ar_(user_, &t, 1) != 0) throw fpca::Error(-6, "allreduce failed");
+      sum(&t, 1);
       return t;
    }
 
  private:
+   void sum(double *buf, uint64_t count)
+   {
+      if (ar_ && ar_(user_, buf, count) != 0) throw fpca::Error(-6, "allreduce failed");
+   }
+   // whole: column-major N x b; blk: column-major rows_ x b (rows beyond N are zero)
+   void take_rows(const std::vector<double> &whole, std::vector<double> &blk) const
+   {
+      if (!sh_.on()) {
+         blk = whole;
+         return;
+      }
+      std::fill(blk.begin(), blk.end(), 0.0);
+      for (int c = 0; c < b_; c++)
+         for (uint64_t i = 0; i < rows_ && row0_ + i < N_; i++) blk[i + (size_t)c * rows_] = whole[row0_ + i + (size_t)c * N_];
+   }
+   void all_gather(const std::vector<double> &blk, std::vector<double> &whole)
+   {
+      std::fill(whole.begin(), whole.end(), 0.0);
+      for (int c = 0; c < b_; c++)
+         for (uint64_t i = 0; i < rows_ && row0_ + i < N_; i++) whole[row0_ + i + (size_t)c * N_] = blk[i + (size_t)c * rows_];
+      sum(whole.data(), N_ * (uint64_t)b_);
+   }
    orc_data *d_;
    orc_op *op_;
    int b_;
-   uint64_t N_;
+   uint64_t N_, rows_ = 0, row0_ = 0;
+   fpca::RowShard sh_;
    hostsim_allreduce_fn ar_;
    void *user_;
-   std::vector<std::vector<double>> blocks_; // column-major N x b
+   std::vector<std::vector<double>> blocks_; // column-major rows_ x b
    std::vector<unsigned char> used_;
+   std::vector<double> full_in_, full_out_;  // row-sharded: whole N x b blocks either side of the operator
 };
 
 } // namespace
@@ -128,15 +189,16 @@ class HostSimBackend : public fpca::BlockBackend {
 extern "C" {
 
 /* Runs the product's block Krylov-Schur driver on this rank's shard `d` (an oracle Data object).
+ * nranks / rank: > 1 ranks -> the row-sharded solver (RowShard), 0 or 1 -> whole blocks on every rank.
  * maxiter > 0: --maxiter as the reference counts it (fpca_pca_opts.maxiter); maxiter < 0: fpca_pca_opts.max_applies = -maxiter.
  * info_out: [converged, block_applies, restarts, blockvec].  Returns FPCA_OK / FPCA_ENOTCONVERGED / <0. */
 int hostsim_pca(orc_data *d, int ndim, int blockvec, int maxiter, double tol, int divisor, int max_blocks,
                 uint64_t seed, int verbose, uint64_t P_total, hostsim_allreduce_fn ar, void *user, double *U,
-                double *dvals, double *Px, double *pve, double *trace, int *info_out)
+                double *dvals, double *Px, double *pve, double *trace, int *info_out, int nranks, int rank)
 {
    try {
       const int b = fpca::choose_blockvec(ndim, blockvec);
-      HostSimBackend be(d, b, 0, ar, user);
+      HostSimBackend be(d, b, 0, ar, user, nranks, rank); // nranks > 1: row-sharded solver; <= 1: replicated (round 2)
       fpca_pca_opts o;
       std::memset(&o, 0, sizeof(o));
       o.ndim = ndim;

@@ -20,6 +20,7 @@ from tests.test_host_solver import hostsim  # noqa: E402
 
 def main():
     bed, fam, k, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    replicated = len(sys.argv) > 5 and sys.argv[5] == "replicated"  # round 2's scheme: whole blocks everywhere, one all-reduce per apply
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     N = O.count_fam_rows(fam)
@@ -30,15 +31,19 @@ def main():
     shard = raw[lo * npk:hi * npk].copy()
     d = O.OracleData(packed=shard, N=N, P=hi - lo, stand="binom2")
 
-    calls = {"n": 0, "elems": 0}
+    calls = {"n": 0, "elems": 0, "small": 0, "small_elems": 0}
 
     @C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_uint64)
     def allreduce(user, buf, count):
         a = np.ctypeslib.as_array(buf, shape=(count,))
         t = torch.from_numpy(a)
         dist.all_reduce(t)  # in place on the shared memory
-        calls["n"] += 1
-        calls["elems"] += int(count)
+        if count % N == 0 and count // N in (16, 32, 48, 64):  # block-sized (N x b) sums vs the small ones (Gram coefficients, the trace)
+            calls["n"] += 1
+            calls["elems"] += int(count)
+        else:
+            calls["small"] += 1
+            calls["small_elems"] += int(count)
         return 0
 
     L = hostsim()
@@ -49,7 +54,7 @@ def main():
     tr = C.c_double()
     info = (C.c_int * 4)()
     rc = L.hostsim_pca(d.h, k, 0, 500, 1e-8, 2, 0, 1, 0, P_total, allreduce, None, U.ctypes.data, dv.ctypes.data,
-                       Px.ctypes.data, pve.ctypes.data, C.byref(tr), info)
+                       Px.ctypes.data, pve.ctypes.data, C.byref(tr), info, 1 if replicated else world, rank)
     # every rank must hold the same answer (replicated host algebra, deterministic)
     t = torch.from_numpy(dv.copy())
     gathered = [torch.zeros_like(t) for _ in range(world)]
@@ -57,8 +62,9 @@ def main():
     same = all(torch.equal(gathered[0], g) for g in gathered)
     if rank == 0:
         json.dump(dict(rc=rc, d=dv.tolist(), pve=pve.tolist(), trace=tr.value, applies=info[1], b=info[3], same=same,
-                       allreduce_calls=calls["n"], allreduce_elems=calls["elems"], shard=[lo, hi], P_total=P_total,
-                       U0=U[:, 0].tolist()), open(out_path, "w"))
+                       allreduce_calls=calls["n"], allreduce_elems=calls["elems"], small_calls=calls["small"],
+                       small_elems=calls["small_elems"], shard=[lo, hi], P_total=P_total, N=N,
+                       U0=U[:, 0].tolist(), Ulast=U[:, k - 1].tolist()), open(out_path, "w"))
     dist.destroy_process_group()
 
 

@@ -515,3 +515,30 @@ def test_thick_restart_at_full_height_keeps_an_orthonormal_basis(fp):
         assert np.max(np.abs(r["d"] - free["d"]) / free["d"]) < 1e-9
         err, mse, rmse = ctx.check(r["U"], r["d"])
         assert np.all(np.sqrt(err) <= 1.01e-7 * r["d"])
+
+
+@pytest.mark.parametrize("nch", [1, 2, 4])
+def test_row_sharded_solver_path_on_one_rank(fp, monkeypatch, nch):
+    """The row-sharded solver (backend.hpp RowShard; the default with several ranks) forced on ONE rank: all-gather /
+    reduce-scatter go through RCCL's own ncclAllGather / ncclReduceScatter on the hardware (one rank: the only way this box
+    can execute them), K3 runs in row chunks with the reduce-scatter of each chunk on the communication stream, the blocks
+    are slices with the padded chunk layout -- and the solve must give what the plain path gives.  N is chosen so that the
+    last chunk is cut by the end of the matrix."""
+    N, P, k = 40000, 1500, 8
+    with fp.Context.synthetic(N, P, n_pop=6, accum="i8") as ref:
+        r0 = ref.pca(ndim=k, do_loadings=True)
+    monkeypatch.setenv("FPCA_AR_CHUNKS", str(nch))
+    monkeypatch.setenv("FPCA_FORCE_ROWSHARD", "1")
+    with fp.test_hooks(), fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:
+        c.comm_init_rank(1, 0, fp.Context.comm_unique_id())
+        assert c.allreduce_chunks() == nch
+        calls0, _ = c.collective_stats()
+        r = c.pca(ndim=k, do_loadings=True)
+        calls, nbytes = c.collective_stats()
+        assert r["info"]["converged"] == 1 and r["info"]["block_applies"] == r0["info"]["block_applies"]
+        # per apply: nch all-gathers + nch reduce-scatters; + nch all-gathers for the download and for the loadings block
+        assert calls - calls0 == 2 * nch * r["info"]["block_applies"] + 2 * nch
+        assert np.max(np.abs(r["d"] - r0["d"]) / r0["d"]) < 1e-12
+        sg = np.sign(np.sum(r["U"] * r0["U"], axis=0))
+        assert np.max(np.abs(r["U"] * sg - r0["U"])) < 1e-9 and np.max(np.abs(r["V"] * sg - r0["V"])) < 1e-9
+        assert np.max(np.abs(r["Px"] - r["U"] * np.sqrt(r["d"]))) < 1e-12

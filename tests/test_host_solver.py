@@ -21,7 +21,7 @@ def hostsim():
         L.hostsim_pca.restype = C.c_int
         L.hostsim_pca.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_int,
                                   C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.POINTER(C.c_double), C.POINTER(C.c_int)]
+                                  C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.c_int]
         L.hostsim_symeig.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.hostsim_symeig_rows.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.hostsim_symeig_cols.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -37,7 +37,7 @@ def hostsim():
     return HS
 
 
-def run_pca(d, k, blockvec=0, tol=1e-6, maxiter=500, div=2, max_blocks=0, seed=1, allreduce=None, P_total=0):
+def run_pca(d, k, blockvec=0, tol=1e-6, maxiter=500, div=2, max_blocks=0, seed=1, allreduce=None, P_total=0, nranks=1, rank=0):
     L = hostsim()
     N = d.N
     U = np.zeros((N, k), order="F")
@@ -47,7 +47,7 @@ def run_pca(d, k, blockvec=0, tol=1e-6, maxiter=500, div=2, max_blocks=0, seed=1
     tr = C.c_double()
     info = (C.c_int * 4)()
     rc = L.hostsim_pca(d.h, k, blockvec, maxiter, tol, div, max_blocks, seed, 0, P_total, allreduce, None, U.ctypes.data,
-                       dv.ctypes.data, Px.ctypes.data, pve.ctypes.data, C.byref(tr), info)
+                       dv.ctypes.data, Px.ctypes.data, pve.ctypes.data, C.byref(tr), info, nranks, rank)
     return rc, dict(U=U, d=dv, Px=Px, pve=pve, trace=tr.value, converged=info[0], applies=info[1], restarts=info[2], b=info[3])
 
 
