@@ -536,9 +536,16 @@ def test_row_sharded_solver_path_on_one_rank(fp, monkeypatch, nch):
         r = c.pca(ndim=k, do_loadings=True)
         calls, nbytes = c.collective_stats()
         assert r["info"]["converged"] == 1 and r["info"]["block_applies"] == r0["info"]["block_applies"]
-        # per apply: nch all-gathers + nch reduce-scatters; + nch all-gathers for the download and for the loadings block
-        assert calls - calls0 == 2 * nch * r["info"]["block_applies"] + 2 * nch
+        # per apply: nch all-gathers + nch reduce-scatters; + nch all-gathers each for the download and for the loadings block;
+        # + the scalar all-reduce of the trace (one rank: the Gram sums stay local)
+        assert calls - calls0 == 2 * nch * r["info"]["block_applies"] + 2 * nch + 1
         assert np.max(np.abs(r["d"] - r0["d"]) / r0["d"]) < 1e-12
         sg = np.sign(np.sum(r["U"] * r0["U"], axis=0))
-        assert np.max(np.abs(r["U"] * sg - r0["U"])) < 1e-9 and np.max(np.abs(r["V"] * sg - r0["V"])) < 1e-9
+        # the five structured pairs (6 sub-populations) are isolated: same vectors to rounding; the bulk pairs behind them are
+        # only determined to tol x theta / gap by either solve (different row order = different summation order in the Grams)
+        assert np.max(np.abs(r["U"][:, :5] * sg[:5] - r0["U"][:, :5])) < 1e-9 and np.max(np.abs(r["V"][:, :5] * sg[:5] - r0["V"][:, :5])) < 1e-9
+        assert np.max(np.abs(r["U"] * sg - r0["U"])) < 1e-5
+        assert np.max(np.abs(r["U"].T @ r["U"] - np.eye(k))) < 1e-10
+        err, mse, rmse = c.check(r["U"], r["d"])
+        assert np.all(np.sqrt(err) <= 1.01e-6 * r["d"])
         assert np.max(np.abs(r["Px"] - r["U"] * np.sqrt(r["d"]))) < 1e-12
