@@ -101,6 +101,66 @@ def measure_traffic(args, dom):
     return total
 
 
+def e2e_cli(fp, size, k, device):
+    """wall-clock and phases of the flashpca CLI on a synthetic fileset in a fresh directory under /tmp"""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    N, P = (WORKLOADS[size]["N"], WORKLOADS[size]["P"])
+    td = tempfile.mkdtemp(prefix="fpca_e2e_", dir="/tmp")
+    try:
+        pre = os.path.join(td, "syn")
+        t0 = time.perf_counter()
+        with open(pre + ".bed", "wb") as f:
+            f.write(bytes([0x6C, 0x1B, 0x01]))
+            step = max(1, (1 << 30) // ((N + 3) // 4))
+            for j0 in range(0, P, step):
+                with fp.Context.synthetic(N, min(step, P - j0), snp_begin=j0, n_pop=min(2 * k, 64), device=device) as c:
+                    c.download_packed().tofile(f)
+            f.flush()
+            os.fsync(f.fileno())
+        with open(pre + ".fam", "w") as f:
+            f.write("".join("F%d I%d 0 0 0 -9\n" % (i, i) for i in range(N)))
+        with open(pre + ".bim", "w") as f:
+            f.write("".join("1 rs%d 0 %d A C\n" % (j, j + 1) for j in range(P)))
+        t_write = time.perf_counter() - t0
+        cmd = [fp.CLI_PATH, "--bfile", pre, "--ndim", str(k), "--outload", "load.txt", "--outmeansd", "ms.txt", "--device", str(device)]
+
+        def run(label):
+            t1 = time.perf_counter()
+            r = subprocess.run(cmd, cwd=td, capture_output=True, text=True, env=dict(os.environ, FPCA_TIMING="1"), timeout=600)
+            wall = time.perf_counter() - t1
+            if r.returncode != 0:
+                raise RuntimeError("flashpca CLI failed (%s): %s" % (label, (r.stderr or r.stdout)[-300:]))
+            ph = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"\[fpca-cli\] (.+?)\s+([0-9.]+) ms", r.stderr)}
+            lib_ph = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"\[fpca\] (device init \+ allocations|\.bed -> HBM|solver|run_pca|loadings, mean/sd)\s+([0-9.]+) ms", r.stderr)}
+            return dict(wall_s=wall, phases_ms=ph, library_phases_ms=lib_ph)
+
+        warm = run("warm")
+        warm2 = run("warm")  # (the first run of a fresh binary also pages the executable and libamdhip64 in)
+        if warm2["wall_s"] < warm["wall_s"]:
+            warm = warm2
+        dropped = False
+        try:
+            fd = os.open(pre + ".bed", os.O_RDONLY)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            os.close(fd)
+            dropped = True
+        except Exception:
+            pass
+        cold = run("cold") if dropped else None
+        bed_bytes = os.path.getsize(pre + ".bed")
+        outs = {f: os.path.getsize(os.path.join(td, f)) for f in ("eigenvectors.txt", "pcs.txt", "eigenvalues.txt", "pve.txt", "load.txt", "ms.txt")}
+        return dict(command="flashpca --bfile syn --ndim %d --outload load.txt --outmeansd ms.txt" % k, samples=N, snps=P, bed_bytes=bed_bytes,
+                    output_bytes=sum(outs.values()), fileset_write_s=t_write, warm=warm,
+                    cold=cold, cold_note="after fsync + posix_fadvise(DONTNEED) on the .bed: whether the pages really left the cache depends on the "
+                                         "file system under /tmp (an overlay / tmpfs keeps them)")
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +178,9 @@ def main():
     ap.add_argument("--no-pca", action="store_true")
     ap.add_argument("--no-pca-hard", action="store_true", help="skip the second full PCA on a slowly converging spectrum (4 sub-populations)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra exact-int8-mode measurement of the same workload")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run of the flashpca CLI on a fileset in /tmp")
+    ap.add_argument("--e2e-size", default="cfg2", choices=["cfg2", "cfg3"],
+                    help="fileset of the end-to-end CLI run [cfg2: 50000 x 20000, 250 MB; cfg3 writes and reads 12.5 GB]")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the bounded baseline sample")
     ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "replay", "none"],
                     help="roofline.traffic: measure = two extra rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of a 2-step run of the "
@@ -492,6 +555,16 @@ def main():
                 if "pca" in out:
                     alt["pca_eigenvalue_max_rel_diff_between_modes"] = float(max(abs(a - c) / abs(c) for a, c in zip(r2["d"], r["d"])))
             out["fp64_mode" if other == "fp64" else "exact_int8_mode"] = alt
+
+    # ---- the whole program: `flashpca --bfile ... --ndim k --outload ... --outmeansd ...` on a fileset written to /tmp, the
+    # reference's own process boundary (flashpca.cpp:589-604, 755-813): text parse, .bed upload, K1, solve, loadings, four
+    # text files + loadings + mean/sd.  Phases as the CLI prints them under FPCA_TIMING=1; once with the .bed in the page
+    # cache (just written), once after asking the kernel to drop it (fsync + posix_fadvise DONTNEED) ---------------------
+    if world == 1 and not args.no_e2e:
+        try:
+            out["e2e_cli"] = e2e_cli(fp, args.e2e_size, k, local_rank)
+        except Exception as e:  # never lose the line over the side measurement
+            out["e2e_cli"] = dict(error=str(e)[:300])
 
     # ---- CPU baseline: the oracle (restated reference path) on a bounded sample, rank 0, N=1 only -----------
     if world == 1 and not args.no_cpu_baseline:

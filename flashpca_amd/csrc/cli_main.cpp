@@ -15,9 +15,11 @@
 #include <ctime>
 #include <iostream>
 #include <map>
+#include <exception>
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <atomic>
@@ -591,12 +593,43 @@ int main(int argc, char *argv[])
          if (phase_timing && !quiet) std::fprintf(stderr, "[fpca-cli] %-32s %8.3f ms\n", what, std::chrono::duration<double>(now - last).count() * 1e3);
          last = now;
       };
-      // N = number of rows of the .fam whose 6th column parses as a number (flashpca.cpp:589 -> data.cpp:408-413)
-      fpca::TextMatrix pheno = fpca::read_text(fam_file, 6);
-      const uint64_t N = pheno.rows;
+      // One GPU: the HIP runtime starts up (~0.1 s) on a helper thread while this one reads the text files, and the .bim is
+      // parsed on another while the .fam is (only N, from the .fam, is needed before the upload can start).  With --gpus the
+      // parent must not touch HIP, nor hold threads, before it forks: everything stays on this thread.
+      struct Joiner { // (joins on every way out of the try block, exceptions included)
+         std::vector<std::thread> th;
+         ~Joiner()
+         {
+            for (auto &t : th)
+               if (t.joinable()) t.join();
+         }
+      } helpers;
+      if (ngpus == 1) helpers.th.emplace_back([] { (void)fpca_device_count(); });
       std::vector<std::string> snp_ids, ref_alleles, alt_alleles, fam_ids, indiv_ids;
-      fpca::read_plink_bim(bim_file, snp_ids, ref_alleles, alt_alleles);
-      fpca::read_plink_fam(fam_file, fam_ids, indiv_ids);
+      std::exception_ptr bim_error;
+      auto parse_bim = [&] {
+         try {
+            fpca::read_plink_bim(bim_file, snp_ids, ref_alleles, alt_alleles);
+         } catch (...) {
+            bim_error = std::current_exception();
+         }
+      };
+      std::thread bim_thread;
+      if (ngpus == 1) bim_thread = std::thread(parse_bim);
+      // N = number of rows of the .fam whose 6th column parses as a number (flashpca.cpp:589 -> data.cpp:408-413), and the
+      // two id columns (read_plink_fam, flashpca.cpp:591) from the same pass over the file
+      uint64_t N = 0;
+      try {
+         N = fpca::read_fam(fam_file, fam_ids, indiv_ids);
+      } catch (...) {
+         if (bim_thread.joinable()) bim_thread.join();
+         throw;
+      }
+      if (ngpus == 1)
+         bim_thread.join();
+      else
+         parse_bim();
+      if (bim_error) std::rethrow_exception(bim_error);
       if (N == 0) throw std::runtime_error("no samples found in " + fam_file);
       phase(".fam / .bim");
 
@@ -864,58 +897,99 @@ int main(int argc, char *argv[])
       phase("compute");
 
       // ---- write out results (flashpca.cpp:755-878) --------------------------------------------------------
+      // The "Writing ..." lines appear in the reference's order; the files themselves -- eigenvectors, PCs and loadings are
+      // 140 + 140 + 28 MB of text at 500,000 x 100,000 -- are formatted and written CONCURRENTLY, each by its own in-order
+      // writer fed by a share of the CPUs (plink_io.cpp save_text), and the device context (25 GB to give back) is torn
+      // down on another thread meanwhile.  Same bytes as one file after the other.
       const std::vector<std::string> none;
-      if (mode == MODE_PCA) {
-         std::cout << timestamp() << "Writing " << n_dim << " eigenvalues to file " << eigvalfile << std::endl;
-         fpca::save_text(d.data(), n_dim, 1, none, none, eigvalfile, precision);
-
-         std::cout << timestamp() << "Writing " << n_dim << " eigenvectors to file " << eigvecfile << std::endl;
-         std::vector<std::string> rownames(N);
-         for (uint64_t i = 0; i < N; i++) rownames[i] = fam_ids[i] + "\t" + indiv_ids[i];
-         std::vector<std::string> colnames(n_dim + 1);
-         colnames[0] = "FID\tIID";
-         for (int i = 0; i < n_dim; i++) colnames[i + 1] = "U" + std::to_string(i + 1);
-         fpca::save_text(U.data(), N, n_dim, colnames, rownames, eigvecfile, precision);
-
-         std::cout << timestamp() << "Writing " << n_dim << " PCs to file " << pcfile << std::endl;
-         for (int i = 0; i < n_dim; i++) colnames[i + 1] = "PC" + std::to_string(i + 1);
-         fpca::save_text(Px.data(), N, n_dim, colnames, rownames, pcfile, precision);
-
-         std::cout << timestamp() << "Writing " << n_dim << " proportion variance explained to file " << eigpvefile << std::endl;
-         fpca::save_text(pve.data(), n_dim, 1, none, none, eigpvefile, precision);
-
-         if (do_loadings) {
-            std::cout << timestamp() << "Writing SNP loadings to file " << loadingsfile << std::endl;
-            std::vector<std::string> cn = {"SNP\tRefAllele"};
-            for (int i = 0; i < n_dim; i++) cn.push_back("V" + std::to_string(i + 1));
-            std::vector<std::string> rn(snp_ids.size());
-            for (size_t i = 0; i < rn.size(); i++) rn[i] = snp_ids[i] + "\t" + ref_alleles[i];
-            if (rn.size() != nsnps) throw std::runtime_error("the .bim file has a different number of SNPs than the .bed");
-            fpca::save_text(V.data(), nsnps, n_dim, cn, rn, loadingsfile, precision);
-         }
-      } else if (mode == MODE_PROJECT) {
-         std::vector<std::string> rownames(N);
-         for (uint64_t i = 0; i < N; i++) rownames[i] = fam_ids[i] + "\t" + indiv_ids[i];
-         std::vector<std::string> colnames(k_out + 1);
-         colnames[0] = "FID\tIID";
-         for (int i = 0; i < k_out; i++) colnames[i + 1] = "PC" + std::to_string(i + 1);
-         fpca::save_text(Px.data(), N, k_out, colnames, rownames, projfile, precision);
+      const unsigned cpus = fpca::usable_cpus();
+      std::vector<std::thread> writers;
+      std::exception_ptr write_error;
+      auto launch = [&](auto fn) {
+         writers.emplace_back([&write_error, fn] {
+            try {
+               fn();
+            } catch (...) {
+               write_error = std::current_exception();
+            }
+         });
+      };
+      auto finish_writers = [&] {
+         for (auto &w : writers)
+            if (w.joinable()) w.join();
+         writers.clear();
+         if (write_error) std::rethrow_exception(write_error);
+      };
+      std::vector<std::string> rownames, colnames_u, colnames_pc, cn_load, rn_snp, cn_ms;
+      auto sample_rownames = [&] {
+         rownames.resize(N);
+         const unsigned nt = std::max(1u, std::min(cpus, 8u));
+         std::vector<std::thread> th;
+         for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+               for (uint64_t i = N * t / nt; i < N * (t + 1) / nt; i++) rownames[i] = fam_ids[i] + "\t" + indiv_ids[i];
+            });
+         for (auto &x : th) x.join();
+      };
+      auto snp_rownames = [&] {
+         if (!rn_snp.empty()) return;
+         rn_snp.resize(snp_ids.size());
+         for (size_t i = 0; i < rn_snp.size(); i++) rn_snp[i] = snp_ids[i] + "\t" + ref_alleles[i];
+         if (rn_snp.size() != nsnps) throw std::runtime_error("the .bim file has a different number of SNPs than the .bed");
+      };
+      if (save_meansd && meansd.empty()) { // (--project / --check: the statistics are still on the device)
+         meansd.resize((size_t)nsnps * 2);
+         fpca_ok(fpca_stats(ctx, meansd.data(), nullptr));
       }
-      if (save_meansd) {
-         if (meansd.empty()) {
-            meansd.resize((size_t)nsnps * 2);
-            fpca_ok(fpca_stats(ctx, meansd.data(), nullptr));
+      launch([&] { fpca_destroy(ctx); }); // nothing below needs the device
+      try {
+         if (mode == MODE_PCA) {
+            const unsigned nbig = 2 + (do_loadings ? 1 : 0), share = std::max(2u, cpus / nbig);
+            std::cout << timestamp() << "Writing " << n_dim << " eigenvalues to file " << eigvalfile << std::endl;
+            fpca::save_text(d.data(), n_dim, 1, none, none, eigvalfile, precision);
+
+            std::cout << timestamp() << "Writing " << n_dim << " eigenvectors to file " << eigvecfile << std::endl;
+            sample_rownames();
+            colnames_u.assign(n_dim + 1, "FID\tIID");
+            colnames_pc = colnames_u;
+            for (int i = 0; i < n_dim; i++) {
+               colnames_u[i + 1] = "U" + std::to_string(i + 1);
+               colnames_pc[i + 1] = "PC" + std::to_string(i + 1);
+            }
+            launch([&, share] { fpca::save_text(U.data(), N, n_dim, colnames_u, rownames, eigvecfile, precision, share); });
+
+            std::cout << timestamp() << "Writing " << n_dim << " PCs to file " << pcfile << std::endl;
+            launch([&, share] { fpca::save_text(Px.data(), N, n_dim, colnames_pc, rownames, pcfile, precision, share); });
+
+            std::cout << timestamp() << "Writing " << n_dim << " proportion variance explained to file " << eigpvefile << std::endl;
+            fpca::save_text(pve.data(), n_dim, 1, none, none, eigpvefile, precision);
+
+            if (do_loadings) {
+               std::cout << timestamp() << "Writing SNP loadings to file " << loadingsfile << std::endl;
+               cn_load = {"SNP\tRefAllele"};
+               for (int i = 0; i < n_dim; i++) cn_load.push_back("V" + std::to_string(i + 1));
+               snp_rownames();
+               launch([&, share] { fpca::save_text(V.data(), nsnps, n_dim, cn_load, rn_snp, loadingsfile, precision, share); });
+            }
+         } else if (mode == MODE_PROJECT) {
+            sample_rownames();
+            colnames_pc.assign(k_out + 1, "FID\tIID");
+            for (int i = 0; i < k_out; i++) colnames_pc[i + 1] = "PC" + std::to_string(i + 1);
+            launch([&] { fpca::save_text(Px.data(), N, k_out, colnames_pc, rownames, projfile, precision); });
          }
-         std::cout << timestamp() << "Writing mean + sd file " << meansdfile << std::endl;
-         std::vector<std::string> cn = {"SNP\tRefAllele", "Mean", "SD"};
-         std::vector<std::string> rn(snp_ids.size());
-         for (size_t i = 0; i < rn.size(); i++) rn[i] = snp_ids[i] + "\t" + ref_alleles[i];
-         if (rn.size() != nsnps) throw std::runtime_error("the .bim file has a different number of SNPs than the .bed");
-         fpca::save_text(meansd.data(), nsnps, 2, cn, rn, meansdfile, precision);
+         if (save_meansd) {
+            std::cout << timestamp() << "Writing mean + sd file " << meansdfile << std::endl;
+            cn_ms = {"SNP\tRefAllele", "Mean", "SD"};
+            snp_rownames();
+            launch([&] { fpca::save_text(meansd.data(), nsnps, 2, cn_ms, rn_snp, meansdfile, precision, 2); });
+         }
+      } catch (...) {
+         for (auto &w : writers)
+            if (w.joinable()) w.join(); // (they hold references to this scope)
+         throw;
       }
-      phase("output files");
-      fpca_destroy(ctx);
-      phase("teardown");
+      finish_writers();
+      phase("output files + teardown");
       std::cout << timestamp() << "Goodbye!" << std::endl;
    } catch (std::exception &e) {
       std::cerr << timestamp() << "Exception: " << e.what() << std::endl;

@@ -1245,7 +1245,15 @@ int fpca_create_from_bed(fpca_ctx **out, const char *bed_path, uint64_t N, uint6
       if (snp_begin > nsnps) throw Error(FPCA_EINVAL, "snp_begin beyond the end of the file");
       uint64_t pg = P_g ? P_g : nsnps - snp_begin;
       if (snp_begin + pg > nsnps) throw Error(FPCA_EINVAL, "SNP range beyond the end of the file");
+      const bool timing = std::getenv("FPCA_TIMING") != nullptr;
+      auto tl = std::chrono::steady_clock::now();
+      auto lap = [&](const char *what) {
+         const auto now = std::chrono::steady_clock::now();
+         if (timing) std::fprintf(stderr, "[fpca] %-28s %8.3f ms\n", what, std::chrono::duration<double>(now - tl).count() * 1e3);
+         tl = now;
+      };
       ctx_alloc_common(c, N, pg, stand_method, device, accum);
+      lap("device init + allocations");
       c->P_total = nsnps;
       // stream the shard: contiguous byte range [3 + np*begin, 3 + np*(begin+pg)) of the file -> parallel pread into one of
       // two pinned bounce buffers -> 1-D H2D copy into a device staging buffer -> repitch kernel into the resident matrix;
@@ -1284,6 +1292,7 @@ int fpca_create_from_bed(fpca_ctx **out, const char *bed_path, uint64_t N, uint6
       }
       cleanup();
       ctx_finish_upload(c);
+      lap(".bed -> HBM");
    });
    if (fd >= 0) close(fd);
    if (rc != FPCA_OK) {

@@ -26,9 +26,20 @@ void read_plink_bim(const std::string &filename, std::vector<std::string> &snp_i
 // read_MAF (data.cpp:419-500): MAF column of a plink .frq whose SNP ids must match snp_ids
 std::vector<double> read_maf(const std::string &filename, const std::vector<std::string> &snp_ids);
 
+// What the CLI needs from the .fam in ONE pass over the file: read_text(fam, 6) -- N = its row count, every field from the
+// 6th on must parse as a number, every line must have the same number of fields (flashpca.cpp:589 -> data.cpp:408-413,
+// 504-586) -- and read_plink_fam's two id columns (data.cpp:639-672); same errors as the two calls in that order.
+uint64_t read_fam(const std::string &filename, std::vector<std::string> &fam_ids, std::vector<std::string> &indiv_ids);
+
+// CPUs this process may actually run on at once: hardware threads, affinity mask and cgroup CPU quota (a container on a
+// 256-thread host may own 16 of them; 256 threads against that quota only queue up)
+unsigned usable_cpus();
+
 // save_text (util.h:69-108): header line (if colnames non-empty), then per row  [rowname TAB] v1 TAB v2 ...
 // numbers through operator<< with std::setprecision(precision).  M is column-major rows x cols (ld = rows).
+// max_threads: formatting threads (0 = usable_cpus()); the bytes do not depend on it.
 bool save_text(const double *M, uint64_t rows, uint64_t cols, const std::vector<std::string> &colnames,
-               const std::vector<std::string> &rownames, const std::string &filename, unsigned precision = 7);
+               const std::vector<std::string> &rownames, const std::string &filename, unsigned precision = 7,
+               unsigned max_threads = 0);
 
 } // namespace fpca
