@@ -81,6 +81,7 @@ SIGNATURES = {
     "fpca_version": (C.c_char_p, []),
     "fpca_device_count": (_I, []),
     "fpca_device_name": (_I, [_I, C.c_char_p, _I]),
+    "fpca_warmup": (_I, [_I]),
     "fpca_create": (_I, [C.POINTER(_P), _P, _U64, _U64, _I, _I, _I]),
     "fpca_create_from_bed": (_I, [C.POINTER(_P), C.c_char_p, _U64, _U64, _U64, _I, _I, _I, C.POINTER(_U64)]),
     "fpca_create_synthetic": (_I, [C.POINTER(_P), _U64, _U64, _U64, _U64, _I, _D, _D, _I, _I, _I]),

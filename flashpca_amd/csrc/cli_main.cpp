@@ -15,6 +15,7 @@
 #include <ctime>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <exception>
 #include <new>
 #include <stdexcept>
@@ -604,7 +605,7 @@ int main(int argc, char *argv[])
                if (t.joinable()) t.join();
          }
       } helpers;
-      if (ngpus == 1) helpers.th.emplace_back([] { (void)fpca_device_count(); });
+      if (ngpus == 1) helpers.th.emplace_back([device] { (void)fpca_warmup(device); }); // (errors resurface in fpca_create_from_bed)
       std::vector<std::string> snp_ids, ref_alleles, alt_alleles, fam_ids, indiv_ids;
       std::exception_ptr bim_error;
       auto parse_bim = [&] {
@@ -786,7 +787,22 @@ int main(int argc, char *argv[])
       // the reference prints its dense block geometry here (flashpca.cpp:688-690); the whole packed matrix is one resident block
       std::cout << timestamp() << "blocksize: " << nsnps << " (" << (long long)((N + 3) / 4) * (long long)nsnps << " bytes per block)" << std::endl;
 
-      std::vector<double> U, d, Px, pve, V, meansd;
+      // the big results live in UNINITIALISED memory: a std::vector would zero 80 + 80 + 16 MB on this thread first (35 ms of
+      // page faults at 500,000 x 100,000); the parallel download touches the pages instead
+      struct Buf {
+         std::unique_ptr<double[]> p;
+         size_t n = 0;
+         void resize(size_t k)
+         {
+            p.reset(new double[k]);
+            n = k;
+         }
+         double *data() { return p.get(); }
+         bool empty() const { return n == 0; }
+         double *begin() { return p.get(); }
+         double *end() { return p.get() + n; }
+      } U, Px, V;
+      std::vector<double> d, pve, meansd;
       int k_out = n_dim;
       if (mode == MODE_PCA) {
          std::cout << timestamp() << "PCA begin" << std::endl;
@@ -836,7 +852,10 @@ int main(int argc, char *argv[])
             }
             if (!all_ok) return multi_abort();
             wait_children();
-            if (do_loadings) V.assign(mg.V, mg.V + (size_t)nsnps * n_dim);
+            if (do_loadings) {
+               V.resize((size_t)nsnps * n_dim);
+               std::memcpy(V.data(), mg.V, (size_t)nsnps * n_dim * sizeof(double));
+            }
             meansd.assign(mg.meansd, mg.meansd + (size_t)nsnps * 2);
          }
          if (rc == FPCA_ENOTCONVERGED) // randompca.cpp:210-217
@@ -892,17 +911,18 @@ int main(int argc, char *argv[])
          if (divisor == FPCA_DIVISOR_N1) div = (double)N - 1;
          else if (divisor == FPCA_DIVISOR_P) div = (double)L.rows;
          const double s = std::sqrt(div);
-         for (auto &x : Px) x /= s; // randompca.cpp:818
+         for (double *x = Px.begin(); x != Px.end(); ++x) *x /= s; // randompca.cpp:818
       }
       phase("compute");
 
       // ---- write out results (flashpca.cpp:755-878) --------------------------------------------------------
-      // The "Writing ..." lines appear in the reference's order; the files themselves -- eigenvectors, PCs and loadings are
-      // 140 + 140 + 28 MB of text at 500,000 x 100,000 -- are formatted and written CONCURRENTLY, each by its own in-order
-      // writer fed by a share of the CPUs (plink_io.cpp save_text), and the device context (25 GB to give back) is torn
-      // down on another thread meanwhile.  Same bytes as one file after the other.
+      // The files -- eigenvectors, PCs and loadings are 140 + 140 + 28 MB of text at 500,000 x 100,000 -- are written one
+      // after the other, each by an in-order writer fed by every CPU this process may use (plink_io.cpp save_text: formatting
+      // 22 million numbers IS the output phase; three files at once on a third of the CPUs each measured no faster), while
+      // the device context (25 GB to give back) is torn down on another thread.
       const std::vector<std::string> none;
       const unsigned cpus = fpca::usable_cpus();
+      if (phase_timing && !quiet) std::fprintf(stderr, "[fpca-cli] usable CPUs: %u\n", cpus);
       std::vector<std::thread> writers;
       std::exception_ptr write_error;
       auto launch = [&](auto fn) {
@@ -944,7 +964,7 @@ int main(int argc, char *argv[])
       launch([&] { fpca_destroy(ctx); }); // nothing below needs the device
       try {
          if (mode == MODE_PCA) {
-            const unsigned nbig = 2 + (do_loadings ? 1 : 0), share = std::max(2u, cpus / nbig);
+            const unsigned share = cpus;
             std::cout << timestamp() << "Writing " << n_dim << " eigenvalues to file " << eigvalfile << std::endl;
             fpca::save_text(d.data(), n_dim, 1, none, none, eigvalfile, precision);
 
@@ -956,10 +976,10 @@ int main(int argc, char *argv[])
                colnames_u[i + 1] = "U" + std::to_string(i + 1);
                colnames_pc[i + 1] = "PC" + std::to_string(i + 1);
             }
-            launch([&, share] { fpca::save_text(U.data(), N, n_dim, colnames_u, rownames, eigvecfile, precision, share); });
+            fpca::save_text(U.data(), N, n_dim, colnames_u, rownames, eigvecfile, precision, share);
 
             std::cout << timestamp() << "Writing " << n_dim << " PCs to file " << pcfile << std::endl;
-            launch([&, share] { fpca::save_text(Px.data(), N, n_dim, colnames_pc, rownames, pcfile, precision, share); });
+            fpca::save_text(Px.data(), N, n_dim, colnames_pc, rownames, pcfile, precision, share);
 
             std::cout << timestamp() << "Writing " << n_dim << " proportion variance explained to file " << eigpvefile << std::endl;
             fpca::save_text(pve.data(), n_dim, 1, none, none, eigpvefile, precision);
@@ -969,19 +989,19 @@ int main(int argc, char *argv[])
                cn_load = {"SNP\tRefAllele"};
                for (int i = 0; i < n_dim; i++) cn_load.push_back("V" + std::to_string(i + 1));
                snp_rownames();
-               launch([&, share] { fpca::save_text(V.data(), nsnps, n_dim, cn_load, rn_snp, loadingsfile, precision, share); });
+               fpca::save_text(V.data(), nsnps, n_dim, cn_load, rn_snp, loadingsfile, precision, share);
             }
          } else if (mode == MODE_PROJECT) {
             sample_rownames();
             colnames_pc.assign(k_out + 1, "FID\tIID");
             for (int i = 0; i < k_out; i++) colnames_pc[i + 1] = "PC" + std::to_string(i + 1);
-            launch([&] { fpca::save_text(Px.data(), N, k_out, colnames_pc, rownames, projfile, precision); });
+            fpca::save_text(Px.data(), N, k_out, colnames_pc, rownames, projfile, precision);
          }
          if (save_meansd) {
             std::cout << timestamp() << "Writing mean + sd file " << meansdfile << std::endl;
             cn_ms = {"SNP\tRefAllele", "Mean", "SD"};
             snp_rownames();
-            launch([&] { fpca::save_text(meansd.data(), nsnps, 2, cn_ms, rn_snp, meansdfile, precision, 2); });
+            fpca::save_text(meansd.data(), nsnps, 2, cn_ms, rn_snp, meansdfile, precision);
          }
       } catch (...) {
          for (auto &w : writers)
@@ -991,6 +1011,11 @@ int main(int argc, char *argv[])
       finish_writers();
       phase("output files + teardown");
       std::cout << timestamp() << "Goodbye!" << std::endl;
+      // every file is closed and the context destroyed: leave without running the HIP runtime's static destructors
+      // (tens of milliseconds of unloading code objects and tearing down queues that nobody waits for)
+      std::cout.flush();
+      std::fflush(nullptr);
+      _exit(EXIT_SUCCESS);
    } catch (std::exception &e) {
       std::cerr << timestamp() << "Exception: " << e.what() << std::endl;
       std::cerr << timestamp() << "Terminating" << std::endl;

@@ -245,9 +245,17 @@ void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int devi
    if (accum != FPCA_ACCUM_FP64 && accum != FPCA_ACCUM_FP32 && !i8)
       throw Error(FPCA_EINVAL, "accum must be FPCA_ACCUM_AUTO, FPCA_ACCUM_FP64, FPCA_ACCUM_FP32 or FPCA_ACCUM_I8(2..8)");
    if (i8 && dense) throw Error(FPCA_EINVAL, "the int8-sliced mode needs 2-bit genotype input");
+   const bool timing = std::getenv("FPCA_TIMING") != nullptr;
+   auto tl = std::chrono::steady_clock::now();
+   auto lap = [&](const char *what) {
+      const auto now = std::chrono::steady_clock::now();
+      if (timing) std::fprintf(stderr, "[fpca]   %-26s %8.3f ms\n", what, std::chrono::duration<double>(now - tl).count() * 1e3);
+      tl = now;
+   };
    int ndev = 0;
    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
       throw Error(FPCA_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+   lap("hipGetDeviceCount");
    if (device < 0 || device >= ndev) throw Error(FPCA_ENODEVICE, "device index out of range");
    hipDeviceProp_t prop;
    if (hipGetDeviceProperties(&prop, device) != hipSuccess) throw Error(FPCA_ENODEVICE, "hipGetDeviceProperties failed");
@@ -266,7 +274,9 @@ void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int devi
    c->accum = accum;
    c->i8_S = i8 ? accum - FPCA_ACCUM_I8(0) : 0;
    c->dense = dense;
+   lap("device properties, hipSetDevice");
    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+   lap("stream");
    if (dense) {
       HIP_CHECK(hipMalloc(&c->d_Xd, (size_t)c->P_pad * c->N_pad * sizeof(double)));
       HIP_CHECK(hipMemsetAsync(c->d_Xd, 0, (size_t)c->P_pad * c->N_pad * sizeof(double), c->stream));
@@ -274,6 +284,7 @@ void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int devi
       HIP_CHECK(hipMalloc(&c->d_packed, c->pitch * c->P_pad));
       HIP_CHECK(hipMemsetAsync(c->d_packed, PAD_BYTE, c->pitch * c->P_pad, c->stream));
    }
+   lap("hipMalloc packed + memset");
    HIP_CHECK(hipMalloc(&c->d_lut, c->P_pad * 4 * sizeof(double)));
    HIP_CHECK(hipMalloc(&c->d_mean, c->P_pad * sizeof(double)));
    HIP_CHECK(hipMalloc(&c->d_sd, c->P_pad * sizeof(double)));
@@ -1150,6 +1161,22 @@ int fpca_device_count(void)
    int n = 0;
    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
    return n;
+}
+
+int fpca_warmup(int device)
+{
+   return guarded([&] {
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw Error(FPCA_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+      if (device < 0 || device >= ndev) throw Error(FPCA_ENODEVICE, "device index out of range");
+      HIP_CHECK(hipSetDevice(device));
+      HIP_CHECK(hipFree(nullptr)); // creates the primary context
+      void *p = nullptr;          // first allocation + first pinned allocation: the runtime sets its pools up here
+      HIP_CHECK(hipMalloc(&p, 1 << 20));
+      HIP_CHECK(hipFree(p));
+      HIP_CHECK(hipHostMalloc(&p, 1 << 20, hipHostMallocDefault));
+      HIP_CHECK(hipHostFree(p));
+   });
 }
 
 int fpca_device_name(int device, char *buf, int buflen)

