@@ -1929,9 +1929,11 @@ int fpca_debug_census(int nwg, uint64_t lds_bytes, uint32_t *out)
 int fpca_debug_mfma_peak(int waves_per_simd, int iters, int pattern, double *tflops)
 {
    return guarded([&] {
-      if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 10 || pattern < 0 || (pattern > 3 && pattern != 10 && pattern != 11) || !tflops)
+      if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 10 || pattern < 0 || (pattern > 3 && (pattern < 10 || pattern > 13)) || !tflops)
          throw Error(FPCA_EINVAL, "bad argument");
-      if (pattern >= 10) // v_mfma_i32_32x32x32_i8 (TOP/s): 10 = zero operands, 11 = random operands
+      if (pattern >= 12) // the b = 16 column remainder: 12 = four 32-wide tiles (half of the last one padding), 13 = three + 16x16x64
+         *tflops = kern::mfma_i8_mix_tops(pattern - 12, iters, nullptr);
+      else if (pattern >= 10) // v_mfma_i32_32x32x32_i8 (TOP/s): 10 = zero operands, 11 = random operands
          *tflops = kern::mfma_i8_peak_tops(waves_per_simd, iters, pattern == 11 ? 0x1234567u : 0u, nullptr);
       else
          *tflops = kern::mfma_peak_tflops(waves_per_simd, iters, pattern, nullptr);

@@ -296,16 +296,24 @@ enum { I8_FULL = 0, I8_SKIP_EMPTY = 1, I8_NO_MISSING = 2 };
 // Bit 6 drops the per-chunk barrier: 8.77 -> 8.82 ms, i.e. the barrier and the pipeline refill behind it cost nothing.
 // With an all-zero fp64 operand (same instructions, same traffic; scripts/i8_power_probe.py) the same launch takes 7.07 ms
 // instead of 9.04: the kernel follows the bare MFMA stream's power curve (3470 -> 4540 TOP/s) -- it is energy, not time.
-template <bool TWO_, int MT_, int NT_, int WR_, int WC_, int KC_, int G_, int MODE_ = I8_FULL, int ABL_ = 0>
+// HALF: the last of the NT column tiles has only 16 columns (S b = 112 for b = 16, S = 7: 3.5 tiles).  As a 32-wide tile half
+// of it would multiply zero padding -- an eighth of the kernel's MFMA passes; instead the 16 columns run on
+// v_mfma_i32_16x16x64_i8, which takes TWO 32-k steps at once: the genotype fragments of an even and an odd k-step (lanes =
+// 32 rows x 2 k-halves each) are regrouped by v_permlane16_swap into two 16-row x 64-k operands, the slice-column operand is
+// one ds_read_b128 per lane with the matching (k-half, k-step) -> quarter order.  A bare stream of the two mixes
+// (scripts/mfma_mix_probe.py): 3280 -> 3720 useful TOP/s.
+template <bool TWO_, int MT_, int NT_, int WR_, int WC_, int KC_, int G_, int MODE_ = I8_FULL, int ABL_ = 0, bool HALF_ = false>
 struct I8Cfg {
-   static constexpr bool TWO = TWO_;
+   static constexpr bool TWO = TWO_, HALF = HALF_;
    static constexpr int MT = MT_, NT = NT_, WR = WR_, WC = WC_, KC = KC_, G = G_, NQ = TWO ? 2 : 1, MODE = MODE_;
    static constexpr int ABL = ABL_;
    static constexpr int MATS = MODE == I8_NO_MISSING ? 1 : 2;
+   static constexpr int NTF = HALF ? NT - 1 : NT;       // full 32-column tiles
    static_assert(!(TWO && MATS == 1), "without E there is only one operand");
    static_assert(WR * WC == 4 && MATS * MT * NT <= 16 && (MT == 1 || G == 1) && G <= NT, "shape");
+   static_assert(!HALF || (WC == 1 && MT == 2 && G == 1 && MATS == 1 && !TWO && ABL == 0 && (KC / 32) % 2 == 0), "half-tile variant");
    static constexpr int ROWS = WR * MT * 32;            // workgroup rows
-   static constexpr int COLS = WC * NT * 32;            // workgroup columns of each operand
+   static constexpr int COLS = WC * NT * 32 - (HALF ? 16 : 0); // workgroup columns of each operand
    static constexpr int LDQ = KC + 16;                  // operand tile row stride (bytes)
    static constexpr int QTILE = COLS * LDQ;             // bytes of one operand tile
    static constexpr int STAGE = NQ * QTILE;
@@ -316,7 +324,9 @@ struct I8Cfg {
    static constexpr int PW = KC / 128;                  // 16-byte packed pieces per lane per m-tile (lane half = KC/2 k)
    static constexpr int NSTEP = KS * MT * G;            // micro-steps per chunk
    static constexpr int H = NSTEP / 2;
-   static_assert(COLS % RSTEP == 0 && NSTEP % 2 == 0 && STAGE * 2 <= 160 * 1024, "staging");
+   // dynamic LDS: the double-buffered operand tiles; the epilogue reuses it for 4 waves x NT dumped tiles + the weights
+   static constexpr int LDS_BYTES = (2 * STAGE > 4 * NT * 4096 + 2 * WC * NT * 32 * 8) ? 2 * STAGE : 4 * NT * 4096 + 2 * WC * NT * 32 * 8;
+   static_assert(COLS % RSTEP == 0 && NSTEP % 2 == 0 && LDS_BYTES <= 160 * 1024, "staging");
 };
 
 // returns (MODE == I8_SKIP_EMPTY) whether any lane of the wave holds a missing genotype in this 32-row x 32-k block
@@ -349,7 +359,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
    constexpr bool TWO = C::TWO;
    constexpr int MODE = C::MODE, MATS = C::MATS;
    constexpr int MT = C::MT, NT = C::NT, NQ = C::NQ, KC = C::KC, NP = C::NP, NP1 = C::NP1, NSTEP = C::NSTEP, LDQ = C::LDQ,
-                 H = C::H, G = C::G, PW = C::PW, NPK = MT * PW;
+                 H = C::H, G = C::G, PW = C::PW, NPK = MT * PW, NTF = C::NTF;
+   constexpr bool HALF = C::HALF;
+   constexpr int AMASK = HALF ? 3 : 1; // decoded genotype fragments kept alive: 2, or 4 (even AND odd k-step of both m-tiles)
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int li = lane & 31, kh = lane >> 5;
@@ -379,7 +391,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
    const uint64_t row0 = (uint64_t)rt * C::ROWS;
    const int col0 = zblk * C::COLS;
 
-   v16i acc[MATS][MT][NT]; // [mat][m][n]
+   v16i acc[MATS][MT][NT]; // [mat][m][n]   (HALF: the last n is never touched and costs nothing)
+   v4i acch[MT][2];        // HALF: the 16-column remainder, rows 16 t .. 16 t + 15 of m-tile m in acch[m][t]
+#pragma unroll
+   for (int m = 0; m < MT; m++) acch[m][0] = acch[m][1] = (v4i){0, 0, 0, 0};
 #pragma unroll
    for (int a = 0; a < MATS; a++)
 #pragma unroll
@@ -399,6 +414,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
    for (int m = 0; m < MT; m++) pvoff[m] = (uint32_t)((wr * 32 * MT + 32 * m + li) * pitch + kh * (KC / 8));
    const uint8_t *prow = packed + row0 * pitch;
    const uint32_t aQ0 = lds_base + (uint32_t)(wc * 32 * NT + li) * LDQ + kh * (KC / 2);
+   // HALF: lane (column j = lane & 15, quarter qd = lane >> 4) of the 16x16x64 operand reads k-half qd >> 1 of k-step 2 kp + (qd & 1)
+   const uint32_t aQh0 = lds_base + (uint32_t)(32 * NTF + (lane & 15)) * LDQ + ((lane >> 5) & 1) * (KC / 2) + ((lane >> 4) & 1) * 16;
 
    u4 qreg[NP];
    u4 pk[MT][PW], pkn[MT][PW]; // packed words of the current / next chunk (one dword per k-step)
@@ -442,29 +459,33 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
       // micro-step s -> (ks, m, g); operand fragments are keyed by (ks, g), genotype fragments by (ks, m)
       constexpr int NG = (NT + G - 1) / G; // n-tiles per group (the last group may be shorter)
       v4i bq[2][NQ][NG];
-      v4i ag[2], am[2]; // decoded genotype fragments, index = micro-step parity
-      bool enz[2];      // ... and whether the E fragment has any nonzero at all (wave-uniform)
+      v4i bqh = {0, 0, 0, 0};          // HALF: the 16-column operand of the current pair of k-steps
+      v4i ag[AMASK + 1], am[AMASK + 1]; // decoded genotype fragments, index = micro-step parity (HALF: (k-step parity, m))
+      bool enz[AMASK + 1];             // ... and whether the E fragment has any nonzero at all (wave-uniform)
+      const uint32_t aQh = aQh0 + (uint32_t)buf * C::STAGE;
       auto read_b = [&](auto kk, auto gg, auto par) {
          constexpr int ks = decltype(kk)::value, g = decltype(gg)::value, p = decltype(par)::value;
          static_for<NG>([&](auto jj) {
             constexpr int j = decltype(jj)::value, n = g * NG + j;
-            if constexpr (n < NT) {
+            if constexpr (n < NTF) {
                bq[p][0][j] = lds_read16<32 * n * LDQ + ks * 16>(aQ);
                if constexpr (TWO) bq[p][NQ - 1][j] = lds_read16<32 * n * LDQ + ks * 16>(aQ2);
             }
          });
+         if constexpr (HALF && (ks & 1) == 1) bqh = lds_read16<(ks >> 1) * 32>(aQh); // both k-steps of the pair in one read
       };
       auto wait_b = [&](auto gg, auto par) {
          constexpr int g = decltype(gg)::value, p = decltype(par)::value;
          static_for<NG>([&](auto jj) {
             constexpr int j = decltype(jj)::value, n = g * NG + j;
-            if constexpr (n < NT) {
+            if constexpr (n < NTF) {
                if constexpr (TWO)
                   lds_wait(bq[p][0][j], bq[p][NQ - 1][j]);
                else
                   lds_wait(bq[p][0][j]);
             }
          });
+         if constexpr (HALF) lds_wait(bqh);
       };
       read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       enz[0] = i8_decode<MODE>(pk[0][0][0], ag[0], am[0]);
@@ -502,20 +523,34 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
          // --- this micro-step's MFMAs, the next micro-step's decode in their shadow
          static_for<NG>([&](auto jj) {
             constexpr int j = decltype(jj)::value, n = g * NG + j;
-            if constexpr (n < NT) {
-               acc[0][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ag[akey & 1], bq[bkey & 1][0][j], acc[0][m][n], 0, 0, 0);
+            if constexpr (n < NTF) {
+               acc[0][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ag[akey & AMASK], bq[bkey & 1][0][j], acc[0][m][n], 0, 0, 0);
                if constexpr (MODE == I8_FULL)
-                  acc[1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(am[akey & 1], bq[bkey & 1][NQ - 1][j], acc[1][m][n], 0, 0, 0);
+                  acc[1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(am[akey & AMASK], bq[bkey & 1][NQ - 1][j], acc[1][m][n], 0, 0, 0);
             }
             if constexpr (j == 0 && akey1 != akey && !(C::ABL & 2))
-               enz[akey1 & 1] = i8_decode<MODE>(pk[m1][ks1 >> 2][ks1 & 3], ag[akey1 & 1], am[akey1 & 1]);
+               enz[akey1 & AMASK] = i8_decode<MODE>(pk[m1][ks1 >> 2][ks1 & 3], ag[akey1 & AMASK], am[akey1 & AMASK]);
          });
+         if constexpr (HALF && (ks & 1) == 1) {
+            // the 16 remaining columns over k-steps ks - 1 and ks: row group r of the even / odd fragment = rows 16 (r & 1) ..
+            // of k-half r >> 1; v_permlane16_swap exchanges row groups 1, 3 of its first operand with 0, 2 of its second, which
+            // leaves [even.0, odd.0, even.2, odd.2] (rows 0..15 in all four k quarters) and [even.1, odd.1, even.3, odd.3]
+            v4i t0 = ag[m], t1 = ag[2 + m];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+               const auto r = __builtin_amdgcn_permlane16_swap((unsigned)t0[q], (unsigned)t1[q], false, false);
+               t0[q] = (int)r[0];
+               t1[q] = (int)r[1];
+            }
+            acch[m][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(t0, bqh, acch[m][0], 0, 0, 0);
+            acch[m][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(t1, bqh, acch[m][1], 0, 0, 0);
+         }
          if constexpr (MODE == I8_SKIP_EMPTY) {
-            if (enz[akey & 1]) {
+            if (enz[akey & AMASK]) {
                static_for<NG>([&](auto jj) {
                   constexpr int j = decltype(jj)::value, n = g * NG + j;
                   if constexpr (n < NT)
-                     acc[1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(am[akey & 1], bq[bkey & 1][NQ - 1][j], acc[1][m][n], 0, 0, 0);
+                     acc[1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(am[akey & AMASK], bq[bkey & 1][NQ - 1][j], acc[1][m][n], 0, 0, 0);
                });
             }
          }
@@ -556,12 +591,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
    __syncthreads(); // every wave has finished reading the operand tiles
    constexpr int WREG = NT * 4096; // bytes of a wave's private tile area: [NT][32 rows][32 cols] int32
    double *sW = reinterpret_cast<double *>(smem + 4 * WREG); // weights of this workgroup's slice-columns: [2][COLS]
-   for (int t = tid; t < C::COLS; t += 256) {
-      sW[t] = wg[col0 + t];
-      sW[C::COLS + t] = wm[col0 + t];
+   constexpr int WCOLS = C::WC * NT * 32; // (HALF: the 16 columns missing from the last tile carry zero weights)
+   for (int t = tid; t < WCOLS; t += 256) {
+      sW[t] = t < C::COLS ? wg[col0 + t] : 0.0;
+      sW[WCOLS + t] = t < C::COLS ? wm[col0 + t] : 0.0;
    }
    __syncthreads();
-   static_assert(2 * C::STAGE >= 4 * WREG + 2 * C::COLS * 8, "epilogue LDS layout");
+   static_assert(C::LDS_BYTES >= 4 * WREG + 2 * WCOLS * 8, "epilogue LDS layout");
    int *sT = reinterpret_cast<int *>(smem + wave * WREG);
    const double *sWl = sW + wc * 32 * NT + li;
    const int kb = bw / 32; // a lane's tiles n, n + kb, ... feed the same virtual column 32 ((tile0 + n) % kb) + li
@@ -570,11 +606,21 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
 #pragma unroll
       for (int m = 0; m < MT; m++) {
 #pragma unroll
-         for (int n = 0; n < NT; n++) {
+         for (int n = 0; n < NTF; n++) {
             const v16i v = acc[a][m][n];
 #pragma unroll
             for (int r = 0; r < 16; r++) sT[(n * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + li] = v[r];
             __builtin_amdgcn_sched_barrier(0);
+         }
+         if constexpr (HALF) { // 16x16 C/D map: register r of lane l = D[4 (l >> 4) + r][l & 15]; columns 16..31 of the tile are zero
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+               for (int r = 0; r < 4; r++) {
+                  const int row = 16 * t + 4 * (lane >> 4) + r;
+                  sT[(NTF * 32 + row) * 32 + (lane & 15)] = acch[m][t][r];
+                  sT[(NTF * 32 + row) * 32 + 16 + (lane & 15)] = 0;
+               }
          }
          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
          __builtin_amdgcn_wave_barrier();
@@ -584,7 +630,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
             for (int k = 0; k < kb; k++) {
                double acc64 = 0.0;
                for (int n = NT - 1 - ((NT - 1 - k) % kb); n >= 0; n -= kb) // tiles n == k (mod kb), last slice first
-                  acc64 += sWl[a * C::COLS + 32 * n] * (double)sT[(n * 32 + row) * 32 + li];
+                  acc64 += sWl[a * WCOLS + 32 * n] * (double)sT[(n * 32 + row) * 32 + li];
                out[((size_t)(32 * m + row) * 2 + a) * bw + 32 * ((tile0 + k) % kb)] = acc64;
             }
          }
@@ -670,6 +716,7 @@ __global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ p
 // all tiles and KC = 128: 24.3; K2 with the K3 shape: 18.9 -- versus 18.7 / 20.6 for the shapes kept.
 struct I8Shape {
    int nt, zb, rows, cols, kc;
+   bool half; // the last tile is the 16-column remainder (v_mfma_i32_16x16x64_i8), cols = 32 nt - 16
 };
 
 static I8Shape i8_shape(int S, int b, bool two, int mode = I8_FULL)
@@ -682,6 +729,10 @@ static I8Shape i8_shape(int S, int b, bool two, int mode = I8_FULL)
    sh.rows = (two || mode == I8_NO_MISSING) ? 256 : 128;
    sh.cols = 32 * sh.nt;
    sh.kc = 256;
+   // b = 16 with S = 7 slices: 112 slice-columns = 3.5 tiles -- the one-matrix kernel (the default route up to 0.45 % missing
+   // calls) takes the remainder as a half tile
+   sh.half = !two && mode == I8_NO_MISSING && sh.zb == 1 && sh.nt == 4 && S * b == 32 * sh.nt - 16;
+   if (sh.half) sh.cols -= 16;
    return sh;
 }
 
@@ -778,10 +829,10 @@ static void launch_i8(const I8Plan &pl, hipStream_t stream, const uint8_t *packe
 {
    static bool attr_set = false;
    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::STAGE);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<C>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
       attr_set = true;
    }
-   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<C>), dim3(pl.grid), dim3(256), 2 * C::STAGE, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw,
+   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<C>), dim3(pl.grid), dim3(256), C::LDS_BYTES, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw,
                       ws, rows_pad, chunks_total, zb, pl.nA, pl.sB, pl.cpsB, pl.rowB0, pl.rowsB);
 }
 
@@ -844,7 +895,10 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
          }
       } else
 #endif
-      FPCA_I8_K2_NT(I8_NO_MISSING)
+      if (sh.half)
+         launch_i8<I8Cfg<false, 2, 4, 4, 1, 256, 1, I8_NO_MISSING, 0, true>>(FPCA_I8_ARGS);
+      else
+         FPCA_I8_K2_NT(I8_NO_MISSING)
    } else if (mode == I8_SKIP_EMPTY) {
       FPCA_I8_K2_NT(I8_SKIP_EMPTY)
    } else {
@@ -1338,6 +1392,75 @@ __global__ __launch_bounds__(256, 1) void k_mfma_i8_peak(int *out, int iters, ui
    int r;
    asm volatile("s_nop 7\n\ts_nop 7\n\tv_mov_b32 %0, v0" : "=v"(r)::"v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143");
    if (r == 0x7fffffff) out[threadIdx.x] = r;
+}
+
+// diagnostic: what the 16-column remainder of the b = 16 GEMM costs on the matrix pipe.  One loop iteration = the MFMAs of a
+// wave (64 rows) for two 32-k steps against S b = 112 slice-columns, random operands:
+//   MIX = 0: 16 x v_mfma_i32_32x32x32_i8 (4 column tiles; in the 4th, columns 16..31 of the operand are zero padding)
+//   MIX = 1: 12 x 32x32x32 (3 full tiles) + 4 x v_mfma_i32_16x16x64_i8 (the 16 remaining columns, both k-steps at once)
+// Returns useful TOP/s (2 x 64 x 112 x 64 operations per iteration).
+template <int MIX>
+__global__ __launch_bounds__(256, 1) void k_mfma_i8_mix(int *out, int iters, uint32_t seed)
+{
+   const uint32_t l = threadIdx.x & 63;
+   v4i a[4], b[4], bh[4];
+   for (int t = 0; t < 4; t++)
+      for (int q = 0; q < 4; q++) {
+         uint32_t h = (seed + 0x9E3779B9u * (t * 4 + q + 1)) ^ (l * 0x85EBCA6Bu);
+         h ^= h >> 15;
+         h *= 0x2C1B3C6Du;
+         h ^= h >> 12;
+         a[t][q] = (int)(h & 0x02020202u) | (int)((h >> 8) & 0x01010101u); // genotype-like bytes 0..3
+         b[t][q] = (int)(h * 0x9E3779B1u);                                // full-range bytes
+         bh[t][q] = ((l & 31) >= 16) ? 0 : b[t][q];                       // a column tile whose upper 16 columns are padding
+      }
+   v16i acc[16];
+   v4i acch[4];
+   for (int t = 0; t < 16; t++)
+      for (int r = 0; r < 16; r++) acc[t][r] = 0;
+   for (int t = 0; t < 4; t++) acch[t] = (v4i){0, 0, 0, 0};
+   for (int it = 0; it < iters; it++) {
+      if (MIX == 0) {
+#pragma unroll
+         for (int t = 0; t < 16; t++) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t & 3], (t & 3) == 3 ? bh[t >> 2] : b[t & 3], acc[t], 0, 0, 0);
+      } else {
+#pragma unroll
+         for (int t = 0; t < 12; t++) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t & 3], b[t % 3], acc[t], 0, 0, 0);
+#pragma unroll
+         for (int t = 0; t < 4; t++) acch[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t], b[t], acch[t], 0, 0, 0);
+      }
+      asm volatile("" ::: "memory");
+   }
+   int r = 0;
+   for (int t = 0; t < 16; t++) r ^= acc[t][t & 15];
+   for (int t = 0; t < 4; t++) r ^= acch[t][t];
+   if (r == 0x7fffffff) out[threadIdx.x] = r;
+}
+
+double mfma_i8_mix_tops(int mix, int iters, hipStream_t stream)
+{
+   int *d = nullptr;
+   (void)hipMalloc(&d, 4096);
+   hipEvent_t e0, e1;
+   (void)hipEventCreate(&e0);
+   (void)hipEventCreate(&e1);
+   auto go = [&](int n) {
+      if (mix)
+         hipLaunchKernelGGL(k_mfma_i8_mix<1>, dim3(256), dim3(256), 0, stream, d, n, 0x1234567u);
+      else
+         hipLaunchKernelGGL(k_mfma_i8_mix<0>, dim3(256), dim3(256), 0, stream, d, n, 0x1234567u);
+   };
+   go(iters / 10);
+   (void)hipEventRecord(e0, stream);
+   go(iters);
+   (void)hipEventRecord(e1, stream);
+   (void)hipEventSynchronize(e1);
+   float ms = 0;
+   (void)hipEventElapsedTime(&ms, e0, e1);
+   (void)hipEventDestroy(e0);
+   (void)hipEventDestroy(e1);
+   (void)hipFree(d);
+   return 256.0 * 4 * (double)iters * 2.0 * 64 * 112 * 64 / (ms * 1e-3) / 1e12;
 }
 
 double mfma_i8_peak_tops(int waves_per_simd, int iters, uint32_t fill, hipStream_t stream)
