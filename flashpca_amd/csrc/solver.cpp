@@ -257,6 +257,8 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    int n = 0;
    uint64_t reseed = o.seed * 7919 + 13;
    int skip_rr = 0; // Rayleigh-Ritz tests to skip (set after a test that ended far from convergence)
+   double prev_worst = 0; // worst relative residual of the previous test and the apply count it was made at
+   int prev_step = 0;
 
    while (res.block_applies < o.max_applies) {
       const int m = (int)V.size();
@@ -474,6 +476,20 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       }
       if (res.block_applies >= o.max_applies) break;
       skip_rr = worst > 1e6 * o.tol ? 2 : worst > 1e3 * o.tol ? 1 : 0;
+      // Slowly converging spectra (k reaching into the bulk: 150+ applies) spend their host time in tests that cannot
+      // succeed: the worst residual falls by a few per cent per apply.  From the decay between this test and the previous
+      // one the number of applies still needed is estimated, and the next test is placed half-way there (at most 8 applies
+      // ahead; a restart always tests).  Computed from the Ritz data only, so every rank skips alike.
+      if (prev_worst > 0 && worst < prev_worst && worst > o.tol && res.block_applies > prev_step) {
+         const double rho = std::pow(worst / prev_worst, 1.0 / (double)(res.block_applies - prev_step));
+         if (rho < 1.0 && rho > 0.0) {
+            const double n_est = std::log(o.tol / worst) / std::log(rho);
+            const int rate_skip = (int)std::min(8.0, std::max(0.0, std::floor(n_est / 2.0) - 1.0));
+            skip_rr = std::max(skip_rr, rate_skip);
+         }
+      }
+      prev_worst = worst;
+      prev_step = res.block_applies;
 
       if (m + 1 > mcap) {
          // ---- thick restart: keep the best Ritz vectors + the new residual block ----------------------
