@@ -81,7 +81,7 @@ def measure_traffic(args, dom):
         with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
                    os.path.abspath(__file__), "--workload", args.workload, "--accum", args.accum, "--blockvec", str(args.blockvec),
-                   "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pca", "--no-alt", "--traffic", "none"]
+                   "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pca", "--no-alt", "--no-e2e", "--traffic", "none"]
             subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True,
                            env={k: v for k, v in dict(os.environ, TMPDIR="/tmp").items() if k != "LD_PRELOAD"})
             fs = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
@@ -371,11 +371,11 @@ def main():
     # `replay`: the committed passes of the same workload under profiles/.  `traffic_source` says which.
     roofline["algorithmic_bytes"] = float((N + 3) // 4) * P_rank + 8.0 * b * (N + P_rank)
     roofline["traffic_measured_in_this_run"] = False
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     mode = args.traffic
     if mode == "auto":
         import shutil
 
-        under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
         mode = "measure" if (world == 1 and shutil.which("rocprofv3") and args.accum in ("i8", "fp64") and not under_profiler) else "replay"
     if mode == "measure" and world == 1:
         try:
@@ -560,7 +560,7 @@ def main():
     # reference's own process boundary (flashpca.cpp:589-604, 755-813): text parse, .bed upload, K1, solve, loadings, four
     # text files + loadings + mean/sd.  Phases as the CLI prints them under FPCA_TIMING=1; once with the .bed in the page
     # cache (just written), once after asking the kernel to drop it (fsync + posix_fadvise DONTNEED) ---------------------
-    if world == 1 and not args.no_e2e:
+    if world == 1 and not args.no_e2e and not under_profiler:  # (a profiler would follow the CLI child process too)
         try:
             out["e2e_cli"] = e2e_cli(fp, args.e2e_size, k, local_rank)
         except Exception as e:  # never lose the line over the side measurement

@@ -1,9 +1,9 @@
 # Regenerates the committed profile evidence of a round:  bash scripts/gpu_profile_round.sh r02
 # (run through gpurun; writes under gpurun_out/<round>/, scripts/copy_profiles.sh copies the summaries into profiles/)
-R=${1:-r02}
+R=${1:-r03}
 mkdir -p gpurun_out/$R; export TMPDIR=/tmp
 PMC_SQ="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-Q="--no-cpu-baseline --no-pca-hard"
+Q="--no-cpu-baseline --no-pca-hard --no-e2e"
 # the default line = the driver's command (500k x 100k headline, exact-integer mode; carries the fp64 kernels' numbers as
 # fp64_mode, the CPU baseline and both PCA solves), then the other workloads and the explicit modes
 python bench.py > gpurun_out/$R/bench_cfg3_n1.json 2> gpurun_out/$R/bench_cfg3_n1.err
@@ -24,9 +24,9 @@ for a in i8 fp64; do
     for kind in fetch write sq; do
       case $kind in fetch) C="FETCH_SIZE";; write) C="WRITE_SIZE";; sq) C="--kernel-trace $PMC_SQ";; esac
       if [ $kind = sq ]; then
-        rocprofv3 --kernel-trace --pmc $PMC_SQ --output-format csv -d gpurun_out/$R/pmc_${kind}_${wl}_$a -o pmc -- python bench.py --workload $wl --accum $a --steps $st --warmup 1 --no-cpu-baseline --no-pca --no-alt --traffic none > /dev/null 2>&1
+        rocprofv3 --kernel-trace --pmc $PMC_SQ --output-format csv -d gpurun_out/$R/pmc_${kind}_${wl}_$a -o pmc -- python bench.py --workload $wl --accum $a --steps $st --warmup 1 --no-cpu-baseline --no-pca --no-alt --no-e2e --traffic none > /dev/null 2>&1
       else
-        rocprofv3 --pmc $C --output-format csv -d gpurun_out/$R/pmc_${kind}_${wl}_$a -o pmc -- python bench.py --workload $wl --accum $a --steps $st --warmup 1 --no-cpu-baseline --no-pca --no-alt --traffic none > /dev/null 2>&1
+        rocprofv3 --pmc $C --output-format csv -d gpurun_out/$R/pmc_${kind}_${wl}_$a -o pmc -- python bench.py --workload $wl --accum $a --steps $st --warmup 1 --no-cpu-baseline --no-pca --no-alt --no-e2e --traffic none > /dev/null 2>&1
       fi
     done
   done
@@ -36,7 +36,12 @@ python scripts/summarise_pmc.py gpurun_out/$R _fp64 > gpurun_out/$R/pmc_summary.
 python scripts/summarise_pmc.py gpurun_out/$R _i8 > gpurun_out/$R/pmc_summary_i8.json
 python scripts/mfma_i8_peak.py > gpurun_out/$R/mfma_i8_microbench.txt 2>&1
 python scripts/mfma_peak.py > gpurun_out/$R/mfma_f64_microbench.txt 2>&1
-python bench.py --workload cfg5 $Q > gpurun_out/$R/bench_cfg5_n1.json 2>/dev/null
+python bench.py --workload cfg5 $Q --no-e2e > gpurun_out/$R/bench_cfg5_n1.json 2>/dev/null
+python bench.py --blockvec 32 $Q --no-e2e --no-alt > gpurun_out/$R/bench_cfg3_n1_b32.json 2>/dev/null
+python scripts/ortho_slice_cost.py > gpurun_out/$R/ortho_slice_cost.txt 2>&1
+python scripts/mfma_mix_probe.py > gpurun_out/$R/mfma_mix_probe.txt 2>&1
+python scripts/hard_spectrum_once.py > gpurun_out/$R/hard_spectrum.txt 2>&1
+FPCA_TIMING=1 bash scripts/gpu_cli_e2e.sh 500000 100000 3 > gpurun_out/$R/cli_e2e_cfg3.txt 2>&1
 bash scripts/power_sample.sh i8 > gpurun_out/$R/power_sample.txt 2>&1
 # slim the raw traces before they travel back (the stats CSVs are what profiles/ keeps)
 find gpurun_out/$R -name "*kernel_trace.csv" -size +2M -delete; find gpurun_out/$R -name "*counter_collection.csv" -size +8M -delete
