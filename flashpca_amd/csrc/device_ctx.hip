@@ -925,7 +925,9 @@ class HipBackend : public BlockBackend {
       const bool force = FPCA_TEST_ENV("FPCA_FORCE_ROWSHARD") != nullptr;
       if (!replicated && ((c->multi() && c->rank_known && c->nranks > 1) || force)) {
          const int G = (c->multi() && c->rank_known) ? c->nranks : 1;
-         const int nch = (c->comm && !c->ar_fn && c->comm_stream && c->i8_S) ? ar_chunks(c) : 1;
+         // (chunk count from N and the communicator only -- NOT from the arithmetic in effect: a rank whose int8 buffers did
+         //  not fit runs the fp64 kernels but must issue the same sequence of collectives as the others)
+         const int nch = (c->comm && !c->ar_fn && c->comm_stream) ? ar_chunks(c) : 1;
          sh_ = RowShard::make(c->N_pad, G, (c->multi() && c->rank_known) ? c->rank : 0, nch, 512);
          rows_ = sh_.slice_rows();
          const size_t need = (size_t)sh_.full_rows() * b;
