@@ -1298,14 +1298,14 @@ int fpca_create_from_bed(fpca_ctx **out, const char *bed_path, uint64_t N, uint6
          }
       };
       try {
-         for (int i = 0; i < 2; i++) {
-            HIP_CHECK(hipHostMalloc(&bounce[i], rows_per_chunk * np, hipHostMallocDefault));
-            HIP_CHECK(hipMalloc(&dstage[i], rows_per_chunk * np));
-            HIP_CHECK(hipEventCreate(&done[i]));
-         }
          int slot = 0;
          for (uint64_t r0 = 0; r0 < pg; r0 += rows_per_chunk, slot ^= 1) {
             const uint64_t nr = std::min(rows_per_chunk, pg - r0);
+            if (!bounce[slot]) { // the second slot's 64 MB of pinned memory (14 ms to allocate) come while the first chunk is on the wire
+               HIP_CHECK(hipHostMalloc(&bounce[slot], std::min(rows_per_chunk, pg) * np, hipHostMallocDefault));
+               HIP_CHECK(hipMalloc(&dstage[slot], std::min(rows_per_chunk, pg) * np));
+               HIP_CHECK(hipEventCreate(&done[slot]));
+            }
             HIP_CHECK(hipEventSynchronize(done[slot])); // the previous copy out of this slot has finished
             const uint64_t want = nr * np;
             const off_t off = (off_t)(3 + np * (snp_begin + r0)); // data.cpp:218

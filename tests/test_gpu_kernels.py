@@ -517,14 +517,15 @@ def test_thick_restart_at_full_height_keeps_an_orthonormal_basis(fp):
         assert np.all(np.sqrt(err) <= 1.01e-7 * r["d"])
 
 
-@pytest.mark.parametrize("nch", [1, 2, 4])
-def test_row_sharded_solver_path_on_one_rank(fp, monkeypatch, nch):
+@pytest.mark.parametrize("nch,k", [(1, 8), (2, 8), (4, 8), (2, 20)])  # k = 20: two blocks of Ritz vectors to gather
+def test_row_sharded_solver_path_on_one_rank(fp, monkeypatch, nch, k):
     """The row-sharded solver (backend.hpp RowShard; the default with several ranks) forced on ONE rank: all-gather /
     reduce-scatter go through RCCL's own ncclAllGather / ncclReduceScatter on the hardware (one rank: the only way this box
     can execute them), K3 runs in row chunks with the reduce-scatter of each chunk on the communication stream, the blocks
     are slices with the padded chunk layout -- and the solve must give what the plain path gives.  N is chosen so that the
     last chunk is cut by the end of the matrix."""
-    N, P, k = 40000, 1500, 8
+    N, P = 40000, 1500
+    kb = -(-k // 16)
     with fp.Context.synthetic(N, P, n_pop=6, accum="i8") as ref:
         r0 = ref.pca(ndim=k, do_loadings=True)
     monkeypatch.setenv("FPCA_AR_CHUNKS", str(nch))
@@ -538,7 +539,7 @@ def test_row_sharded_solver_path_on_one_rank(fp, monkeypatch, nch):
         assert r["info"]["converged"] == 1 and r["info"]["block_applies"] == r0["info"]["block_applies"]
         # per apply: nch all-gathers + nch reduce-scatters; + nch all-gathers each for the download and for the loadings block;
         # + the scalar all-reduce of the trace (one rank: the Gram sums stay local)
-        assert calls - calls0 == 2 * nch * r["info"]["block_applies"] + 2 * nch + 1
+        assert calls - calls0 == 2 * nch * r["info"]["block_applies"] + 2 * nch * kb + 1
         assert np.max(np.abs(r["d"] - r0["d"]) / r0["d"]) < 1e-12
         sg = np.sign(np.sum(r["U"] * r0["U"], axis=0))
         # the five structured pairs (6 sub-populations) are isolated: same vectors to rounding; the bulk pairs behind them are

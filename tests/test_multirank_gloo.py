@@ -22,20 +22,14 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,k,mode", [(2, 10, "rowshard"), (3, 10, "rowshard"), (2, 20, "rowshard"),  # k = 20: two blocks of Ritz
-                                          (2, 10, "replicated"), (3, 10, "replicated")])         # vectors at the automatic width 16
-def test_sharded_pca_matches_golden(golden_dir, tmp_path, world, k, mode):
-    name = "data_chr1"
-    g = json.load(open(os.path.join(golden_dir, "golden_%s_binom2.json" % name)))
+def run_world(world, bed, fam, k, out, mode):
     port = free_port()
-    out = str(tmp_path / "res.json")
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"),
-                                       os.path.join(golden_dir, name + ".bed"), os.path.join(golden_dir, name + ".fam"),
-                                       str(k), out, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), bed, fam, str(k), out, mode],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
         try:
@@ -45,7 +39,39 @@ def test_sharded_pca_matches_golden(golden_dir, tmp_path, world, k, mode):
             o, _ = p.communicate()
         logs.append(o.decode(errors="replace"))
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
-    r = json.load(open(out))
+    return json.load(open(out))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_small_sample_path(tmp_path, world):
+    """Fewer than three blocks of samples (N = 40, k = 8): the solver forms X X' from applies on the identity (dense_small)
+    -- upload, apply and download are all collectives in the row-sharded backend, and every rank must walk through them
+    alike."""
+    from oracle import oracle as O
+
+    N, P, k = 40, 301, 8
+    rng = np.random.default_rng(world)
+    packed = rng.integers(0, 256, size=(P, (N + 3) // 4), dtype=np.uint8)
+    bed, fam = str(tmp_path / "t.bed"), str(tmp_path / "t.fam")
+    with open(bed, "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x01]))
+        f.write(packed.tobytes())
+    open(fam, "w").write("".join("F%d I%d 0 0 0 -9\n" % (i, i) for i in range(N)))
+    r = run_world(world, bed, fam, k, str(tmp_path / "res.json"), "rowshard")
+    assert r["rc"] == 0 and r["same"]
+    X = O.OracleData(packed=packed, N=N, P=P, stand="binom2").dense()
+    w = np.linalg.eigvalsh(X @ X.T / P)[::-1][:k]
+    assert np.max(np.abs(np.array(r["d"]) - w)) < 1e-10 * w[0]
+    assert r["applies"] == -(-N // r["b"])
+
+
+@pytest.mark.parametrize("world,k,mode", [(2, 10, "rowshard"), (3, 10, "rowshard"), (2, 20, "rowshard"),  # k = 20: two blocks of Ritz
+                                          (2, 10, "replicated"), (3, 10, "replicated")])         # vectors at the automatic width 16
+def test_sharded_pca_matches_golden(golden_dir, tmp_path, world, k, mode):
+    name = "data_chr1"
+    g = json.load(open(os.path.join(golden_dir, "golden_%s_binom2.json" % name)))
+    out = str(tmp_path / "res.json")
+    r = run_world(world, os.path.join(golden_dir, name + ".bed"), os.path.join(golden_dir, name + ".fam"), k, out, mode)
     assert r["rc"] == 0 and r["same"]
     ev = np.array(g["eigenvalues_div_p"])[:k]
     assert np.max(np.abs(np.array(r["d"]) - ev) / ev) < 1e-9  # divisor uses the TOTAL SNP count
