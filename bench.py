@@ -454,7 +454,7 @@ def main():
     b_wide = 32 if k <= 64 else 64
     if b_wide != b and not args.no_pca:
         out["apply_at_b%d" % b_wide] = side_apply(ctx, b_wide, max(4, args.steps // 4))
-    # (b) the same matrix with 2 % missing calls (real array data carries 1-2 %; the synthetic spec says 0.1 %): above 0.45 % the
+    # (b) the same matrix with 2 % missing calls (real array data carries 1-2 %; the synthetic spec says 0.1 %): above 0.5 % the
     #     missing-call indicator takes the dense route, a second integer matrix on the matrix cores instead of sparse gathers
     if world == 1 and not args.no_alt and args.accum.startswith("i8"):
         with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=min(2 * k, 64), missing_rate=0.02, device=local_rank,

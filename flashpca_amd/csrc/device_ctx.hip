@@ -488,10 +488,10 @@ int i8_mode(const fpca_ctx *c, int b)
    if (c->n_missing == 0) return I8M_NONE;
    const double rate = (double)c->n_missing / ((double)c->N * (double)std::max<uint64_t>(c->P_g, 1));
    // a gathered fp64 row costs 8 b bytes per missing call; the E half of the int8 GEMMs costs the same whatever the rate.
-   // Measured at 500k x 100k (scripts/sparse_breakeven.py, K2 / K3 stage in ms, sparse | dense): b = 16: 0.3 % 7.2 / 7.5 |
-   // 8.7 / 9.5, 0.5 % 8.7 / 9.2 | 8.8 / 9.5, 1 % 12.8 / 13.1 | 8.8 / 9.5; b = 32: 0.3 % 12.4 / 13.4 | 15.6 / 18.1, 0.5 % 15.7 / 16.5 |
-   // 15.6 / 18.1, 1 % 23.7 / 24.4 | 15.6 / 18.1 -- break-even at 0.5 % for both widths
-   if (sparse_ok && rate <= 0.0045) return I8M_SPARSE;
+   // Measured at 500k x 100k (scripts/sparse_breakeven.py, profiles/r03_sparse_breakeven.txt; K2 / K3 stage in ms, sparse |
+   // dense): b = 16: 0.3 % 6.8 / 7.4 | 9.0 / 9.8, 0.5 % 8.5 / 9.1 | 9.0 / 9.9, 1 % 12.6 / 13.0 | 9.0 / 9.8; b = 32: 0.3 % 12.7 / 13.7 |
+   // 16.2 / 18.8, 0.5 % 15.9 / 16.8 | 16.1 / 18.8, 1 % 23.9 / 24.7 | 16.2 / 18.8 -- the lines cross at 0.51-0.63 % for both widths
+   if (sparse_ok && rate <= 0.005) return I8M_SPARSE;
    return rate < 3e-4 ? I8M_SKIP : I8M_FULL; // (block skipping: only where the sparse path does not apply)
 }
 
@@ -552,7 +552,7 @@ void ensure_sparse(fpca_ctx *c, int b)
    c->sparse_ready = true;
 }
 
-// The sparse route needs 8 bytes per missing call (1.8 GB at 500k x 100k and 0.45 %) plus one N x b plane.  If that does not
+// The sparse route needs 8 bytes per missing call (2 GB at 500k x 100k and 0.5 %) plus one N x b plane.  If that does not
 // fit, the context takes the dense missing-indicator route (both integer matrices on the matrix cores) from here on --
 // out-of-memory only; any other failure is reported.  Returns the mode to use.
 int sparse_or_dense(fpca_ctx *c, int b)

@@ -729,7 +729,7 @@ static I8Shape i8_shape(int S, int b, bool two, int mode = I8_FULL)
    sh.rows = (two || mode == I8_NO_MISSING) ? 256 : 128;
    sh.cols = 32 * sh.nt;
    sh.kc = 256;
-   // b = 16 with S = 7 slices: 112 slice-columns = 3.5 tiles -- the one-matrix kernel (the default route up to 0.45 % missing
+   // b = 16 with S = 7 slices: 112 slice-columns = 3.5 tiles -- the one-matrix kernel (the default route up to 0.5 % missing
    // calls) takes the remainder as a half tile
    sh.half = !two && mode == I8_NO_MISSING && sh.zb == 1 && sh.nt == 4 && S * b == 32 * sh.nt - 16;
    if (sh.half) sh.cols -= 16;
