@@ -77,6 +77,7 @@ def measure_traffic(args, dom):
     import tempfile
 
     total = 0.0
+    alone_ns = []  # the dominant kernel's own duration in these runs: counters serialise the kernels, so nothing runs beside it
     for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):  # KiB; FETCH_SIZE counts 64 of every 128 B on gfx950
         with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
@@ -92,13 +93,17 @@ def measure_traffic(args, dom):
             ids = [int(r["Dispatch_Id"]) for r in rows if "k_gemm_i8" in r["Kernel_Name"]]
             want = {d for i, d in enumerate(sorted(set(ids))) if i % 2 == (0 if dom == "xt_b" else 1)}
             vals = [float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) in want and r["Counter_Name"] == counter]
+            alone_ns += [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows
+                         if int(r["Dispatch_Id"]) in want and r["Counter_Name"] == counter and r.get("End_Timestamp")]
         else:
             key = "k_xt_b" if dom == "xt_b" else "k_x_t"
             vals = [float(r["Counter_Value"]) for r in rows if key in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            alone_ns += [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows
+                         if key in r["Kernel_Name"] and r["Counter_Name"] == counter and r.get("End_Timestamp")]
         if not vals:
             raise RuntimeError("no launches of the dominant kernel in the counter file")
         total += sum(vals) / len(vals) * scale
-    return total
+    return total, (sum(alone_ns) / len(alone_ns) * 1e-6 if alone_ns else None)
 
 
 def e2e_cli(fp, size, k, device):
@@ -379,8 +384,15 @@ def main():
         mode = "measure" if (world == 1 and shutil.which("rocprofv3") and args.accum in ("i8", "fp64") and not under_profiler) else "replay"
     if mode == "measure" and world == 1:
         try:
-            roofline["traffic"] = measure_traffic(args, dom)
+            roofline["traffic"], ms_alone = measure_traffic(args, dom)
             roofline["traffic_measured_in_this_run"] = True
+            if ms_alone:
+                # beside `frac` (HIP events inside the timed region, where the sparse gathers of the same stage run on the
+                # low-priority stream UNDER the GEMM and stretch it): the same kernel with the chip to itself
+                per_launch = roofline.get("ops_per_launch", roofline.get("flops_per_launch"))
+                roofline["kernel_alone"] = dict(ms=ms_alone, achieved=per_launch / (ms_alone * 1e-3) / 1e12,
+                                                frac=per_launch / (ms_alone * 1e-3) / 1e12 / roofline["peak"],
+                                                source="durations of the same launches in the two counter child runs (counters serialise the kernels)")
             roofline["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child runs of this bench, 2 block applies "
                                           "each, right after the timed region): FETCH_SIZE x2 + WRITE_SIZE per launch of the dominant kernel")
         except Exception as e:  # no rocprofv3, counters busy, time-out: fall back to the committed passes
