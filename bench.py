@@ -479,6 +479,23 @@ def main():
             out["apply_at_missing_2pct"] = sm
 
     # ---- one full PCA solve to convergence (reported, not the timed region) -------------------------------
+    watchdog = None
+    if not args.no_pca and world > 1:
+        # With several ranks fpca_pca runs the row-sharded solver (all-gather / reduce-scatter inside RCCL) -- a path no
+        # multi-GPU box has executed yet.  The line the driver waits for must not depend on it: if the solves have not come
+        # back after two minutes, every rank leaves and rank 0 prints the line with what has been measured so far.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["pca"] = dict(error="fpca_pca did not return within 120 s on %d ranks (collective hang?); the block apply above is unaffected" % world)
+                sys.stdout.flush()
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(120.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
     if not args.no_pca:
         # two solves: the first one also allocates the Krylov basis blocks and the solver's scratch (kept by the context
         # afterwards), `wall_s` is the second
@@ -509,6 +526,11 @@ def main():
                           wall_minus_apply_s=wall - info["seconds_apply"],
                           eigenvalue_1=float(r["d"][0]), eigenvalue_k=float(r["d"][-1]),
                           max_rel_residual=info["max_residual"])
+        if world > 1:
+            out["pca"]["solver"] = "row-sharded (all-gather -> K2, K3 -> reduce-scatter per apply; every rank orthogonalises N / %d rows)" % world
+            out["pca"]["collectives"] = dict(zip(("calls", "bytes"), ctx.collective_stats()))
+    if watchdog is not None:
+        watchdog.cancel()
 
     # ---- the same solve on a slowly converging spectrum: 4 sub-populations, so that 17 of the 20 wanted eigenvalues sit in
     # the bulk (231 single-vector ops instead of 42 in the probe) -- the cost of a PCA whose k reaches past the
