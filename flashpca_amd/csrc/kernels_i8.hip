@@ -311,7 +311,7 @@ struct I8Cfg {
    static constexpr int NTF = HALF ? NT - 1 : NT;       // full 32-column tiles
    static_assert(!(TWO && MATS == 1), "without E there is only one operand");
    static_assert(WR * WC == 4 && MATS * MT * NT <= 16 && (MT == 1 || G == 1) && G <= NT, "shape");
-   static_assert(!HALF || (WC == 1 && MT == 2 && G == 1 && MATS == 1 && !TWO && ABL == 0 && (KC / 32) % 2 == 0), "half-tile variant");
+   static_assert(!HALF || (WC == 1 && MT == 2 && G == 1 && MODE != I8_SKIP_EMPTY && ABL == 0 && (KC / 32) % 2 == 0), "half-tile variant");
    static constexpr int ROWS = WR * MT * 32;            // workgroup rows
    static constexpr int COLS = WC * NT * 32 - (HALF ? 16 : 0); // workgroup columns of each operand
    static constexpr int LDQ = KC + 16;                  // operand tile row stride (bytes)
@@ -392,9 +392,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
    const int col0 = zblk * C::COLS;
 
    v16i acc[MATS][MT][NT]; // [mat][m][n]   (HALF: the last n is never touched and costs nothing)
-   v4i acch[MT][2];        // HALF: the 16-column remainder, rows 16 t .. 16 t + 15 of m-tile m in acch[m][t]
+   v4i acch[MATS][MT][2];  // HALF: the 16-column remainder, rows 16 t .. 16 t + 15 of m-tile m in acch[mat][m][t]
 #pragma unroll
-   for (int m = 0; m < MT; m++) acch[m][0] = acch[m][1] = (v4i){0, 0, 0, 0};
+   for (int a = 0; a < MATS; a++)
+#pragma unroll
+      for (int m = 0; m < MT; m++) acch[a][m][0] = acch[a][m][1] = (v4i){0, 0, 0, 0};
 #pragma unroll
    for (int a = 0; a < MATS; a++)
 #pragma unroll
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
       // micro-step s -> (ks, m, g); operand fragments are keyed by (ks, g), genotype fragments by (ks, m)
       constexpr int NG = (NT + G - 1) / G; // n-tiles per group (the last group may be shorter)
       v4i bq[2][NQ][NG];
-      v4i bqh = {0, 0, 0, 0};          // HALF: the 16-column operand of the current pair of k-steps
+      v4i bqh = {0, 0, 0, 0}, bqh2 = {0, 0, 0, 0}; // HALF: the 16-column operand(s) of the current pair of k-steps
       v4i ag[AMASK + 1], am[AMASK + 1]; // decoded genotype fragments, index = micro-step parity (HALF: (k-step parity, m))
       bool enz[AMASK + 1];             // ... and whether the E fragment has any nonzero at all (wave-uniform)
       const uint32_t aQh = aQh0 + (uint32_t)buf * C::STAGE;
@@ -472,7 +474,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
                if constexpr (TWO) bq[p][NQ - 1][j] = lds_read16<32 * n * LDQ + ks * 16>(aQ2);
             }
          });
-         if constexpr (HALF && (ks & 1) == 1) bqh = lds_read16<(ks >> 1) * 32>(aQh); // both k-steps of the pair in one read
+         if constexpr (HALF && (ks & 1) == 1) { // both k-steps of the pair in one read
+            bqh = lds_read16<(ks >> 1) * 32>(aQh);
+            if constexpr (TWO) bqh2 = lds_read16<(ks >> 1) * 32 + C::QTILE>(aQh);
+         }
       };
       auto wait_b = [&](auto gg, auto par) {
          constexpr int g = decltype(gg)::value, p = decltype(par)::value;
@@ -485,7 +490,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
                   lds_wait(bq[p][0][j]);
             }
          });
-         if constexpr (HALF) lds_wait(bqh);
+         if constexpr (HALF) {
+            if constexpr (TWO)
+               lds_wait(bqh, bqh2);
+            else
+               lds_wait(bqh);
+         }
       };
       read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       enz[0] = i8_decode<MODE>(pk[0][0][0], ag[0], am[0]);
@@ -542,8 +552,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
                t0[q] = (int)r[0];
                t1[q] = (int)r[1];
             }
-            acch[m][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(t0, bqh, acch[m][0], 0, 0, 0);
-            acch[m][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(t1, bqh, acch[m][1], 0, 0, 0);
+            acch[0][m][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(t0, bqh, acch[0][m][0], 0, 0, 0);
+            acch[0][m][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(t1, bqh, acch[0][m][1], 0, 0, 0);
+            if constexpr (MATS == 2) { // the missing-indicator matrix against its own operand (K3) or the same one (K2)
+               v4i u0 = am[m], u1 = am[2 + m];
+#pragma unroll
+               for (int q = 0; q < 4; q++) {
+                  const auto r = __builtin_amdgcn_permlane16_swap((unsigned)u0[q], (unsigned)u1[q], false, false);
+                  u0[q] = (int)r[0];
+                  u1[q] = (int)r[1];
+               }
+               acch[1][m][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(u0, TWO ? bqh2 : bqh, acch[1][m][0], 0, 0, 0);
+               acch[1][m][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(u1, TWO ? bqh2 : bqh, acch[1][m][1], 0, 0, 0);
+            }
          }
          if constexpr (MODE == I8_SKIP_EMPTY) {
             if (enz[akey & AMASK]) {
@@ -618,7 +639,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
 #pragma unroll
                for (int r = 0; r < 4; r++) {
                   const int row = 16 * t + 4 * (lane >> 4) + r;
-                  sT[(NTF * 32 + row) * 32 + (lane & 15)] = acch[m][t][r];
+                  sT[(NTF * 32 + row) * 32 + (lane & 15)] = acch[a][m][t][r];
                   sT[(NTF * 32 + row) * 32 + 16 + (lane & 15)] = 0;
                }
          }
@@ -731,15 +752,18 @@ static I8Shape i8_shape(int S, int b, bool two, int mode = I8_FULL)
    sh.kc = 256;
    // b = 16 with S = 7 slices: 112 slice-columns = 3.5 tiles -- the one-matrix kernel (the default route up to 0.5 % missing
    // calls) takes the remainder as a half tile
-   sh.half = !two && mode == I8_NO_MISSING && sh.zb == 1 && sh.nt == 4 && S * b == 32 * sh.nt - 16;
-   if (sh.half) sh.cols -= 16;
+   sh.half = mode != I8_SKIP_EMPTY && sh.zb == 1 && sh.nt == 4 && S * b == 32 * sh.nt - 16;
+   if (sh.half) {
+      sh.cols -= 16;
+      sh.rows = 256; // (every half-tile instantiation is 4 waves x 64 rows, the two-matrix K2 one included)
+   }
    return sh;
 }
 
 int gemm_i8_nsc_pad(int S, int b)
 {
    const I8Shape s2 = i8_shape(S, b, false), s3 = i8_shape(S, b, true); // one padded width serves both kernels
-   return std::max(s2.zb * s2.cols, s3.zb * s3.cols);
+   return std::max(s2.zb * 32 * s2.nt, s3.zb * 32 * s3.nt); // (whole tiles: the zero rows behind S*b carry zero weights)
 }
 
 // Work decomposition of one GEMM launch (see k_gemm_i8): one workgroup per CU, so whole rounds of #CU tiles run unsplit
@@ -814,7 +838,7 @@ static int i8_bw(int b) // lcm(32, b) for b in {16, 32, 48, 64}
 size_t gemm_i8_workspace_doubles(uint64_t rows_pad, uint64_t k_pad, int S, int b, bool two)
 {
    size_t need = 0;
-   for (int mode : {(int)I8_FULL, (int)I8_NO_MISSING}) {
+   for (int mode : {(int)I8_FULL, (int)I8_SKIP_EMPTY, (int)I8_NO_MISSING}) { // (the shapes differ: only FULL / NO_MISSING have the half tile)
       if (two && mode == I8_NO_MISSING) continue;
       const I8Shape sh = i8_shape(S, b, two, mode);
       const I8Plan p = i8_plan(rows_pad, k_pad, sh, i8_bw(b));
@@ -861,7 +885,11 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
    case 7: FPCA_I8_K2(7, MODE_); break;                                                                       \
    default: FPCA_I8_K2(8, MODE_); break;                                                                      \
    }
-   if (two) {
+   if (two && sh.half)
+      launch_i8<I8Cfg<true, 2, 4, 4, 1, 256, 1, I8_FULL, 0, true>>(FPCA_I8_ARGS);
+   else if (!two && sh.half && mode == I8_FULL)
+      launch_i8<I8Cfg<false, 2, 4, 4, 1, 256, 1, I8_FULL, 0, true>>(FPCA_I8_ARGS);
+   else if (two) {
       if (mode == I8_SKIP_EMPTY) {
          if (sh.nt == 3)
             FPCA_I8_K3(3, I8_SKIP_EMPTY);
