@@ -455,3 +455,27 @@ def test_randomised_end_to_end_sweep(built_lib):
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_pca.py"), "40", "11"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all 40 cases ok" in r.stdout
+
+
+def test_config3_dense_missing_route_at_full_size(fp, orc):
+    """2 % missing calls at 500,000 x 100,000: above 0.5 % the exact-integer path multiplies BOTH integer matrices (dosage and
+    missing indicator) on the matrix cores -- the two-matrix kernels with the 16-column remainder that `bench.py` times as
+    `apply_at_missing_2pct` -- instead of gathering sparse rows.  16 columns against the fp64 kernels, one of them and a
+    crossprod against the oracle, and the padded / masked rows stay exactly zero."""
+    N, P, b = 500000, 100000, 16
+    rng = np.random.default_rng(2)
+    B = rng.standard_normal((N, b))
+    with fp.Context.synthetic(N, P, missing_rate=0.02, accum="auto") as ctx:
+        assert ctx.accum == "i8x7" and ctx.missing_mode(b) == 0  # dense indicator route
+        packed = ctx.download_packed()
+        Z = ctx.apply_xxt(B)
+        T = ctx.apply_xt(B[:, :1])
+    with fp.Context.synthetic(N, P, missing_rate=0.02, accum="fp64") as c64:
+        Z64 = c64.apply_xxt(B)
+    assert np.max(np.abs(Z - Z64)) <= 1e-12 * np.max(np.abs(Z64))
+    od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+    op = orc.OracleOp(od, 1000, nthreads=orc.host_threads())
+    y = op.perform_op(np.ascontiguousarray(B[:, 5]))
+    assert np.max(np.abs(Z[:, 5] - y)) <= 1e-11 * np.max(np.abs(y))
+    t = op.crossprod(np.ascontiguousarray(B[:, 0]))
+    assert np.max(np.abs(T[:, 0] - t)) <= 1e-11 * np.max(np.abs(t))
