@@ -379,8 +379,22 @@ int shm_allreduce(void *user, double *dbuf, uint64_t count, void *stream)
 }
 #endif
 
+#ifdef FPCA_TEST_HOOKS
+#include <execinfo.h>
+static void on_segv(int)
+{
+   void *bt[64];
+   const int n = backtrace(bt, 64);
+   backtrace_symbols_fd(bt, n, 2);
+   _exit(139);
+}
+#endif
+
 int main(int argc, char *argv[])
 {
+#ifdef FPCA_TEST_HOOKS
+   signal(SIGSEGV, on_segv);
+#endif
    VarMap vm;
    try {
       vm = parse_command_line(argc, argv);
@@ -605,6 +619,7 @@ int main(int argc, char *argv[])
                if (t.joinable()) t.join();
          }
       } helpers;
+      helpers.th.reserve(8); // (threads are referred to by address below)
       if (ngpus == 1) helpers.th.emplace_back([device] { (void)fpca_warmup(device); }); // (errors resurface in fpca_create_from_bed)
       std::vector<std::string> snp_ids, ref_alleles, alt_alleles, fam_ids, indiv_ids;
       std::exception_ptr bim_error;
@@ -636,6 +651,23 @@ int main(int argc, char *argv[])
 
       fpca_ctx *ctx = nullptr;
       uint64_t nsnps = 0; // SNPs in the file (all shards)
+      uint64_t P_file_all = 0; // the same, from the file size alone (data.cpp:165-170) -- known before any device work
+      // the big results live in UNINITIALISED memory: a std::vector would zero 80 + 80 + 16 MB on this thread first (35 ms of
+      // page faults at 500,000 x 100,000); the parallel download touches the pages instead
+      struct Buf {
+         std::unique_ptr<double[]> p;
+         size_t n = 0;
+         void resize(size_t k)
+         {
+            p.reset(new double[k]);
+            n = k;
+         }
+         double *data() { return p.get(); }
+         bool empty() const { return n == 0; }
+         double *begin() { return p.get(); }
+         double *end() { return p.get() + n; }
+      } U, Px, V;
+      std::vector<std::string> rownames, rn_snp; // "FID\tIID" / "SNP\tRefAllele" row labels of the output files
       Multi mg;
       mg.ngpus = ngpus;
       uint64_t snp_begin = 0, snp_count = 0; // this rank's shard (0, 0 = the whole file)
@@ -646,6 +678,7 @@ int main(int argc, char *argv[])
          if (stat(geno_file.c_str(), &st) != 0) throw std::runtime_error("[Data::read_bed] Error reading file " + geno_file + ", error " + strerror(errno));
          const uint64_t np = (N + 3) / 4;
          const uint64_t P_file = (uint64_t)st.st_size > 3 ? ((uint64_t)st.st_size - 3) / np : 0; // data.cpp:165-170
+         P_file_all = P_file;
          // flashpca.cpp:623-633
          const unsigned max_dim = (unsigned)((std::fmin((double)N, (double)P_file) - 1) / 2.0);
          if ((unsigned)n_dim > max_dim) { // (every mode, like the reference)
@@ -742,9 +775,38 @@ int main(int argc, char *argv[])
          return EXIT_FAILURE;
       };
       const int my_device = device + ((ngpus > 1 && !mg.test_transport) ? mg.rank : 0);
-      if (ngpus == 1)
+      // One GPU, PCA: while the .bed streams to the device (that is the copy engine's and the reader threads' business), a
+      // helper thread gets the host side of the results ready -- it touches the pages of the 80 + 80 + 16 MB result buffers
+      // (first-touch page faults are 35 ms of a one-threaded pass, and the download would otherwise pay them) and builds the
+      // row labels of the output files.
+      size_t prep_idx = (size_t)-1;
+      if (ngpus == 1 && mode == MODE_PCA && P_file_all > 0) {
+         U.resize((size_t)N * n_dim);
+         Px.resize((size_t)N * n_dim);
+         if (do_loadings) V.resize((size_t)P_file_all * n_dim);
+         prep_idx = helpers.th.size();
+         helpers.th.emplace_back([&] {
+            for (Buf *bf : {&U, &Px, &V})
+               for (size_t i = 0; i < bf->n; i += 512) bf->p[i] = 0.0; // one write per 4 KB page
+            rownames.resize(N);
+            for (uint64_t i = 0; i < N; i++) rownames[i] = fam_ids[i] + "\t" + indiv_ids[i];
+            if ((do_loadings || save_meansd) && snp_ids.size() == P_file_all) {
+               rn_snp.resize(snp_ids.size());
+               for (size_t i = 0; i < rn_snp.size(); i++) rn_snp[i] = snp_ids[i] + "\t" + ref_alleles[i];
+            }
+         });
+      }
+      struct JoinOne { // joins the helper before the buffers it writes go out of scope, whichever way this scope is left
+         std::thread *t;
+         ~JoinOne()
+         {
+            if (t && t->joinable()) t->join();
+         }
+      } join_prep{prep_idx != (size_t)-1 ? &helpers.th[prep_idx] : nullptr};
+      if (ngpus == 1) {
          fpca_ok(fpca_create_from_bed(&ctx, geno_file.c_str(), N, 0, 0, stand_method_x, device, accum, &nsnps));
-      else {
+         if (join_prep.t && join_prep.t->joinable()) join_prep.t->join();
+      } else {
          if (mg.sh->failed.load() == 0) {
             if (fpca_create_from_bed(&ctx, geno_file.c_str(), N, snp_begin, snp_count, stand_method_x, my_device, accum, &nsnps) != FPCA_OK)
                multi_fail(mg, fpca_last_error());
@@ -787,21 +849,6 @@ int main(int argc, char *argv[])
       // the reference prints its dense block geometry here (flashpca.cpp:688-690); the whole packed matrix is one resident block
       std::cout << timestamp() << "blocksize: " << nsnps << " (" << (long long)((N + 3) / 4) * (long long)nsnps << " bytes per block)" << std::endl;
 
-      // the big results live in UNINITIALISED memory: a std::vector would zero 80 + 80 + 16 MB on this thread first (35 ms of
-      // page faults at 500,000 x 100,000); the parallel download touches the pages instead
-      struct Buf {
-         std::unique_ptr<double[]> p;
-         size_t n = 0;
-         void resize(size_t k)
-         {
-            p.reset(new double[k]);
-            n = k;
-         }
-         double *data() { return p.get(); }
-         bool empty() const { return n == 0; }
-         double *begin() { return p.get(); }
-         double *end() { return p.get() + n; }
-      } U, Px, V;
       std::vector<double> d, pve, meansd;
       int k_out = n_dim;
       if (mode == MODE_PCA) {
@@ -822,9 +869,9 @@ int main(int argc, char *argv[])
          fpca_pca_info info;
          int rc;
          if (ngpus == 1) {
-            U.resize((size_t)N * n_dim);
-            Px.resize((size_t)N * n_dim);
-            if (do_loadings) V.resize((size_t)nsnps * n_dim);
+            if (U.empty()) U.resize((size_t)N * n_dim);
+            if (Px.empty()) Px.resize((size_t)N * n_dim);
+            if (do_loadings && (V.empty() || nsnps != P_file_all)) V.resize((size_t)nsnps * n_dim);
             meansd.resize((size_t)nsnps * 2);
             rc = fpca_pca(ctx, &o, U.data(), d.data(), Px.data(), pve.data(), do_loadings ? V.data() : nullptr, meansd.data(), &info);
          } else {
@@ -940,8 +987,9 @@ int main(int argc, char *argv[])
          writers.clear();
          if (write_error) std::rethrow_exception(write_error);
       };
-      std::vector<std::string> rownames, colnames_u, colnames_pc, cn_load, rn_snp, cn_ms;
+      std::vector<std::string> colnames_u, colnames_pc, cn_load, cn_ms;
       auto sample_rownames = [&] {
+         if (rownames.size() == N) return; // (built beside the upload)
          rownames.resize(N);
          const unsigned nt = std::max(1u, std::min(cpus, 8u));
          std::vector<std::thread> th;
