@@ -293,6 +293,22 @@ long hostsim_read_fam(const char *filename, char *err, int errlen)
    }
 }
 
+/* the CLI's one-pass .fam reader (plink_io.cpp read_fam): returns N, the ids joined as "fid\tiid\n" into ids (capacity cap) */
+long hostsim_read_fam_onepass(const char *filename, char *ids, uint64_t cap, char *err, int errlen)
+{
+   try {
+      std::vector<std::string> a, b;
+      const uint64_t n = fpca::read_fam(filename, a, b);
+      std::string all;
+      for (size_t i = 0; i < a.size(); i++) all += a[i] + "\t" + b[i] + "\n";
+      if (ids && all.size() + 1 <= cap) std::memcpy(ids, all.c_str(), all.size() + 1);
+      return (long)n;
+   } catch (const std::exception &e) {
+      if (err) std::snprintf(err, errlen, "%s", e.what());
+      return -1;
+   }
+}
+
 long hostsim_read_bim(const char *filename, char *err, int errlen)
 {
    try {

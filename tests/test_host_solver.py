@@ -278,6 +278,40 @@ def test_text_io_roundtrip(tmp_path):
     assert b"Error reading file" in err.value
 
 
+def test_one_pass_fam_reader_matches_the_two_reference_passes(tmp_path, golden_dir):
+    """The CLI reads the .fam once (plink_io.cpp read_fam); the reference reads it twice -- read_text(fam, 6) for N and the
+    numeric check of the phenotype column (flashpca.cpp:589 -> data.cpp:408-413, 504-586) and read_plink_fam for the ids
+    (data.cpp:639-672).  Same N, same ids, same refusals."""
+    L = hostsim()
+    L.hostsim_read_fam_onepass.restype = C.c_long
+    L.hostsim_read_fam_onepass.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_int]
+    err = C.create_string_buffer(256)
+    ids = C.create_string_buffer(1 << 16)
+    out = np.zeros(4096)
+    cols = C.c_uint64()
+    fam = os.path.join(golden_dir, "data_chr1.fam").encode()
+    n = L.hostsim_read_fam_onepass(fam, ids, 1 << 16, err, 256)
+    assert n == 957 == L.hostsim_read_text(fam, 6, -1, 0, out.ctypes.data, 4096, C.byref(cols), err, 256) == L.hostsim_read_fam(fam, err, 256)
+    want = "".join("\t".join(l.split()[:2]) + "\n" for l in open(fam.decode()).read().splitlines())
+    assert ids.value.decode() == want
+    f = str(tmp_path / "t.fam")
+    cases = [("F1 I1 0 0 1 -9\nF2\tI2  0 0 2 1.5\r\nF3 I3 0 0 1 nan\nF4 I4 0 0 1 2", 3, None),          # tail without newline dropped; CR, tabs
+             ("F1 I1 0 0 1 -9 7\nF2 I2 0 0 2 1 8\n", 2, None),                                        # extra numeric columns are fine
+             ("F1 I1 0 0 1 x\n", -1, b"cannot be parsed as a number"),
+             ("F1 I1 0 0 1 -9\nF2 I2 0 0 2\n", -1, b"inconsistent number of columns"),
+             ("F1 I1 0 0 1 -9\nF2 I2 0 0 2 1 3\n", -1, b"inconsistent number of columns"),
+             ("", 0, None)]
+    for text, expect, msg in cases:
+        open(f, "w").write(text)
+        got = L.hostsim_read_fam_onepass(f.encode(), ids, 1 << 16, err, 256)
+        ref = L.hostsim_read_text(f.encode(), 6, -1, 0, out.ctypes.data, 4096, C.byref(cols), err, 256)
+        assert got == expect == ref, (text, got, ref)
+        if msg:
+            L.hostsim_read_fam_onepass(f.encode(), ids, 1 << 16, err, 256)
+            assert msg in err.value, err.value
+    assert L.hostsim_read_fam_onepass(b"/nonexistent.fam", ids, 1 << 16, err, 256) == -1 and b"Error reading file" in err.value
+
+
 def test_parallel_writer_is_byte_identical_to_iostream_format(tmp_path):
     """The chunk-parallel writer must reproduce operator<< under setprecision(p) (== "%.{p}g") for every row."""
     L = hostsim()
