@@ -29,6 +29,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void
 
 class PcaOpts(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("info_size", C.c_uint32),
         ("ndim", C.c_int),
         ("blockvec", C.c_int),
         ("maxiter", C.c_int),
@@ -40,6 +42,8 @@ class PcaOpts(C.Structure):
         ("seed", C.c_uint64),
         ("replicated_solver", C.c_int),
         ("max_applies", C.c_int),
+        ("mixed", C.c_int),
+        ("cheap_slices", C.c_int),
     ]
 
 
@@ -58,6 +62,9 @@ class PcaInfo(C.Structure):
         ("seconds_total", C.c_double),
         ("seconds_download", C.c_double),
         ("seconds_post", C.c_double),
+        ("cheap_applies", C.c_int),
+        ("cheap_slices", C.c_int),
+        ("seconds_exact", C.c_double),
     ]
 
 
@@ -79,6 +86,7 @@ _P, _U64, _I, _D = C.c_void_p, C.c_uint64, C.c_int, C.c_double
 SIGNATURES = {
     "fpca_last_error": (C.c_char_p, []),
     "fpca_version": (C.c_char_p, []),
+    "fpca_abi_version": (_I, []),
     "fpca_device_count": (_I, []),
     "fpca_device_name": (_I, [_I, C.c_char_p, _I]),
     "fpca_warmup": (_I, [_I]),
@@ -123,6 +131,8 @@ SIGNATURES = {
     "fpca_debug_k4": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P]),
 }
 
+ABI_VERSION = 2  # FPCA_ABI_VERSION of the include/fpca.h the structures above mirror
+
 _lib = None
 _loaded = {}
 
@@ -135,6 +145,13 @@ def _load(path):
                 "no CPU fallback" % path
             )
         L = C.CDLL(path)
+        try:
+            L.fpca_abi_version.restype = C.c_int
+            abi = L.fpca_abi_version()
+        except AttributeError:
+            abi = 1
+        if abi != ABI_VERSION:  # (an older or newer build behind FPCA_LIB: its structs have other sizes)
+            raise RuntimeError("%s speaks ABI version %d, this binding %d -- rebuild it (make -C flashpca_amd/csrc)" % (path, abi, ABI_VERSION))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res

@@ -173,13 +173,14 @@ class Context:
 
     # ---- driver ---------------------------------------------------------------------------------------
     def pca(self, ndim=10, tol=1e-6, maxiter=500, div="p", do_loadings=False, blockvec=0, max_blocks=0, seed=1, verbose=0,
-            allow_unconverged=False, max_applies=0, replicated_solver=False):
+            allow_unconverged=False, max_applies=0, replicated_solver=False, mixed=0, cheap_slices=0):
         o = PcaOpts()
         lib().fpca_pca_default_opts(C.byref(o))
         o.ndim, o.tol, o.maxiter, o.divisor = ndim, tol, maxiter, DIVISOR[div]
         o.do_loadings, o.blockvec, o.max_blocks, o.seed, o.verbose = int(do_loadings), blockvec, max_blocks, seed, verbose
         o.max_applies = max_applies
         o.replicated_solver = int(replicated_solver)
+        o.mixed, o.cheap_slices = int(mixed), int(cheap_slices)  # mixed: 0 automatic (on), 1 on, -1 off (every pass exact)
         U = np.empty((self.N, ndim), order="F")
         d = np.empty(ndim)
         Px = np.empty((self.N, ndim), order="F")

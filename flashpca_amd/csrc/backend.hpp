@@ -51,6 +51,10 @@ class BlockBackend {
 
    // out = sum over ranks g of X_g X_g' in    (K2 + K3 + all-reduce); in != out
    virtual void apply(int in, int out) = 0;
+   // Arithmetic of the following apply() calls: cheap = the backend's reduced-precision passes (exact-integer mode: fewer
+   // byte slices of the fp64 operand), else its exact ones.  Returns false -- and changes nothing -- when the backend has
+   // no cheaper arithmetic than the one it runs; the solver then never asks again.
+   virtual bool set_cheap(bool cheap) { (void)cheap; return false; }
 
    // C[q][p][c] = sum_s A_q[s][p] W[s][c]   for q < nq  (host result => synchronises)
    virtual void gram(const int *a, int nq, int w, double *C) = 0;

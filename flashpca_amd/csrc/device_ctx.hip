@@ -20,6 +20,7 @@
 #include <rccl/rccl.h> // types only: the library is dlopen()ed on first use (fpca_comm_*)
 
 #include "../../include/fpca.h"
+#include "../../include/fpca_debug.h"
 #include "backend.hpp"
 #include "common.hpp"
 #include "kernels.hpp"
@@ -123,6 +124,9 @@ struct fpca_ctx {
    double *d_small = nullptr;                   // small device scratch (scalars, column scales)
    // exact-integer mode (FPCA_ACCUM_I8(S)): sample-major packed copy, K3 row scales, sliced operands, int32 partials
    int i8_S = 0;
+   int i8_S_req = 0; // the S the context was created with (i8_S drops to 0 if the mode's buffers do not fit; this does not)
+   int i8_Sc = 0;    // slices of the passes being made NOW when that is fewer than i8_S (the eigensolver's cheap passes), else 0
+   int cur_S() const { return (i8_Sc > 0 && i8_Sc < i8_S) ? i8_Sc : i8_S; }
    bool i8_auto = false; // mode chosen by FPCA_ACCUM_AUTO: falls back to fp64 if the extra buffers do not fit
    uint8_t *d_packedT = nullptr;
    size_t pitchT = 0;
@@ -130,6 +134,7 @@ struct fpca_ctx {
    int8_t *d_Qb = nullptr, *d_Qg = nullptr, *d_Qm = nullptr;
    int i8_nsc = 0; // rows currently allocated (and zero-padded) in the Q buffers
    int i8_pad_zeroed_for = -1; // S*b for which rows [S*b, i8_nsc) of the Q buffers are known to be zero
+   int i8_ws_for_S = 0, i8_ws_for_b = 0; // (S, b) the workspace was last sized for (the plan search is not free: 20 us)
    double *d_i8ws = nullptr;
    size_t i8ws_cap = 0;
    bool i8_scales_done = false, i8_transposed = false;
@@ -273,6 +278,7 @@ void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int devi
    c->stand = stand;
    c->accum = accum;
    c->i8_S = i8 ? accum - FPCA_ACCUM_I8(0) : 0;
+   c->i8_S_req = c->i8_S;
    c->dense = dense;
    lap("device properties, hipSetDevice");
    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -398,6 +404,7 @@ bool ensure_i8(fpca_ctx *c, int b)
       c->i8_nsc = 0;
       c->i8_pad_zeroed_for = -1;
       c->i8ws_cap = 0;
+      c->i8_ws_for_S = c->i8_ws_for_b = 0;
       c->i8_S = 0;
       c->accum = FPCA_ACCUM_FP64;
       return false;
@@ -424,7 +431,9 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
       kern::i8_rowscales(c->d_mean, c->d_sd, c->P_g, c->P_pad, c->d_inv_sd, c->d_mu_inv_sd, s);
       c->i8_scales_done = true;
    }
-   const int nsc = kern::gemm_i8_nsc_pad(c->i8_S, b);
+   const int Sc = c->cur_S();
+   const int nsc_cur = kern::gemm_i8_nsc_pad(Sc, b);               // rows of Q the kernels of this pass read
+   const int nsc = std::max(nsc_cur, kern::gemm_i8_nsc_pad(c->i8_S, b)); // rows to hold: the exact passes need the most
    if (nsc > c->i8_nsc) {
       for (int8_t **q : {&c->d_Qb, &c->d_Qg, &c->d_Qm})
          if (*q) {
@@ -439,22 +448,25 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
    }
    // rows >= S*b of the Q operands must be zero (they are multiplied like any other column); the slicing kernels never
    // write them, so once per (allocation, S*b) is enough -- this runs at the top of every apply
-   if (nsc != c->i8_S * b && c->i8_pad_zeroed_for != c->i8_S * b) {
-      c->i8_pad_zeroed_for = c->i8_S * b;
-      const size_t used = (size_t)c->i8_S * b;
-      HIP_CHECK(hipMemsetAsync(c->d_Qb + used * c->N_pad, 0, (nsc - used) * c->N_pad, s));
-      HIP_CHECK(hipMemsetAsync(c->d_Qg + used * c->P_pad, 0, (nsc - used) * c->P_pad, s));
-      HIP_CHECK(hipMemsetAsync(c->d_Qm + used * c->P_pad, 0, (nsc - used) * c->P_pad, s));
-   }
-   size_t need = std::max(kern::gemm_i8_workspace_doubles(c->P_pad, c->N_pad, c->i8_S, b, false),
-                          std::max(kern::gemm_i8_workspace_doubles(c->N_pad, c->P_pad, c->i8_S, b, true),
-                                   kern::gemm_i8_workspace_doubles(c->N_pad, c->P_pad, c->i8_S, b, false)));
+   // (... and once per change of the slice count: the cheap passes of the eigensolver leave their own padding rows behind)
+   if (nsc_cur != Sc * b && c->i8_pad_zeroed_for != Sc * b) {
+      c->i8_pad_zeroed_for = Sc * b;
+      const size_t used = (size_t)Sc * b;
+      HIP_CHECK(hipMemsetAsync(c->d_Qb + used * c->N_pad, 0, (nsc_cur - used) * c->N_pad, s));
+      HIP_CHECK(hipMemsetAsync(c->d_Qg + used * c->P_pad, 0, (nsc_cur - used) * c->P_pad, s));
+      HIP_CHECK(hipMemsetAsync(c->d_Qm + used * c->P_pad, 0, (nsc_cur - used) * c->P_pad, s));
+   } else if (nsc_cur == Sc * b)
+      c->i8_pad_zeroed_for = -1; // (whole tiles: nothing to zero now, but the next ragged count must not trust stale rows)
+   if (Sc == c->i8_ws_for_S && b == c->i8_ws_for_b) return; // workspace already sized for this (S, b)
+   size_t need = std::max(kern::gemm_i8_workspace_doubles(c->P_pad, c->N_pad, Sc, b, false),
+                          std::max(kern::gemm_i8_workspace_doubles(c->N_pad, c->P_pad, Sc, b, true),
+                                   kern::gemm_i8_workspace_doubles(c->N_pad, c->P_pad, Sc, b, false)));
    for (int nch = 2; nch <= 4; nch++) // K3 in row chunks (overlapped all-reduce): the plan of a chunk may use more planes
       for (int i = 0; i < nch; i++) {
          const uint64_t rows = ar_chunk_begin(c, nch, i + 1) - ar_chunk_begin(c, nch, i);
          if (rows)
-            need = std::max(need, std::max(kern::gemm_i8_workspace_doubles(rows, c->P_pad, c->i8_S, b, true),
-                                           kern::gemm_i8_workspace_doubles(rows, c->P_pad, c->i8_S, b, false)));
+            need = std::max(need, std::max(kern::gemm_i8_workspace_doubles(rows, c->P_pad, Sc, b, true),
+                                           kern::gemm_i8_workspace_doubles(rows, c->P_pad, Sc, b, false)));
       }
    if (c->rank_known && c->nranks > 1) // K3 in the row chunks of the row-sharded solver (apply_sharded)
       for (int nch = 2; nch <= 4; nch++) {
@@ -462,8 +474,8 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
          for (int i = 0; i < nch; i++) {
             const uint64_t r0 = std::min<uint64_t>((uint64_t)i * sh.L, c->N_pad), r1 = std::min<uint64_t>((uint64_t)(i + 1) * sh.L, c->N_pad);
             if (r1 > r0)
-               need = std::max(need, std::max(kern::gemm_i8_workspace_doubles(r1 - r0, c->P_pad, c->i8_S, b, true),
-                                              kern::gemm_i8_workspace_doubles(r1 - r0, c->P_pad, c->i8_S, b, false)));
+               need = std::max(need, std::max(kern::gemm_i8_workspace_doubles(r1 - r0, c->P_pad, Sc, b, true),
+                                              kern::gemm_i8_workspace_doubles(r1 - r0, c->P_pad, Sc, b, false)));
          }
       }
    if (need > c->i8ws_cap) {
@@ -473,6 +485,8 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
       HIP_ALLOC(hipMalloc(&c->d_i8ws, need * sizeof(double)));
       c->i8ws_cap = need;
    }
+   c->i8_ws_for_S = Sc;
+   c->i8_ws_for_b = b;
 }
 
 // how the int8 GEMMs treat the missing-indicator matrix (kernels_i8.hip: I8_FULL / I8_SKIP_EMPTY / I8_NO_MISSING)
@@ -603,7 +617,7 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipE
    const double *eplane = nullptr;
    hipEvent_t wait = nullptr;
    kern::i8_colmax(dB, c->N, b, 1, &ob, s);
-   kern::i8_slice(dB, c->N_pad, c->N, b, c->i8_S, 1, &ob, s);
+   kern::i8_slice(dB, c->N_pad, c->N, b, c->cur_S(), 1, &ob, s);
    if (mode == I8M_SPARSE) mode = sparse_or_dense(c, b);
    if (mode == I8M_SPARSE) { // E'B: for every SNP the sum of the B rows of its missing samples, on the (low-priority) side
       if (sparse_on_side_stream(c, b)) { // stream, released together with the GEMM
@@ -618,7 +632,7 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipE
       mode = I8M_NONE;
    }
    kern::gemm_i8(c->d_packed, c->pitch, c->d_Qb, c->d_Qb, ob.colw, ob.colw, ob.colsum, c->d_mean, c->d_sd, c->d_T, c->d_i8ws, c->P_pad,
-                 c->N_pad, c->P_g, mode, eplane, b, c->i8_S, chain ? ot : nullptr, s, gev, wait);
+                 c->N_pad, c->P_g, mode, eplane, b, c->cur_S(), chain ? ot : nullptr, s, gev, wait);
 }
 
 // Row chunks of Y for the overlapped all-reduce (built-in communicator only): the all-reduce of chunk i runs on the
@@ -651,7 +665,7 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_
    if (mode == I8M_SPARSE) mode = sparse_or_dense(c, b);
    if (do_slice) {
       if (!have_max) kern::i8_colmax(c->d_T, c->P_g, b, 2, ot, s);
-      kern::i8_slice(c->d_T, c->P_pad, c->P_g, b, c->i8_S, 2, ot, s);
+      kern::i8_slice(c->d_T, c->P_pad, c->P_g, b, c->cur_S(), 2, ot, s);
       if (mode == I8M_SPARSE) { // E (mean T / sd): for every sample the sum of the scaled T rows of its missing SNPs
          if (sparse_on_side_stream(c, b)) {
             HIP_CHECK(hipEventRecord(c->ev_aux_go, s)); // T is complete on s here (and the K2 combine has consumed the plane)
@@ -674,7 +688,7 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_
    // G.M alone: one operand (Qm is still sliced: its column sums are 1'Qm, and M'Qm = 1'Qm - E'Qm)
    kern::gemm_i8(c->d_packedT + r0 * c->pitchT, c->pitchT, c->d_Qg, mode == I8M_NONE ? c->d_Qg : c->d_Qm, ot[0].colw, ot[1].colw,
                  ot[1].colsum, nullptr, nullptr, dY + r0 * b, c->d_i8ws, r1 - r0, c->P_pad, c->N > r0 ? std::min(c->N - r0, r1 - r0) : 0, mode,
-                 eplane, b, c->i8_S, nullptr, s, gev, wait);
+                 eplane, b, c->cur_S(), nullptr, s, gev, wait);
 }
 
 // The all-reduce of a finished Y, in the SAME sequence of collectives as the overlapped row chunks of the exact-integer
@@ -912,8 +926,11 @@ void staged_download(fpca_ctx *c_, const double *d_img, uint64_t N, int ncols, d
 
 class HipBackend : public BlockBackend {
  public:
-   HipBackend(fpca_ctx *c, int b, bool replicated = false)
-      : c_(c), b_(b), d_ptrs_(c->be_ptrs), d_C_(c->be_C), d_gpart_(c->be_gpart), C_cap_(c->be_C_cap), gpart_cap_(c->be_gpart_cap),
+   // cheap_S: byte slices of the eigensolver's cheap passes (0: none).  Whether they exist is decided from the arithmetic the
+   // context was CREATED with, not from what it runs now: a rank whose exact-integer buffers did not fit runs the fp64 kernels
+   // for every pass but must follow the same sequence of passes as the others.
+   HipBackend(fpca_ctx *c, int b, bool replicated = false, int cheap_S = 0)
+      : c_(c), b_(b), cheap_S_((c->i8_S_req > 0 && cheap_S >= 2 && cheap_S < c->i8_S_req) ? cheap_S : 0), d_ptrs_(c->be_ptrs), d_C_(c->be_C), d_gpart_(c->be_gpart), C_cap_(c->be_C_cap), gpart_cap_(c->be_gpart_cap),
         h_pin_(c->be_pin), pin_cap_(c->be_pin_cap)
    {
       HIP_CHECK(hipSetDevice(c->device));
@@ -947,6 +964,7 @@ class HipBackend : public BlockBackend {
    }
    ~HipBackend() override
    {
+      c_->i8_Sc = 0;
       (void)hipStreamSynchronize(c_->stream);
       for (double *p : blocks_)
          if (p) c_->block_pool.emplace_back(block_bytes(), p);
@@ -1008,7 +1026,16 @@ class HipBackend : public BlockBackend {
       float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, e0_, e1_));
       sec_apply_ += ms * 1e-3;
+      if (!c_->i8_Sc) sec_exact_ += ms * 1e-3;
    }
+   bool set_cheap(bool cheap) override
+   {
+      if (!cheap_S_) return false;
+      c_->i8_Sc = cheap ? cheap_S_ : 0;
+      return true;
+   }
+   int cheap_slices() const { return cheap_S_; }
+   double seconds_exact() const { return sec_exact_; }
    // Host <-> device traffic of the small matrices goes through one pinned buffer ([1024 pointers][coefficients]); the
    // event marks the last asynchronous read of it, so a call never overwrites what an earlier copy has not picked up.
    void pin_wait()
@@ -1119,6 +1146,7 @@ class HipBackend : public BlockBackend {
    }
    fpca_ctx *c_;
    int b_;
+   int cheap_S_; // byte slices of the cheap passes (0: the backend has none)
    uint64_t rows_ = 0; // rows of a block as THIS rank stores it: N_pad, or its slice of the row-sharded solver
    RowShard sh_;
    std::vector<double *> blocks_;
@@ -1130,7 +1158,7 @@ class HipBackend : public BlockBackend {
    size_t &pin_cap_;
    bool pin_busy_ = false;
    hipEvent_t e0_, e1_, ev_pin_;
-   double sec_apply_ = 0, sec_other_ = 0;
+   double sec_apply_ = 0, sec_other_ = 0, sec_exact_ = 0;
 };
 
 template <typename F> int guarded(F &&f)
@@ -1157,6 +1185,7 @@ extern "C" {
 
 const char *fpca_last_error(void) { return fpca::g_last_error.c_str(); }
 const char *fpca_version(void) { return FPCA_VERSION; }
+int fpca_abi_version(void) { return FPCA_ABI_VERSION; }
 
 int fpca_device_count(void)
 {
@@ -1556,6 +1585,7 @@ int fpca_comm_init_rank(fpca_ctx *ctx, int nranks, int rank, const uint8_t id[FP
       ctx->nranks = nranks;
       ctx->rank = rank;
       ctx->rank_known = true;
+      ctx->i8_ws_for_S = ctx->i8_ws_for_b = 0; // (the row chunks of the multi-rank K3 enter the workspace size)
       if (!ctx->comm_stream) {
          HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
          for (hipEvent_t &e : ctx->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1585,6 +1615,7 @@ int fpca_set_rank(fpca_ctx *ctx, int nranks, int rank)
    ctx->nranks = nranks;
    ctx->rank = rank;
    ctx->rank_known = true;
+   ctx->i8_ws_for_S = ctx->i8_ws_for_b = 0;
    return FPCA_OK;
 }
 
@@ -1607,6 +1638,8 @@ int fpca_set_total_snps(fpca_ctx *ctx, uint64_t P_total)
 void fpca_pca_default_opts(fpca_pca_opts *o)
 {
    std::memset(o, 0, sizeof(*o));
+   o->struct_size = (uint32_t)sizeof(fpca_pca_opts);
+   o->info_size = (uint32_t)sizeof(fpca_pca_info);
    o->ndim = 10;      // flashpca.cpp:325
    o->blockvec = 0;
    o->maxiter = 500;  // flashpca.cpp:426
@@ -1623,7 +1656,12 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
 {
    int solver_rc = FPCA_OK;
    int rc = guarded([&] {
-      if (!ctx || !opts) throw Error(FPCA_EINVAL, "bad argument to fpca_pca");
+      if (!opts) throw Error(FPCA_EINVAL, "bad argument to fpca_pca");
+      if (opts->struct_size != sizeof(fpca_pca_opts) || opts->info_size != sizeof(fpca_pca_info))
+         throw Error(FPCA_EINVAL, "fpca_pca_opts was not filled by this library's fpca_pca_default_opts (struct sizes " + std::to_string(opts->struct_size) +
+                                      " / " + std::to_string(opts->info_size) + ", expected " + std::to_string(sizeof(fpca_pca_opts)) + " / " +
+                                      std::to_string(sizeof(fpca_pca_info)) + "): the caller was built against another include/fpca.h");
+      if (!ctx) throw Error(FPCA_EINVAL, "bad argument to fpca_pca");
       HIP_CHECK(hipSetDevice(ctx->device));
       const int k = opts->ndim;
       // Spectra's requirement nev < ncv = 2 nev + 1 <= n, enforced by the reference CLI (flashpca.cpp:623-633)
@@ -1639,7 +1677,9 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
          if (timing) std::fprintf(stderr, "[fpca] %-28s %8.3f ms\n", what, std::chrono::duration<double>(now - tp0).count() * 1e3);
          tp0 = now;
       };
-      HipBackend be(ctx, b, opts->replicated_solver != 0);
+      if (opts->cheap_slices != 0 && (opts->cheap_slices < 3 || opts->cheap_slices > 7)) throw Error(FPCA_EINVAL, "cheap_slices must be 0 or 3..7");
+      const int cheap_S = opts->mixed < 0 ? 0 : (opts->cheap_slices ? opts->cheap_slices : 4);
+      HipBackend be(ctx, b, opts->replicated_solver != 0, cheap_S);
       lap("backend setup");
       PcaOutputs out;
       out.U = U;
@@ -1651,6 +1691,10 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
       std::vector<double> dloc(k);
       if (!out.d) out.d = dloc.data();
       solver_rc = run_pca(be, *opts, ctx->P_total, out, info, &ritz, &div);
+      if (info) {
+         info->cheap_slices = info->cheap_applies > 0 ? be.cheap_slices() : 0;
+         info->seconds_exact = be.seconds_exact();
+      }
       lap("run_pca");
       const auto tpost = std::chrono::steady_clock::now();
       if (opts->do_loadings && V) {

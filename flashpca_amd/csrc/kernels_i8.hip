@@ -325,7 +325,11 @@ struct I8Cfg {
    static constexpr int NSTEP = KS * MT * G;            // micro-steps per chunk
    static constexpr int H = NSTEP / 2;
    // dynamic LDS: the double-buffered operand tiles; the epilogue reuses it for 4 waves x NT dumped tiles + the weights
-   static constexpr int LDS_BYTES = (2 * STAGE > 4 * NT * 4096 + 2 * WC * NT * 32 * 8) ? 2 * STAGE : 4 * NT * 4096 + 2 * WC * NT * 32 * 8;
+   static constexpr int LDS_NEED = (2 * STAGE > 4 * NT * 4096 + 2 * WC * NT * 32 * 8) ? 2 * STAGE : 4 * NT * 4096 + 2 * WC * NT * 32 * 8;
+   // The narrowest column block (2 tiles: 136 registers, 34 KB) would fit three workgroups per CU; measured at 500,000 x
+   // 100,000 (scripts/r4_narrow_probe.sh, GEMM kernels K2 / K3): three per CU 4.61 / 4.74 ms, two 4.31 / 4.39, one 5.20 / 5.74 --
+   // so it asks for enough LDS to be two (the wider blocks are two or one by their registers: 224+ of 512).
+   static constexpr int LDS_BYTES = (!TWO && NT <= 2 && LDS_NEED < 56 * 1024) ? 56 * 1024 : LDS_NEED;
    static_assert(COLS % RSTEP == 0 && NSTEP % 2 == 0 && LDS_BYTES <= 160 * 1024, "staging");
 };
 
@@ -738,16 +742,25 @@ __global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ p
 struct I8Shape {
    int nt, zb, rows, cols, kc;
    bool half; // the last tile is the 16-column remainder (v_mfma_i32_16x16x64_i8), cols = 32 nt - 16
+   int mt = 2; // 32-row tiles per wave (one-matrix kernel: 2, or 4 for the narrow column blocks)
 };
 
 static I8Shape i8_shape(int S, int b, bool two, int mode = I8_FULL)
 {
-   const int tiles = (S * b + 31) / 32, cap = two ? 4 : 8, lo = two ? 3 : 4; // largest / smallest instantiated block
+   const int tiles = (S * b + 31) / 32, cap = two ? 4 : 8; // largest instantiated block
+   // smallest instantiated block: 3 tiles (two operands) / 4 tiles; the one-matrix kernel also exists with 2 and 3 tiles
+   // (few slices of a narrow block: S = 4, b = 16 is 64 slice-columns)
+   int lo = two ? 3 : 4;
+   if (!two && mode == I8_NO_MISSING) lo = 2;
    I8Shape sh;
    sh.zb = (tiles + cap - 1) / cap;
    sh.nt = std::max(lo, (tiles + sh.zb - 1) / sh.zb);
    // one matrix only (I8_NO_MISSING): the freed accumulators go into a second row tile per wave (64 rows x NT tiles)
    sh.rows = (two || mode == I8_NO_MISSING) ? 256 : 128;
+   if (!two && mode == I8_NO_MISSING && sh.nt <= 3 && FPCA_TEST_ENV("FPCA_I8_MT4")) { // experiment: 128 rows per wave
+      sh.mt = 4;
+      sh.rows = 512;
+   }
    sh.cols = 32 * sh.nt;
    sh.kc = 256;
    // b = 16 with S = 7 slices: 112 slice-columns = 3.5 tiles -- the one-matrix kernel (the default route up to 0.5 % missing
@@ -851,12 +864,18 @@ template <class C>
 static void launch_i8(const I8Plan &pl, hipStream_t stream, const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm,
                       uint64_t k_pad, const double *wg, const double *wm, int bw, double *ws, uint64_t rows_pad, int chunks_total, int zb)
 {
-   static bool attr_set = false;
+   static bool attr_set = false, attr_set2 = false;
    if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<C>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
       attr_set = true;
    }
-   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<C>), dim3(pl.grid), dim3(256), C::LDS_BYTES, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw,
+   // (test builds: FPCA_I8_LDS_PAD = extra bytes of dynamic LDS per workgroup, i.e. fewer co-resident workgroups per CU)
+   static const int lds_pad = FPCA_TEST_ENV("FPCA_I8_LDS_PAD") ? atoi(FPCA_TEST_ENV("FPCA_I8_LDS_PAD")) : 0;
+   if (lds_pad && !attr_set2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<C>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + lds_pad);
+      attr_set2 = true;
+   }
+   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<C>), dim3(pl.grid), dim3(256), C::LDS_BYTES + lds_pad, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw,
                       ws, rows_pad, chunks_total, zb, pl.nA, pl.sB, pl.cpsB, pl.rowB0, pl.rowsB);
 }
 
@@ -925,6 +944,14 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
 #endif
       if (sh.half)
          launch_i8<I8Cfg<false, 2, 4, 4, 1, 256, 1, I8_NO_MISSING, 0, true>>(FPCA_I8_ARGS);
+      else if (sh.nt == 2 && sh.mt == 4)
+         launch_i8<I8Cfg<false, 4, 2, 4, 1, 256, 1, I8_NO_MISSING>>(FPCA_I8_ARGS);
+      else if (sh.nt == 3 && sh.mt == 4)
+         launch_i8<I8Cfg<false, 4, 3, 4, 1, 256, 1, I8_NO_MISSING>>(FPCA_I8_ARGS);
+      else if (sh.nt == 2)
+         launch_i8<I8Cfg<false, 2, 2, 4, 1, 256, 1, I8_NO_MISSING>>(FPCA_I8_ARGS);
+      else if (sh.nt == 3)
+         launch_i8<I8Cfg<false, 2, 3, 4, 1, 256, 1, I8_NO_MISSING>>(FPCA_I8_ARGS);
       else
          FPCA_I8_K2_NT(I8_NO_MISSING)
    } else if (mode == I8_SKIP_EMPTY) {

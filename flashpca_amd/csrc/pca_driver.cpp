@@ -64,6 +64,7 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
    }
    so.seed = o.seed ? o.seed : 1;
    so.verbose = o.verbose;
+   so.mixed = o.mixed >= 0;
    SolverResult r = block_krylov_schur(be, so);
    const bool timing = std::getenv("FPCA_TIMING") != nullptr;
    auto lap = [&, last = std::chrono::steady_clock::now()](const char *what) mutable {
@@ -111,6 +112,9 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
       info->block_applies = r.block_applies;
       info->vector_ops = r.block_applies * be.width();
       info->restarts = r.restarts;
+      info->cheap_applies = r.cheap_applies;
+      info->cheap_slices = 0;  // (filled in by fpca_pca, which knows the backend's arithmetic)
+      info->seconds_exact = 0;
       info->blockvec = be.width();
       info->trace = trace;
       info->max_residual = r.max_rel_residual;

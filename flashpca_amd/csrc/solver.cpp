@@ -13,6 +13,8 @@
 //            res_i = || R S[last block, i] ||                == || A u_i - theta_i u_i ||, u_i = V S[:, i]
 //            stop when res_i < tol * max(eps^(2/3), |theta_i|) for the k largest (Spectra's rule)
 //            V_m = Q, or thick restart keeping the b best Ritz vectors when the basis is full
+// (the loop below is the slight generalisation in which several basis blocks may be waiting for their pass through the
+//  operator -- needed when Krylov passes in cheap arithmetic are verified by exact ones, see "mixed precision")
 //
 // All N-sized work is delegated to the backend; this file only does (m b)-sized dense algebra.
 #include "solver.hpp"
@@ -201,12 +203,17 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    int mcap = o.max_blocks > 0 ? o.max_blocks : std::max(4, (b == 16 ? 384 : 512) / b);
    if (kb > 1) mcap = std::max(mcap, 2 * nk_wide + 2);
    if (kb > 1 && o.max_blocks <= 0) mcap = std::max(mcap, 3 * nk_wide); // room to grow between two restarts
-   // the basis [V_0..V_{m-1}, Q] must fit in N dimensions
+   // the basis must fit in N dimensions
    const int fit = (int)std::min<uint64_t>(N / (uint64_t)b, 1u << 20) - 1;
    if (fit < 2 || (kb > 1 && fit < nk_wide + 2)) return dense_small(be, o);
    mcap = std::min(mcap, fit);
    if (mcap < 2) mcap = 2;
-   const int nmax = mcap * b;
+   // The basis V_0 .. V_{M-1} is a QUEUE: its first `na` blocks have been through the operator (column blocks 0 .. na-1 of
+   // T = V'AV are known, and A V_c lies in span(V) for c < na), the others wait for their turn.  Plain block Lanczos has
+   // exactly one block waiting (the newest); after the switch from cheap to exact passes (below) all the kept Ritz blocks
+   // wait, and each of their passes appends one more block.  nqmax bounds the blocks waiting + the one being made.
+   const int nqmax = std::max(2, nk_wide) + 2;
+   const int nmax = (mcap + nqmax) * b;
    const double eps23 = std::pow(DBL_EPSILON, 2.0 / 3.0);
 
    SolverResult res;
@@ -223,7 +230,8 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       tph = now;
    };
    std::vector<int> V;
-   std::vector<double> T((size_t)nmax * nmax, 0.0), Tw((size_t)nmax * nmax), theta(nmax);
+   int na = 0; // blocks of V that have been through the operator
+   std::vector<double> T((size_t)nmax * nmax, 0.0), Tw, theta(nmax);
    std::vector<double> H((size_t)nmax * b), C((size_t)(nmax + b) * b), negC((size_t)(nmax + b) * b);
    std::vector<double> R1, R2, R3, R((size_t)b * b), tmp((size_t)b * b), M1, M2, Gw;
    std::vector<int> VW;
@@ -241,6 +249,24 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          for (size_t i = 0; i < cnt; i++) H[i] += C[i];
    };
 
+   // ---- mixed precision (exact-integer backends) -----------------------------------------------------------------------
+   // A pass on fewer byte slices of the fp64 operand costs ~0.75 of an exact one and perturbs the operator by ~1e-9 of its
+   // norm, which a Krylov iteration to tol = 1e-6 does not feel (measured: same number of passes down to 3 slices).  The
+   // iteration starts EXACT -- a solve that converges within a handful of passes never leaves that mode and is what it always
+   // was -- and switches to cheap passes once the measured decay of the residuals predicts enough passes to pay for the
+   // verification: when the reference's rule holds on the cheap passes' estimates, the basis is compressed to its leading
+   // Ritz blocks, those go through the EXACT operator one by one (rebuilding T = Y'AY from nothing), and the rule is judged
+   // on the exact residuals || (I - YY') A Y s ||.  If it fails there, the iteration goes on from that state -- with cheap
+   // passes towards a tighter threshold first, exact passes only after the third failure.
+   const bool can_cheap = o.mixed && be.set_cheap(true);
+   if (can_cheap) be.set_cheap(false);
+   bool cheap = false;        // mode of the passes being made
+   bool tainted = false;      // T holds columns from cheap passes: convergence cannot be declared from it
+   int verifications = 0;     // switches from cheap back to exact passes so far
+   double tol_cheap = 0.8 * o.tol; // threshold for the estimates of the cheap passes (the exact residual sits within the noise of it)
+   double best_cheap = 0;          // smallest worst-residual the current run of cheap passes has reached, and when
+   int best_cheap_step = 0;
+
    // ---- start block ----------------------------------------------------------------------------
    int v0 = be.alloc_block();
    be.fill_random(v0, o.seed);
@@ -253,19 +279,25 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    int W = be.alloc_block();
    double scale = 0; // running estimate of ||A|| (largest Ritz value)
    TridiagKeep keep;            // Householder reduction of the last Rayleigh-Ritz matrix
-   std::vector<double> S, Srow; // eigenvectors of T (n x n, ld n; only when needed) / their last b rows (b x n)
-   int n = 0;
+   std::vector<double> S, Srow; // eigenvectors of T (n x n, ld n; only when needed) / their last rows (nrows x n)
+   std::vector<double> Cpl;     // coupling of the waiting blocks to the leading Ritz vectors (restart)
+   int n = 0;                   // order of the last Rayleigh-Ritz problem (= na b at that time)
    uint64_t reseed = o.seed * 7919 + 13;
    int skip_rr = 0; // Rayleigh-Ritz tests to skip (set after a test that ended far from convergence)
    double prev_worst = 0; // worst relative residual of the previous test and the apply count it was made at
    int prev_step = 0;
 
    while (res.block_applies < o.max_applies) {
-      const int m = (int)V.size();
+      const int M = (int)V.size(); // blocks in the basis; V[na] goes through the operator now, W becomes block M
+      if (na >= M) throw Error(-3, "solver: internal error (no block waiting)");
       phase(PH_RESTART);
-      be.apply(V[m - 1], W);
+      be.apply(V[na], W);
       phase(PH_APPLY);
       res.block_applies++;
+      if (cheap) {
+         res.cheap_applies++;
+         tainted = true;
+      }
       // Three passes over (basis, W), each ONE Gram launch -- C = V'W and G = W'W together, the block itself riding along
       // as the last "basis" block -- and ONE update launch:
       //   1  W <- W - V C1
@@ -274,16 +306,16 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       //                              orthonormalisation, W_before = W_after R
       // i.e. classical Gram-Schmidt twice, normalisation, a third projection (the normalisation may have amplified
       // components along V) and a second normalisation: what used to be five Gram + five update launches, each Gram a
-      // round trip to the host.  H = V'AV column = C1 + C2 + C3 R1.
+      // round trip to the host.  H = V'A V_na = C1 + C2 + C3 R1.
       VW.assign(V.begin(), V.end());
       VW.push_back(W);
-      const size_t cnt = (size_t)m * b * b;
-      auto gram_vw = [&]() { // C[0 .. m b b) = V'W, Gw = W'W
-         be.gram(VW.data(), m + 1, W, C.data());
+      const size_t cnt = (size_t)M * b * b;
+      auto gram_vw = [&]() { // C[0 .. M b b) = V'W, Gw = W'W
+         be.gram(VW.data(), M + 1, W, C.data());
          Gw.assign(C.begin() + (long)cnt, C.begin() + (long)(cnt + (size_t)b * b));
       };
       auto minus_ctc = [&]() { // Gw -= C'C  (C: [q][p][c])
-         for (size_t qp = 0; qp < (size_t)m * b; qp++) {
+         for (size_t qp = 0; qp < (size_t)M * b; qp++) {
             const double *row = &C[qp * b];
             for (int c1 = 0; c1 < b; c1++) {
                const double x = row[c1];
@@ -292,20 +324,20 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
             }
          }
       };
-      auto update_with = [&](const std::vector<double> &M) { // W <- (W - V C) M : coefficients [-C_q M ; M]
-         for (size_t qp = 0; qp < (size_t)m * b; qp++) {
+      auto update_with = [&](const std::vector<double> &Mx) { // W <- (W - V C) Mx : coefficients [-C_q Mx ; Mx]
+         for (size_t qp = 0; qp < (size_t)M * b; qp++) {
             const double *row = &C[qp * b];
             double *out = &negC[qp * b];
             for (int c = 0; c < b; c++) out[c] = 0.0;
             for (int j = 0; j < b; j++) {
                const double x = -row[j];
                if (x == 0.0) continue;
-               const double *mj = &M[(size_t)j * b];
+               const double *mj = &Mx[(size_t)j * b];
                for (int c = 0; c < b; c++) out[c] += x * mj[c];
             }
          }
-         std::copy(M.begin(), M.end(), negC.begin() + (long)cnt);
-         be.gemm(VW.data(), m + 1, negC.data(), -1, W);
+         std::copy(Mx.begin(), Mx.end(), negC.begin() + (long)cnt);
+         be.gemm(VW.data(), M + 1, negC.data(), -1, W);
       };
       std::fill(H.begin(), H.begin() + (long)cnt, 0.0);
       gram_vw();
@@ -313,14 +345,14 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          negC[i] = -C[i];
          H[i] += C[i];
       }
-      be.gemm(V.data(), m, negC.data(), W, W);
+      be.gemm(V.data(), M, negC.data(), W, W);
       phase(PH_PROJ);
 
       gram_vw();
       auto t0 = clk::now();
       if (scale == 0) {
          // first step: ||A|| estimate from the diagonal block H_00 (Rayleigh quotients)
-         for (int i = 0; i < b; i++) scale = std::max(scale, std::fabs(H[(size_t)i * b + i]));
+         for (int i = 0; i < b; i++) scale = std::max(scale, std::fabs(H[((size_t)na * b + i) * b + i]));
       }
       for (size_t i = 0; i < cnt; i++) H[i] += C[i];
       minus_ctc();
@@ -333,7 +365,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       gram_vw();
       t0 = clk::now();
       // H += C3 * R1   (C: [q][p][c] row-major b x b per q; R1 column-major)
-      for (int q = 0; q < m; q++)
+      for (int q = 0; q < M; q++)
          for (int p = 0; p < b; p++) {
             const double *cr = &C[((size_t)q * b + p) * b];
             for (int c = 0; c < b; c++) {
@@ -395,28 +427,38 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          }
       }
 
-      // ---- projected matrix and Rayleigh-Ritz ------------------------------------------------------
+      // ---- projected matrix: column block na of T = V'AV over ALL blocks, and the coupling R of the new block M --------
       phase(PH_RESTART);
       t0 = clk::now();
-      n = m * b;
-      for (int q = 0; q < m; q++)
+      for (int q = 0; q < M; q++) {
+         if (q == na) continue;
          for (int p = 0; p < b; p++)
             for (int c = 0; c < b; c++) {
                const double h = H[((size_t)q * b + p) * b + c];
-               if (q == m - 1) continue;
-               Tat(q * b + p, (m - 1) * b + c) = h;
-               Tat((m - 1) * b + c, q * b + p) = h;
+               Tat(q * b + p, na * b + c) = h;
+               Tat(na * b + c, q * b + p) = h;
             }
+      }
       for (int p = 0; p < b; p++)
          for (int c = 0; c < b; c++) {
-            const double h = 0.5 * (H[((size_t)(m - 1) * b + p) * b + c] + H[((size_t)(m - 1) * b + c) * b + p]);
-            Tat((m - 1) * b + p, (m - 1) * b + c) = h;
+            const double h = 0.5 * (H[((size_t)na * b + p) * b + c] + H[((size_t)na * b + c) * b + p]);
+            Tat(na * b + p, na * b + c) = h;
          }
+      for (int j = 0; j < (M + 1) * b; j++) // block row / column M is new: it couples to block na (through R) and to nothing else
+         for (int r = 0; r < b; r++) Tat(M * b + r, j) = Tat(j, M * b + r) = 0.0;
+      for (int r = 0; r < b; r++)
+         for (int c = 0; c < b; c++) {
+            Tat(M * b + r, na * b + c) = R[(size_t)r + (size_t)c * b];
+            Tat(na * b + c, M * b + r) = R[(size_t)r + (size_t)c * b];
+         }
+      na++;
+      const int Mn = M + 1; // blocks now: V[0 .. M) and W
+      n = na * b;
       // Far from convergence the Rayleigh-Ritz test cannot succeed at the very next step (residuals fall by one to two
       // orders of magnitude per block apply at best): it is skipped for a step (two when six orders away).  Convergence is
       // only ever declared by an actual test, so the worst case is one block apply more than strictly needed.
       if (n < k && skip_rr == 0) skip_rr = 1; // fewer basis columns than wanted pairs: nothing to test yet
-      if (skip_rr > 0 && res.block_applies < o.max_applies && m + 1 <= mcap) {
+      if (skip_rr > 0 && res.block_applies < o.max_applies && na + 1 <= mcap) {
          skip_rr--;
          host_s += since(t0);
          phase(PH_RR);
@@ -425,35 +467,66 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          continue;
       }
       if (n < k) throw Error(-5, "solver: maxiter allows fewer basis vectors than the wanted number of eigenpairs");
+      // rows of T below the applied part: the waiting blocks' coupling.  Only its trailing columns are populated (a block
+      // couples to what was applied after it joined the basis): row_lo = first populated column
+      const int nu = (Mn - na) * b;
+      int row_lo = n;
+      for (int j = 0; j < n && row_lo == n; j++)
+         for (int r = 0; r < nu; r++)
+            if (Tat(n + r, j) != 0.0) {
+               row_lo = j / b * b;
+               break;
+            }
+      if (row_lo == n) row_lo = n - b;
+      const int nrows = n - row_lo;
+      Tw.resize((size_t)n * n);
       for (int j = 0; j < n; j++) std::memcpy(&Tw[(size_t)j * n], &T[(size_t)j * nmax], sizeof(double) * n);
-      // eigenvalues + the last block of rows of the eigenvectors (all the residual test needs); the full
-      // eigenvector matrix is formed only when it is used: convergence, thick restart, last step
-      Srow.resize((size_t)b * n);
-      if (symeig_desc_rows(n, Tw.data(), n, theta.data(), (m - 1) * b, b, Srow.data(), &keep) != 0)
+      // eigenvalues + the trailing rows of the eigenvectors (all the residual test needs); the full eigenvector matrix is
+      // formed only when it is used: convergence, thick restart, last step
+      Srow.resize((size_t)nrows * n);
+      if (symeig_desc_rows(n, Tw.data(), n, theta.data(), row_lo, nrows, Srow.data(), &keep) != 0)
          throw Error(-3, "solver: projected eigensolver failed");
       scale = std::max(scale, std::fabs(theta[0]));
-      // residual estimates: || R * S[(m-1)b : mb, i] ||
+      // residual estimates: || T[waiting rows, applied columns] s_i ||  (== || A u_i - theta_i u_i ||, u_i = V_applied s_i)
       res.residuals.assign(k, 0.0);
       res.evals.assign(theta.begin(), theta.begin() + k);
+      const double tol_now = cheap ? tol_cheap : o.tol;
       bool all_conv = true;
       double worst = 0;
       for (int i = 0; i < k; i++) {
-         const double *s = &Srow[(size_t)i * b];
+         const double *s = &Srow[(size_t)i * nrows];
          double r2 = 0;
-         for (int r = 0; r < b; r++) {
+         for (int r = 0; r < nu; r++) {
             double acc = 0;
-            for (int c = 0; c < b; c++) acc += R[(size_t)r + (size_t)c * b] * s[c];
+            for (int c = 0; c < nrows; c++) acc += Tat(n + r, row_lo + c) * s[c];
             r2 += acc * acc;
          }
          const double rn = std::sqrt(r2);
          res.residuals[i] = rn;
-         const double thr = o.tol * std::max(eps23, std::fabs(theta[i]));
+         const double thr = tol_now * std::max(eps23, std::fabs(theta[i]));
          worst = std::max(worst, rn / std::max(eps23, std::fabs(theta[i])));
          if (!(rn < thr)) all_conv = false;
       }
       res.max_rel_residual = worst;
-      if (all_conv || res.block_applies >= o.max_applies || m + 1 > mcap) {
-         // eigenvectors are needed now, but only the leading 2 b of them (Ritz vectors kept by a restart / returned):
+      const bool out_of_budget = res.block_applies >= o.max_applies;
+      const bool full = na + 1 > mcap;
+      // Cheap passes that stop making progress have reached their noise floor (an operand rounded too coarsely for this
+      // spectrum): no 5 % gain of the worst residual over two basis lengths of passes ends them for good -- the iteration
+      // continues from the current Ritz vectors with exact passes, as after a verification.
+      bool stalled = false;
+      if (cheap) {
+         if (best_cheap == 0 || worst < 0.95 * best_cheap) {
+            best_cheap = worst;
+            best_cheap_step = res.block_applies;
+         } else if (res.block_applies - best_cheap_step > 2 * mcap + 8)
+            stalled = true;
+      }
+      // cheap passes have met their threshold (or given up): the leading Ritz blocks go through the exact operator (below)
+      const bool verify = ((all_conv && tainted) || stalled) && !out_of_budget;
+      // number of leading Ritz blocks a compression keeps
+      const int nk = nk_wide ? std::min(nk_wide, na) : (mcap >= 6 && na >= 3) ? 2 : 1;
+      if (all_conv || out_of_budget || full || verify) {
+         // eigenvectors are needed now, but only the leading ones (Ritz vectors kept by a restart / returned):
          // selected columns by inverse iteration, verified inside; the full QL decomposition is the fallback
          const int need = std::min(n, std::max(2, nk_wide) * b);
          S.assign((size_t)n * need, 0.0);
@@ -468,60 +541,118 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       host_s += since(t0);
       phase(PH_RR);
       if (o.verbose)
-         std::fprintf(stderr, "[fpca] apply %3d  basis %4d  theta1 %.6g  theta_k %.6g  max rel resid %.3e\n",
-                      res.block_applies, n, theta[0], theta[k - 1], worst);
-      if (all_conv) {
+         std::fprintf(stderr, "[fpca] apply %3d%s basis %4d (+%d waiting)  theta1 %.6g  theta_k %.6g  max rel resid %.3e\n", res.block_applies,
+                      cheap ? " (cheap)" : tainted ? " (exact*)" : "        ", n, Mn - na, theta[0], theta[k - 1], worst);
+      if (all_conv && !tainted) {
          res.converged = true;
          break;
       }
-      if (res.block_applies >= o.max_applies) break;
-      skip_rr = worst > 1e6 * o.tol ? 2 : worst > 1e3 * o.tol ? 1 : 0;
-      // Slowly converging spectra (k reaching into the bulk: 150+ applies) spend their host time in tests that cannot
-      // succeed: the worst residual falls by a few per cent per apply.  From the decay between this test and the previous
-      // one the number of applies still needed is estimated, and the next test is placed half-way there (at most 8 applies
-      // ahead; a restart always tests).  Computed from the Ritz data only, so every rank skips alike.
-      if (prev_worst > 0 && worst < prev_worst && worst > o.tol && res.block_applies > prev_step) {
-         const double rho = std::pow(worst / prev_worst, 1.0 / (double)(res.block_applies - prev_step));
-         if (rho < 1.0 && rho > 0.0) {
-            const double n_est = std::log(o.tol / worst) / std::log(rho);
-            const int rate_skip = (int)std::min(8.0, std::max(0.0, std::floor(n_est / 2.0) - 1.0));
-            skip_rr = std::max(skip_rr, rate_skip);
+      if (out_of_budget) break;
+      if (!verify) {
+         skip_rr = worst > 1e6 * tol_now ? 2 : worst > 1e3 * tol_now ? 1 : 0;
+         // Slowly converging spectra (k reaching into the bulk: 150+ applies) spend their host time in tests that cannot
+         // succeed: the worst residual falls by a few per cent per apply.  From the decay between this test and the previous
+         // one the number of applies still needed is estimated, and the next test is placed half-way there (at most 8 applies
+         // ahead; a restart always tests).  Computed from the Ritz data only, so every rank skips alike.
+         double n_est = -1;
+         if (prev_worst > 0 && worst < prev_worst && worst > tol_now && res.block_applies > prev_step) {
+            const double rho = std::pow(worst / prev_worst, 1.0 / (double)(res.block_applies - prev_step));
+            if (rho < 1.0 && rho > 0.0) {
+               n_est = std::log(tol_now / worst) / std::log(rho);
+               const int rate_skip = (int)std::min(8.0, std::max(0.0, std::floor(n_est / 2.0) - 1.0));
+               skip_rr = std::max(skip_rr, rate_skip);
+            }
+         }
+         prev_worst = worst;
+         prev_step = res.block_applies;
+         // exact -> cheap passes: once the decay says that what is left pays for the kb exact passes of the verification
+         // (a cheap pass saves about a quarter of an exact one).  From Ritz data only: every rank switches alike.
+         if (can_cheap && !cheap && verifications < 3 && ((n_est > 4.5 * kb + 4) || (verifications > 0))) {
+            cheap = true;
+            be.set_cheap(true);
+            if (o.verbose) std::fprintf(stderr, "[fpca] apply %3d: switching to cheap passes (about %.0f passes to go)\n", res.block_applies, n_est);
          }
       }
-      prev_worst = worst;
-      prev_step = res.block_applies;
 
-      if (m + 1 > mcap) {
-         // ---- thick restart: keep the best Ritz vectors + the new residual block ----------------------
-         // nk blocks of them: one when the cap is tight, two otherwise (the second block of Ritz vectors keeps the
-         // neighbourhood of the wanted end of the spectrum in the basis, which is what slowly converging pairs need)
-         const int nk = nk_wide ? nk_wide : (mcap >= 6 && m >= 3) ? 2 : 1;
+      if (verify) {
+         // ---- cheap passes done: compress to the leading Ritz blocks and put THEM through the exact operator ------------
+         // Y_j = V_applied S_j, j < nkv (the wanted ones first).  Everything else -- the blocks waiting, T -- came from cheap
+         // passes and is dropped; T is rebuilt from nothing by the exact passes that follow (na = 0: every Y_j waits).
+         const int nkv = nk_wide ? std::min(nk_wide, na) : std::min(2, na);
          t0 = clk::now();
-         std::vector<std::vector<double>> Sk(nk, std::vector<double>((size_t)m * b * b));
-         std::vector<double> Cpl((size_t)b * b * nk); // R * S[last block, 0 : nk b]  (b x nk b, column-major)
-         for (int j = 0; j < nk; j++)
-            for (int q = 0; q < m; q++)
+         std::vector<std::vector<double>> Sk(nkv, std::vector<double>((size_t)na * b * b));
+         for (int j = 0; j < nkv; j++)
+            for (int q = 0; q < na; q++)
                for (int p = 0; p < b; p++)
                   for (int c = 0; c < b; c++) Sk[j][((size_t)q * b + p) * b + c] = S[(size_t)(q * b + p) + (size_t)(j * b + c) * n];
-         matmul(b, nk * b, b, R.data(), b, &S[(size_t)(m - 1) * b], n, Cpl.data(), b);
+         host_s += since(t0);
+         std::vector<int> Y(nkv);
+         for (int j = 0; j < nkv; j++) {
+            Y[j] = be.alloc_block();
+            be.gemm(V.data(), na, Sk[j].data(), -1, Y[j]);
+         }
+         for (int h : V) be.free_block(h);
+         V.assign(Y.begin(), Y.end());
+         std::fill(T.begin(), T.end(), 0.0);
+         na = 0;
+         cheap = false;
+         tainted = false;
+         be.set_cheap(false);
+         verifications = stalled ? 3 : verifications + 1; // (stalled: no cheap passes any more)
+         best_cheap = 0;
+         tol_cheap *= 0.5; // (should the exact residuals fail the rule: the next round of cheap passes aims lower)
+         // (until the next Rayleigh-Ritz the Ritz vectors ARE the blocks: what is returned if the budget ends right here)
+         n = nkv * b;
+         S.assign((size_t)n * n, 0.0);
+         for (int i = 0; i < n; i++) S[(size_t)i + (size_t)i * n] = 1.0;
+         skip_rr = 0;
+         prev_worst = 0;
+         keep.n = 0;
+         if (o.verbose)
+            std::fprintf(stderr, "[fpca] apply %3d: %s; %d Ritz block(s) go through the exact operator\n", res.block_applies,
+                         stalled ? "the cheap passes have stopped converging (noise floor)" : "estimates of the cheap passes meet the rule", nkv);
+         continue; // (W is free: it is overwritten by the next apply)
+      }
+
+      if (full) {
+         // ---- thick restart: keep the best Ritz vectors + the blocks waiting (the new residual block) ----------------------
+         // nk blocks of them: one when the cap is tight, two otherwise (the second block of Ritz vectors keeps the
+         // neighbourhood of the wanted end of the spectrum in the basis, which is what slowly converging pairs need)
+         t0 = clk::now();
+         std::vector<std::vector<double>> Sk(nk, std::vector<double>((size_t)na * b * b));
+         for (int j = 0; j < nk; j++)
+            for (int q = 0; q < na; q++)
+               for (int p = 0; p < b; p++)
+                  for (int c = 0; c < b; c++) Sk[j][((size_t)q * b + p) * b + c] = S[(size_t)(q * b + p) + (size_t)(j * b + c) * n];
+         // coupling of the waiting blocks to the kept Ritz vectors: T[waiting, applied] S[:, 0 : nk b]   (nu x nk b)
+         Cpl.assign((size_t)nu * nk * b, 0.0);
+         for (int c = 0; c < nk * b; c++)
+            for (int j = row_lo; j < n; j++) {
+               const double sjc = S[(size_t)j + (size_t)c * n];
+               if (sjc == 0.0) continue;
+               for (int r = 0; r < nu; r++) Cpl[(size_t)r + (size_t)c * nu] += Tat(n + r, j) * sjc;
+            }
          host_s += since(t0);
          std::vector<int> Y(nk);
          for (int j = 0; j < nk; j++) {
             Y[j] = be.alloc_block();
-            be.gemm(V.data(), m, Sk[j].data(), -1, Y[j]);
+            be.gemm(V.data(), na, Sk[j].data(), -1, Y[j]);
          }
-         for (int q = 0; q < m; q++) be.free_block(V[q]);
+         std::vector<int> waiting(V.begin() + na, V.end());
+         waiting.push_back(W);
+         for (int q = 0; q < na; q++) be.free_block(V[q]);
          V.clear();
          for (int j = 0; j < nk; j++) V.push_back(Y[j]);
-         V.push_back(W);
+         for (int h : waiting) V.push_back(h);
          W = be.alloc_block();
          std::fill(T.begin(), T.end(), 0.0);
          for (int i = 0; i < nk * b; i++) Tat(i, i) = theta[i];
-         for (int r = 0; r < b; r++)
+         for (int r = 0; r < nu; r++)
             for (int c = 0; c < nk * b; c++) {
-               Tat(nk * b + r, c) = Cpl[(size_t)r + (size_t)c * b];
-               Tat(c, nk * b + r) = Cpl[(size_t)r + (size_t)c * b];
+               Tat(nk * b + r, c) = Cpl[(size_t)r + (size_t)c * nu];
+               Tat(c, nk * b + r) = Cpl[(size_t)r + (size_t)c * nu];
             }
+         na = nk;
          res.restarts++;
       } else {
          V.push_back(W);
@@ -529,9 +660,9 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       }
    }
 
-   // ---- Ritz vectors of the last Rayleigh-Ritz: U_j = V S[:, j b : (j+1) b], j < kb ------------------
+   // ---- Ritz vectors of the last Rayleigh-Ritz: U_j = V_applied S[:, j b : (j+1) b], j < kb ------------------
    {
-      const int m = n / b;
+      const int m = n / b; // applied blocks at the last Rayleigh-Ritz (a prefix of V)
       const int have = (int)(S.size() / (size_t)std::max(n, 1)); // columns of S that were formed
       std::vector<double> Sk((size_t)m * b * b);
       for (int j = 0; j < kb; j++) {
@@ -546,7 +677,9 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    }
    for (int h : V) be.free_block(h);
    be.free_block(W);
+   if (can_cheap) be.set_cheap(false);
    res.seconds_host = host_s;
+   res.verifications = verifications;
    phase(PH_RESTART);
    if (timing)
       std::fprintf(stderr, "[fpca] solver phases (ms): apply %.3f  projections %.3f  orthonormalisation %.3f  Rayleigh-Ritz %.3f  restart/Ritz vectors/other %.3f\n",

@@ -17,12 +17,15 @@ struct SolverOpts {
    int max_blocks = 0;    // basis cap in blocks (>= 3); 0 = automatic
    uint64_t seed = 1;
    int verbose = 0;
+   bool mixed = true;     // use the backend's cheap passes where it has them (BlockBackend::set_cheap), verified by exact ones
 };
 
 struct SolverResult {
    bool converged = false;
    int block_applies = 0;
    int restarts = 0;
+   int cheap_applies = 0;        // of block_applies: passes in the backend's cheap arithmetic
+   int verifications = 0;        // times the leading Ritz blocks were put through the exact operator after cheap passes
    double max_rel_residual = 0;  // max_i res_i / max(eps^(2/3), |theta_i|)
    double seconds_host = 0;      // projected eigenproblem + small dense algebra
    std::vector<double> evals;    // k eigenvalues of A, descending

@@ -32,7 +32,12 @@
 extern "C" {
 #endif
 
-#define FPCA_VERSION "0.1.0"
+#define FPCA_VERSION "0.2.0"
+/* Binary interface revision: bumped whenever a struct below changes size or a field changes meaning.  A binding checks
+ * fpca_abi_version() == FPCA_ABI_VERSION once after loading the library (flashpca_amd/_lib.py does).
+ *   2 (library 0.2.0): fpca_pca_opts / fpca_pca_info carry their own size and the mixed-precision fields; `maxiter` counts the
+ *     reference's restarts (it was a cap on block applies in 0.1.0 -- use max_applies for that). */
+#define FPCA_ABI_VERSION 2
 
 /* standardisation methods: same numeric values as the reference (util.h:34-38); the packed-genotype constructors
  * accept BINOM / BINOM2 like the CLI (flashpca.cpp:336-349), fpca_create_dense accepts all five */
@@ -69,6 +74,7 @@ typedef struct fpca_ctx fpca_ctx;
 
 const char *fpca_last_error(void);
 const char *fpca_version(void);
+int fpca_abi_version(void);
 /* number of visible HIP devices (<0 on error); name/arch of one device into buf */
 int fpca_device_count(void);
 int fpca_device_name(int device, char *buf, int buflen);
@@ -181,6 +187,8 @@ int fpca_set_total_snps(fpca_ctx *ctx, uint64_t P_total);
  * With fewer than three block widths of samples (N < 3 b; the reference admits ndim <= (min(N,P)-1)/2, flashpca.cpp:623-633)
  * X X' is formed from ceil(N/b) applies on the identity and decomposed directly. */
 typedef struct fpca_pca_opts {
+   uint32_t struct_size; /* sizeof(fpca_pca_opts) / sizeof(fpca_pca_info) of the header the CALLER was compiled against; set by */
+   uint32_t info_size;   /* fpca_pca_default_opts, checked by fpca_pca (FPCA_EINVAL on a mismatch instead of reading garbage) */
    int ndim;        /* --ndim (flashpca.cpp:325 default 10) */
    int blockvec;    /* block width b (16, 32, 48 or 64); 0 = automatic: 16 for ndim <= 64, 32 for ndim <= 128, else 64 -- the
                      * narrowest block gives the shortest time to solution (pca_driver.cpp).  ndim may exceed b -- up to the
@@ -201,10 +209,18 @@ typedef struct fpca_pca_opts {
                      * orthogonalisation (round 2's scheme: one all-reduce per apply); 0 (default) = row-sharded, see fpca_set_rank */
    int max_applies; /* hard cap on block applies, overriding the budget derived from maxiter; 0 = none.  Must allow at least
                      * ceil(ndim / b) of them (FPCA_EINVAL otherwise: fewer basis vectors than wanted pairs) */
+   int mixed;       /* exact-integer arithmetic only.  0 = automatic (on), 1 = on, -1 = off.  On: the Krylov passes run on
+                     * `cheap_slices` byte slices of the fp64 operand instead of the context's S (4 slices = a 30-bit operand:
+                     * ~1e-9 of operator noise, nothing accumulating -- a pass costs about 0.6 of an exact one), and when the
+                     * reference's convergence rule holds on those passes the Ritz vectors are put through the EXACT operator
+                     * (all S slices) once: the eigenvalues returned are Rayleigh quotients of the exact operator and the rule
+                     * ||A u - theta u|| < tol max(eps^(2/3), |theta|) (randompca.cpp:173-178) is judged on exact residuals.  If
+                     * it does not hold there, the iteration continues from those vectors with exact passes only. */
+   int cheap_slices; /* 0 = automatic (4); 3..S-1 */
 } fpca_pca_opts;
 
 typedef struct fpca_pca_info {
-   int converged;         /* all ndim pairs met the rule */
+   int converged;         /* all ndim pairs met the rule (mixed precision: on residuals of the exact operator) */
    int block_applies;     /* passes over the packed matrix (each = b single-vector operator applications) */
    int vector_ops;        /* block_applies * b  == the reference's nops unit (svdwide.cpp:67) */
    int restarts;          /* thick restarts */
@@ -217,6 +233,9 @@ typedef struct fpca_pca_info {
    double seconds_total;
    double seconds_download; /* U and Px to the caller's memory (pinned, pipelined; Px = U sqrt(d) fused into the host side) */
    double seconds_post;     /* loadings (one K2 pass per block of eigenvectors) + mean/sd download */
+   int cheap_applies;       /* of block_applies: passes on cheap_slices byte slices (0 when mixed precision is off) */
+   int cheap_slices;        /* slices of those passes (0: none ran) */
+   double seconds_exact;    /* of seconds_apply: the exact passes (verification and whatever followed it) */
 } fpca_pca_info;
 
 void fpca_pca_default_opts(fpca_pca_opts *opts);
@@ -234,55 +253,6 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
  * err[j] = || X X' u_j / div - u_j lambda_j ||^2, mse = sum(err)/(N k), rmse = sqrt(mse). */
 int fpca_check(fpca_ctx *ctx, const double *evec, int64_t ldu, const double *eval, int k, int divisor,
                double *err, double *mse, double *rmse);
-
-/* ------------------------------------------------------------------------------------------------
- * Measurement hooks (bench.py): run `steps` block-applies of width b on device-resident random blocks after
- * `warmup` untimed ones; HIP events on the context's stream bracket every kernel.  Times in milliseconds. */
-typedef struct fpca_bench_result {
-   double ms_total;      /* wall (event) time of the timed region, all steps */
-   double ms_xt;         /* average per step in K2 (xt_b), incl. its split-K reduce */
-   double ms_x;          /* average per step in K3 (x_t), incl. its split-K reduce */
-   double ms_allreduce;  /* average per step in the all-reduce (0 for one rank) */
-   double flops_per_step;           /* 4 N P_g b */
-   double packed_bytes_per_step;    /* 2 ceil(N/4) P_g */
-   double ms_gemm_xt;    /* average per step of the K2 GEMM kernel launch alone */
-   double ms_gemm_x;     /* average per step of the K3 GEMM kernel launch alone */
-} fpca_bench_result;
-int fpca_bench_apply(fpca_ctx *ctx, int b, int steps, int warmup, fpca_bench_result *res);
-/* Live profiling of caller-driven applies: between fpca_profile_begin and fpca_profile_end every
- * fpca_apply_xxt_dev call (up to max_steps of them) records HIP events on its stream around K2, K3 and the
- * all-reduce; fpca_profile_end synchronises and returns the per-step averages over the recorded calls
- * (ms_total = sum of all recorded steps; *nsteps = number recorded). */
-int fpca_profile_begin(fpca_ctx *ctx, int max_steps);
-/* Eight in-stream events per apply are not free at small sizes (0.62 vs 0.53 ms per apply at 50,000 x 20,000): with
- * stride > 1 only every stride-th apply of the profiled span carries them, the others run exactly as the solver runs
- * them.  Default 1. */
-int fpca_profile_sample_every(fpca_ctx *ctx, int stride);
-int fpca_profile_end(fpca_ctx *ctx, int b, fpca_bench_result *res, int *nsteps);
-/* time the one-off statistics pass (K1) the same way: milliseconds per launch, bytes read */
-int fpca_bench_stats(fpca_ctx *ctx, int reps, double *ms_per_launch, double *bytes_per_launch);
-
-/* diagnostic: D(16x16, row-major) = A(16x4) B(4x16) through v_mfma_f64_16x16x4_f64 with the lane->operand mapping the
- * kernels assume; host pointers.  Used by tests/test_gpu_kernels.py as a guard on the hardware layout. */
-int fpca_debug_mfma_probe(const double *A, const double *B, double *D);
-/* diagnostic: D(32x32 int32, row-major) = A(32x32 int8, row-major) * Bt(32x32 int8, row j = column j of B)' through
- * v_mfma_i32_32x32x32_i8 with the lane->operand mapping of kernels_i8.hip; host pointers */
-int fpca_debug_mfma_i8_probe(const int8_t *A, const int8_t *Bt, int32_t *D);
-/* diagnostic: sustained rate (TFLOP/s) of a pure v_mfma_f64_16x16x4_f64 stream with `waves_per_simd` (1..8) resident
- * waves per SIMD and no memory traffic; pattern 0..3 selects the operand-register sharing pattern (kernels.hip).  The
- * practical ceiling to read the GEMM kernels' roofline fraction against (72-74 TFLOP/s at 2 waves/SIMD vs 78.6 datasheet).
- * pattern 10 / 11: v_mfma_i32_32x32x32_i8 in TOP/s with zero / pseudo-random operands. */
-int fpca_debug_mfma_peak(int waves_per_simd, int iters, int pattern, double *tflops);
-/* diagnostic (tests/test_gpu_kernels.py): the K4 helpers the eigensolver runs on its HBM-resident basis, on caller data and
- * through the very backend object the solver drives (HipBackend::gram incl. its split-K plane reduction, HipBackend::gemm).
- * V: N x (nq b) fp64 column-major with leading dimension N, basis block q = columns [q b, (q+1) b); W: N x b.
- *   C_gram (may be NULL): [q][p][c] = sum_s V_q[s][p] W[s][c]                       nq b b doubles
- *   Out (may be NULL), N x b: (use_init ? W : 0) + sum_q V_q C_in[q]                C_in: [q][p][c], nq b b doubles */
-int fpca_debug_k4(fpca_ctx *ctx, int b, int nq, const double *V, const double *W, double *C_gram, const double *C_in, int use_init,
-                  double *Out);
-/* diagnostic: placement census of an nwg-workgroup grid (256 threads, lds_bytes dynamic LDS each): out[2i] = HW_ID,
- * out[2i+1] = XCC_ID of workgroup i */
-int fpca_debug_census(int nwg, uint64_t lds_bytes, uint32_t *out);
 
 #ifdef __cplusplus
 }

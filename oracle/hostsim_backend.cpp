@@ -6,6 +6,7 @@
  * oracle's perform_op_mat on this rank's SNP shard, and the cross-rank sum is a caller-supplied callback
  * (torch.distributed/gloo in tests/test_multirank_gloo.py).  Never linked into libfpca.so or the CLI.
  */
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -34,8 +35,11 @@ class HostSimBackend : public fpca::BlockBackend {
    // is this rank's slice of rows, the operator is all-gather -> oracle operator on the SNP shard -> reduce-scatter (both
    // built from the callback's sum, like the HIP backend does over a caller-supplied all-reduce), the Gram coefficients are
    // all-reduced.  nranks <= 1: whole blocks, one all-reduce of the N x b product per apply (round 2's scheme).
-   HostSimBackend(orc_data *d, int b, uint32_t block_size, hostsim_allreduce_fn ar, void *user, int nranks = 1, int rank = 0)
-       : d_(d), b_(b), N_(orc_N(d)), ar_(ar), user_(user)
+   // cheap_bits > 0: the backend offers "cheap passes" like the exact-integer mode of the HIP backend does -- the input block
+   // is rounded to cheap_bits-bit fixed point per column (relative to the column maximum, as k_slice rounds the operand of
+   // K2) before the oracle's operator is applied to it; 0: no cheap arithmetic (set_cheap returns false).
+   HostSimBackend(orc_data *d, int b, uint32_t block_size, hostsim_allreduce_fn ar, void *user, int nranks = 1, int rank = 0, int cheap_bits = 0)
+       : d_(d), b_(b), N_(orc_N(d)), ar_(ar), user_(user), cheap_bits_(cheap_bits)
    {
       op_ = orc_op_new(d, block_size ? block_size : (uint32_t)orc_nsnps(d), 1);
       rows_ = N_;
@@ -74,14 +78,45 @@ class HostSimBackend : public fpca::BlockBackend {
       }
       take_rows(whole, blocks_[h]); // (sharded: the rows this rank keeps of the block every rank would have generated)
    }
+   bool set_cheap(bool cheap) override
+   {
+      if (cheap_bits_ <= 0) return false;
+      cheap_on_ = cheap;
+      return true;
+   }
+   int cheap_applies() const { return n_cheap_; }
+   // the cheap passes' operand: every column rounded to cheap_bits_ bits below the power of two above its largest entry
+   void round_columns(const double *in, std::vector<double> &out) const
+   {
+      out.assign(in, in + (size_t)N_ * b_);
+      for (int c = 0; c < b_; c++) {
+         double m = 0;
+         for (uint64_t i = 0; i < N_; i++) m = std::max(m, std::fabs(out[i + (size_t)c * N_]));
+         if (!(m > 0)) continue;
+         int e = 0;
+         (void)std::frexp(m, &e);
+         const double up = std::ldexp(1.0, cheap_bits_ - e), dn = std::ldexp(1.0, e - cheap_bits_);
+         for (uint64_t i = 0; i < N_; i++) out[i + (size_t)c * N_] = std::nearbyint(out[i + (size_t)c * N_] * up) * dn;
+      }
+   }
    void apply(int in, int out) override
    {
+      if (cheap_on_) n_cheap_++;
       if (!sh_.on()) {
-         orc_perform_op_mat(op_, blocks_[in].data(), b_, blocks_[out].data());
+         const double *src = blocks_[in].data();
+         if (cheap_on_) {
+            round_columns(src, rounded_);
+            src = rounded_.data();
+         }
+         orc_perform_op_mat(op_, src, b_, blocks_[out].data());
          sum(blocks_[out].data(), N_ * (uint64_t)b_);
          return;
       }
       all_gather(blocks_[in], full_in_);
+      if (cheap_on_) {
+         round_columns(full_in_.data(), rounded_);
+         full_in_ = rounded_;
+      }
       orc_perform_op_mat(op_, full_in_.data(), b_, full_out_.data());
       sum(full_out_.data(), N_ * (uint64_t)b_); // reduce-scatter = sum + keep my rows
       take_rows(full_out_, blocks_[out]);
@@ -182,6 +217,9 @@ class HostSimBackend : public fpca::BlockBackend {
    std::vector<std::vector<double>> blocks_; // column-major rows_ x b
    std::vector<unsigned char> used_;
    std::vector<double> full_in_, full_out_;  // row-sharded: whole N x b blocks either side of the operator
+   int cheap_bits_ = 0, n_cheap_ = 0;
+   bool cheap_on_ = false;
+   std::vector<double> rounded_;
 };
 
 } // namespace
@@ -192,13 +230,27 @@ extern "C" {
  * nranks / rank: > 1 ranks -> the row-sharded solver (RowShard), 0 or 1 -> whole blocks on every rank.
  * maxiter > 0: --maxiter as the reference counts it (fpca_pca_opts.maxiter); maxiter < 0: fpca_pca_opts.max_applies = -maxiter.
  * info_out: [converged, block_applies, restarts, blockvec].  Returns FPCA_OK / FPCA_ENOTCONVERGED / <0. */
+int hostsim_pca2(orc_data *d, int ndim, int blockvec, int maxiter, double tol, int divisor, int max_blocks,
+                 uint64_t seed, int verbose, uint64_t P_total, hostsim_allreduce_fn ar, void *user, double *U,
+                 double *dvals, double *Px, double *pve, double *trace, int *info_out, int nranks, int rank, int cheap_bits);
 int hostsim_pca(orc_data *d, int ndim, int blockvec, int maxiter, double tol, int divisor, int max_blocks,
                 uint64_t seed, int verbose, uint64_t P_total, hostsim_allreduce_fn ar, void *user, double *U,
                 double *dvals, double *Px, double *pve, double *trace, int *info_out, int nranks, int rank)
 {
+   return hostsim_pca2(d, ndim, blockvec, maxiter, tol, divisor, max_blocks, seed, verbose, P_total, ar, user, U, dvals, Px, pve, trace,
+                       info_out, nranks, rank, 0);
+}
+
+/* The same with the solver's mixed-precision logic in play: cheap_bits > 0 makes the backend offer cheap passes (its input
+ * rounded to cheap_bits bits per column), which the solver verifies by exact ones; info_out then has 6 entries:
+ * [converged, block_applies, restarts, blockvec, cheap_applies, cheap passes the backend actually ran]. */
+int hostsim_pca2(orc_data *d, int ndim, int blockvec, int maxiter, double tol, int divisor, int max_blocks,
+                 uint64_t seed, int verbose, uint64_t P_total, hostsim_allreduce_fn ar, void *user, double *U,
+                 double *dvals, double *Px, double *pve, double *trace, int *info_out, int nranks, int rank, int cheap_bits)
+{
    try {
       const int b = fpca::choose_blockvec(ndim, blockvec);
-      HostSimBackend be(d, b, 0, ar, user, nranks, rank); // nranks > 1: row-sharded solver; <= 1: replicated (round 2)
+      HostSimBackend be(d, b, 0, ar, user, nranks, rank, cheap_bits); // nranks > 1: row-sharded solver; <= 1: replicated (round 2)
       fpca_pca_opts o;
       std::memset(&o, 0, sizeof(o));
       o.ndim = ndim;
@@ -227,6 +279,10 @@ int hostsim_pca(orc_data *d, int ndim, int blockvec, int maxiter, double tol, in
          info_out[1] = info.block_applies;
          info_out[2] = info.restarts;
          info_out[3] = info.blockvec;
+         if (cheap_bits > 0) {
+            info_out[4] = info.cheap_applies;
+            info_out[5] = be.cheap_applies();
+         }
       }
       return rc;
    } catch (const fpca::Error &e) {

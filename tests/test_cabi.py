@@ -11,18 +11,51 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "fpca.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(fpca_[a-z0-9_]+)\s*\(", src)
+HEADERS = ("fpca.h", "fpca_debug.h")  # the drop-in boundary; measurement hooks and hardware diagnostics
+
+
+def declared_functions(headers=HEADERS):
+    names = []
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names += re.findall(r"\b(fpca_[a-z0-9_]+)\s*\(", src)
     return sorted(set(n for n in names if n not in ("fpca_allreduce_fn",)))
 
 
-def test_header_is_plain_c():
-    """The header must compile as C (extern "C", plain pointers and sizes, no C++/torch types)."""
-    out = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "fpca.h")],
+@pytest.mark.parametrize("header", HEADERS)
+def test_header_is_plain_c(header):
+    """The headers must compile as C (extern "C", plain pointers and sizes, no C++/torch types)."""
+    out = subprocess.run(["gcc", "-std=c99", "-Wall", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", header)],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+
+
+def test_drop_in_header_carries_no_lab_bench():
+    """include/fpca.h is what a maintainer of the reference binds (svdwide.h:77-81, randompca.h:77-80): the measurement
+    hooks and hardware probes live in include/fpca_debug.h, which includes it -- not the other way round."""
+    main = declared_functions(("fpca.h",))
+    assert not [n for n in main if re.match(r"fpca_(debug|bench|profile)_", n)], main
+    assert "fpca_debug.h" not in open(os.path.join(ROOT, "include", "fpca.h")).read()
+    dbg = set(declared_functions(("fpca_debug.h",))) - set(main)
+    assert dbg and all(re.match(r"fpca_(debug|bench|profile)_", n) for n in dbg), dbg
+
+
+def test_struct_layouts_match_the_header(built_lib):
+    """The ctypes mirrors of fpca_pca_opts / fpca_pca_info have the sizes the compiled library reports (struct_size /
+    info_size, written by fpca_pca_default_opts), and the ABI revision is the header's."""
+    import flashpca_amd
+    from flashpca_amd import _lib
+
+    o = _lib.PcaOpts()
+    flashpca_amd.lib().fpca_pca_default_opts(C.byref(o))
+    assert (o.struct_size, o.info_size) == (C.sizeof(_lib.PcaOpts), C.sizeof(_lib.PcaInfo))
+    hdr = open(os.path.join(ROOT, "include", "fpca.h")).read()
+    assert int(re.search(r"#define FPCA_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION == flashpca_amd.lib().fpca_abi_version()
+    # a caller built against another header is refused before anything is read through the wrong layout
+    o.struct_size -= 8
+    rc = flashpca_amd.lib().fpca_pca(None, C.byref(o), None, None, None, None, None, None, None)
+    assert rc == -1
 
 
 def test_library_exports_every_declared_symbol(built_lib):
@@ -35,7 +68,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for n in names:
         assert hasattr(L, n), "libfpca.so does not export %s" % n
         assert n in _lib.SIGNATURES, "flashpca_amd/_lib.py has no signature for %s" % n
-    assert flashpca_amd.lib().fpca_version().decode() == "0.1.0"
+    assert flashpca_amd.lib().fpca_version().decode() == "0.2.0"
 
 
 def test_product_never_touches_the_oracle():

@@ -22,6 +22,8 @@ def hostsim():
         L.hostsim_pca.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_int,
                                   C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.c_int]
+        L.hostsim_pca2.restype = C.c_int
+        L.hostsim_pca2.argtypes = L.hostsim_pca.argtypes + [C.c_int]
         L.hostsim_symeig.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.hostsim_symeig_rows.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.hostsim_symeig_cols.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -37,7 +39,8 @@ def hostsim():
     return HS
 
 
-def run_pca(d, k, blockvec=0, tol=1e-6, maxiter=500, div=2, max_blocks=0, seed=1, allreduce=None, P_total=0, nranks=1, rank=0):
+def run_pca(d, k, blockvec=0, tol=1e-6, maxiter=500, div=2, max_blocks=0, seed=1, allreduce=None, P_total=0, nranks=1, rank=0,
+            cheap_bits=0, verbose=0):
     L = hostsim()
     N = d.N
     U = np.zeros((N, k), order="F")
@@ -45,10 +48,11 @@ def run_pca(d, k, blockvec=0, tol=1e-6, maxiter=500, div=2, max_blocks=0, seed=1
     Px = np.zeros((N, k), order="F")
     pve = np.zeros(k)
     tr = C.c_double()
-    info = (C.c_int * 4)()
-    rc = L.hostsim_pca(d.h, k, blockvec, maxiter, tol, div, max_blocks, seed, 0, P_total, allreduce, None, U.ctypes.data,
-                       dv.ctypes.data, Px.ctypes.data, pve.ctypes.data, C.byref(tr), info, nranks, rank)
-    return rc, dict(U=U, d=dv, Px=Px, pve=pve, trace=tr.value, converged=info[0], applies=info[1], restarts=info[2], b=info[3])
+    info = (C.c_int * 6)()
+    rc = L.hostsim_pca2(d.h, k, blockvec, maxiter, tol, div, max_blocks, seed, verbose, P_total, allreduce, None, U.ctypes.data,
+                        dv.ctypes.data, Px.ctypes.data, pve.ctypes.data, C.byref(tr), info, nranks, rank, cheap_bits)
+    return rc, dict(U=U, d=dv, Px=Px, pve=pve, trace=tr.value, converged=info[0], applies=info[1], restarts=info[2], b=info[3],
+                    cheap_applies=info[4], backend_cheap_applies=info[5])
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 16, 33, 64, 129, 200])
@@ -198,6 +202,43 @@ def test_more_components_than_the_block_width_few_samples():
     rc, r2 = run_pca(d, k)  # automatic width 32: the Krylov route fits
     assert rc == 0 and r2["converged"] == 1 and r2["b"] == 32
     assert np.max(np.abs(r2["d"] - w[:k])) < 1e-9 * w[0]
+
+
+@pytest.mark.parametrize("k,bits,kw", [(30, 30, {}), (50, 30, {}), (50, 30, dict(max_blocks=8)), (10, 30, dict(blockvec=16, max_blocks=4)),
+                                        (30, 14, {}), (30, 8, {})])
+def test_mixed_precision_passes_are_verified_by_exact_ones(golden_dir, k, bits, kw):
+    """The solver's mixed-precision logic (solver.cpp) against a backend whose cheap passes round the operand to `bits` bits
+    per column (what fewer byte slices do on the GPU): the iteration starts exact, switches to cheap passes once the decay of
+    the residuals says the verification will pay, and the reference's rule (randompca.cpp:173-178) is judged on residuals of
+    the EXACT operator -- checked here against the dense matrix.  30 bits: the cheap passes carry the solve.  14 / 8 bits: far
+    too coarse for tol = 1e-6 -- their estimates pass while the exact residuals do not, or they stall at their noise floor;
+    either way the solve must end converged in exact arithmetic, never with the cheap passes' answer."""
+    N = O.count_fam_rows(os.path.join(golden_dir, "data_chr1.fam"))
+    d = O.OracleData(os.path.join(golden_dir, "data_chr1.bed"), N, "binom2")
+    X = d.dense()
+    w = np.linalg.eigvalsh(X @ X.T)[::-1][:k] / d.P
+    rc0, r0 = run_pca(d, k, **kw)
+    rc, r = run_pca(d, k, cheap_bits=bits, **kw)
+    assert rc0 == 0 and rc == 0 and r["converged"] == 1
+    assert r0["cheap_applies"] == 0 and r["cheap_applies"] > 0 and r["cheap_applies"] == r["backend_cheap_applies"]
+    assert r["applies"] - r["cheap_applies"] >= -(-k // r["b"])  # at least the exact passes over the wanted Ritz blocks
+    assert np.max(np.abs(r["d"] - w) / w) < 1e-9
+    assert np.max(np.abs(r["d"] - r0["d"]) / w) < 1e-9
+    assert np.max(np.abs(r["U"].T @ r["U"] - np.eye(k))) < 1e-9
+    res = np.linalg.norm(X @ (X.T @ r["U"]) / d.P - r["U"] * r["d"], axis=0)
+    assert np.max(res / r["d"]) < 1.05e-6  # the rule itself, on the exact operator
+    if bits >= 30:
+        assert r["applies"] <= r0["applies"] + 2 * -(-k // r["b"]) + 2  # cheap passes converge like exact ones (+ the verification)
+
+
+def test_easy_spectrum_never_leaves_exact_arithmetic(golden_dir):
+    """A solve that converges within a handful of passes is what it always was: no cheap pass, no verification."""
+    N = O.count_fam_rows(os.path.join(golden_dir, "hapmap3_data.fam"))
+    d = O.OracleData(os.path.join(golden_dir, "hapmap3_data.bed"), N, "binom2")
+    rc0, r0 = run_pca(d, 4)
+    rc, r = run_pca(d, 4, cheap_bits=30)
+    assert rc0 == 0 and rc == 0 and r["cheap_applies"] == 0 and r["applies"] == r0["applies"]
+    assert np.array_equal(r["d"], r0["d"])
 
 
 def test_not_converged_is_reported(golden_dir):
