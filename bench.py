@@ -68,42 +68,85 @@ WARMUP = {"cfg2": 20, "tiny": 20, "cfg3": 5, "cfg5": 2, "cfg4shard": 10, "cfg5sh
 SPINUP = {"cfg2": 150, "tiny": 300, "cfg3": 4, "cfg5": 1, "cfg4shard": 20, "cfg5shard": 4}
 
 
-def measure_traffic(args, dom):
-    """bytes per launch of the dominant GEMM kernel from two rocprofv3 --pmc child runs (see main)."""
-    import collections
+def _child(args, prof_args, steps, tmp):
+    """one child run of this bench (block applies only) under rocprofv3; returns the rows of the csv it wrote"""
     import csv
     import glob
     import subprocess
+
+    cmd = ["rocprofv3"] + prof_args + ["--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
+           os.path.abspath(__file__), "--workload", args.workload, "--accum", args.accum, "--blockvec", str(args.blockvec),
+           "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-pca", "--no-alt", "--no-e2e", "--traffic", "none"]
+    subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True,
+                   env={k: v for k, v in dict(os.environ, TMPDIR="/tmp").items() if k != "LD_PRELOAD"})
+    pat = "*kernel_trace.csv" if "--pmc" not in prof_args else "*counter_collection.csv"
+    fs = glob.glob(os.path.join(tmp, "**", pat), recursive=True)
+    if not fs:
+        raise RuntimeError("rocprofv3 wrote no %s" % pat)
+    key = "Dispatch_Id" if "--pmc" in prof_args else "Start_Timestamp"
+    return sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r[key]))
+
+
+def _dominant_rows(rows, args, dom, id_key="Dispatch_Id"):
+    """the launches of the dominant GEMM kernel among `rows` (one template serves K2 and K3 in the int8 mode: its launches
+    alternate K2, K3, K2, ...)"""
+    if args.accum.startswith("i8"):
+        ids = sorted({int(r[id_key]) for r in rows if "k_gemm_i8" in r["Kernel_Name"]})
+        want = {d for i, d in enumerate(ids) if i % 2 == (0 if dom == "xt_b" else 1)}
+        return [r for r in rows if "k_gemm_i8" in r["Kernel_Name"] and int(r[id_key]) in want]
+    key = "k_xt_b" if dom == "xt_b" else "k_x_t"
+    return [r for r in rows if key in r["Kernel_Name"]]
+
+
+def measure_counters(args, dom):
+    """What hardware counters and the kernel trace say about the dominant GEMM kernel, from four child runs of this bench (block
+    applies only) right after the timed region -- separate passes, as the guide prescribes:
+      --pmc FETCH_SIZE, --pmc WRITE_SIZE       HBM bytes per launch (FETCH_SIZE counts 64 of every 128 B on gfx950: x2; KiB)
+      --kernel-trace --pmc SQ_* GRBM_GUI_ACTIVE  effective clock, matrix-pipe busy fraction, VALU instructions per MFMA, LDS conflicts
+      --kernel-trace                           the kernel's duration in EVENT-FREE steps (counters serialise kernels, a trace does not)
+    """
     import tempfile
 
-    total = 0.0
-    alone_ns = []  # the dominant kernel's own duration in these runs: counters serialise the kernels, so nothing runs beside it
-    for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):  # KiB; FETCH_SIZE counts 64 of every 128 B on gfx950
+    res = dict(traffic=0.0)
+    alone_ns = []  # the dominant kernel's own duration in the counter runs: nothing runs beside it there
+    for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
         with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
-                   os.path.abspath(__file__), "--workload", args.workload, "--accum", args.accum, "--blockvec", str(args.blockvec),
-                   "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pca", "--no-alt", "--no-e2e", "--traffic", "none"]
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True,
-                           env={k: v for k, v in dict(os.environ, TMPDIR="/tmp").items() if k != "LD_PRELOAD"})
-            fs = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
-            if not fs:
-                raise RuntimeError("rocprofv3 wrote no counter file")
-            rows = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Dispatch_Id"]))
-        if args.accum == "i8":  # one template serves K2 and K3: its launches alternate K2, K3, K2, ...
-            ids = [int(r["Dispatch_Id"]) for r in rows if "k_gemm_i8" in r["Kernel_Name"]]
-            want = {d for i, d in enumerate(sorted(set(ids))) if i % 2 == (0 if dom == "xt_b" else 1)}
-            vals = [float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) in want and r["Counter_Name"] == counter]
-            alone_ns += [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows
-                         if int(r["Dispatch_Id"]) in want and r["Counter_Name"] == counter and r.get("End_Timestamp")]
-        else:
-            key = "k_xt_b" if dom == "xt_b" else "k_x_t"
-            vals = [float(r["Counter_Value"]) for r in rows if key in r["Kernel_Name"] and r["Counter_Name"] == counter]
-            alone_ns += [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows
-                         if key in r["Kernel_Name"] and r["Counter_Name"] == counter and r.get("End_Timestamp")]
+            rows = _dominant_rows(_child(args, ["--pmc", counter], 2, tmp), args, dom)
+        vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter]
+        alone_ns += [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if r["Counter_Name"] == counter and r.get("End_Timestamp")]
         if not vals:
             raise RuntimeError("no launches of the dominant kernel in the counter file")
-        total += sum(vals) / len(vals) * scale
-    return total, (sum(alone_ns) / len(alone_ns) * 1e-6 if alone_ns else None)
+        res["traffic"] += sum(vals) / len(vals) * scale
+    res["ms_alone"] = sum(alone_ns) / len(alone_ns) * 1e-6 if alone_ns else None
+    try:
+        sq = ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            rows = _dominant_rows(_child(args, ["--kernel-trace", "--pmc"] + sq, 2, tmp), args, dom)
+        mean = lambda c: (lambda v: sum(v) / len(v) if v else None)([float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == c])
+        dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp")]
+        g, busy, im, iv, lc, la = (mean(c) for c in sq)
+        why = {}
+        if g and dur:
+            why["clock_ghz"] = g / 8 / (sum(dur) / len(dur))  # GRBM_GUI_ACTIVE sums the 8 XCDs
+        if g and busy is not None:
+            why["mfma_pipe_busy"] = busy / 1024 / (g / 8)     # SQ_VALU_MFMA_BUSY_CYCLES sums the 1024 SIMDs
+        if im:
+            why["valu_per_mfma"] = iv / im
+        if la:
+            why["lds_bank_conflict_frac"] = lc / la
+        res["why"] = why
+    except Exception as e:
+        res["why"] = dict(error=str(e)[:200])
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            rows = _dominant_rows(_child(args, ["--kernel-trace"], 12, tmp), args, dom, id_key="Dispatch_Id")
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows][-10:]  # the timed region of the child: its last launches
+        res["ms_trace"] = sum(d) / len(d) * 1e-6 if d else None
+        res["trace_launches"] = len(d)
+    except Exception as e:
+        res["ms_trace"] = None
+        res["trace_error"] = str(e)[:200]
+    return res
 
 
 def e2e_cli(fp, size, k, device):
@@ -182,6 +225,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pca", action="store_true")
     ap.add_argument("--no-pca-hard", action="store_true", help="skip the second full PCA on a slowly converging spectrum (4 sub-populations)")
+    ap.add_argument("--no-validate", action="store_true", help="several ranks: skip the self-validation against a one-context copy of the whole matrix on rank 0")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra exact-int8-mode measurement of the same workload")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run of the flashpca CLI on a fileset in /tmp")
     ap.add_argument("--e2e-size", default="cfg2", choices=["cfg2", "cfg3"],
@@ -298,11 +342,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    # in-stream HIP events around K2 / K3 / their GEMM kernels / the all-reduce on every 4th step of the timed region (all of
-    # them when there are fewer than 8 steps): 8 events per apply cost 15 % at cfg2 size, and the clean steps are the ones
-    # the solver actually runs
-    stride = 4 if args.steps >= 8 else 1
-    ctx.profile_begin(args.steps, sample_every=stride)
+    # THE TIMED REGION: exactly K block applies, issued as the solver issues them -- no HIP events, no profiling hooks
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.apply_xxt_dev(B.data_ptr(), b, Y.data_ptr())
@@ -311,11 +351,23 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof = ctx.profile_end(b)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # Right after it, an INSTRUMENTED region of the same applies: in-stream HIP events (on the kernels' own stream) around K2 /
+    # K3 / their GEMM kernels / the all-reduce of every step.  Eight events per apply stretch a step by a few per cent, which
+    # is why they are not in the region that sets `value`; the per-kernel times below belong to THESE steps
+    # (ms_per_step_instrumented), and the kernel's duration in event-free steps comes from the kernel trace further down.
+    steps_i = max(4, args.steps // 4)
+    ctx.profile_begin(steps_i, sample_every=1)
+    t0i = time.perf_counter()
+    for _ in range(steps_i):
+        ctx.apply_xxt_dev(B.data_ptr(), b, Y.data_ptr())
+    ctx.synchronize()
+    barrier()
+    elapsed_i = time.perf_counter() - t0i
+    prof = ctx.profile_end(b)
 
     # SNPs all ranks processed per step (the shard workloads process one shard; their divisor is the full matrix's)
     P_done = P_rank * world if w["scaling"] == "weak" else P_total
@@ -366,7 +418,11 @@ def main():
                         peak_measured_pure_mfma_stream=mfma_stream_peak(11))  # random operands; power-limited (measured in this run)
         del roofline["flops_per_launch"]
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
-    roofline["hip_events_on_steps"] = "%d of %d (every %d%s step of the timed region)" % (prof["nsteps"], args.steps, stride, "th" if stride > 3 else "")
+    roofline["duration_source"] = "HIP events around the launch in the instrumented steps"
+    roofline["ms_dominant_kernel"] = ms_dom
+    roofline["ms_per_step_instrumented"] = elapsed_i / steps_i * 1e3
+    roofline["hip_events_on_steps"] = ("%d instrumented steps run right after the %d timed ones (the timed region carries no events); ms_xt_b / ms_x_t / "
+                                       "ms_gemm_kernel_* are averages over the instrumented steps" % (prof["nsteps"], args.steps))
     if args.accum == "fp64":
         roofline["peak_measured_pure_mfma_stream"] = mfma_stream_peak(0)  # v_mfma_f64 stream, 2 waves/SIMD (measured in this run)
     # HBM traffic per launch of the dominant kernel: hardware counters serialise the kernels, so they cannot be read inside
@@ -384,22 +440,35 @@ def main():
         mode = "measure" if (world == 1 and shutil.which("rocprofv3") and args.accum in ("i8", "fp64") and not under_profiler) else "replay"
     if mode == "measure" and world == 1:
         try:
-            roofline["traffic"], ms_alone = measure_traffic(args, dom)
+            cnt = measure_counters(args, dom)
+            roofline["traffic"] = cnt["traffic"]
             roofline["traffic_measured_in_this_run"] = True
-            if ms_alone:
-                # beside `frac` (HIP events inside the timed region, where the sparse gathers of the same stage run on the
-                # low-priority stream UNDER the GEMM and stretch it): the same kernel with the chip to itself
-                per_launch = roofline.get("ops_per_launch", roofline.get("flops_per_launch"))
-                roofline["kernel_alone"] = dict(ms=ms_alone, achieved=per_launch / (ms_alone * 1e-3) / 1e12,
-                                                frac=per_launch / (ms_alone * 1e-3) / 1e12 / roofline["peak"],
-                                                source="durations of the same launches in the two counter child runs (counters serialise the kernels)")
+            per_launch = roofline.get("ops_per_launch", roofline.get("flops_per_launch"))
+            if cnt.get("ms_trace"):
+                # THE figure: the kernel's own duration in event-free steps (rocprofv3 --kernel-trace of this command line with
+                # block applies only: the trace reads the dispatch timestamps, nothing is serialised, the gathers of the same stage
+                # run beside the kernel exactly as in the timed region)
+                roofline["ms_dominant_kernel_instrumented_steps"] = ms_dom
+                roofline["achieved_instrumented_steps"] = roofline["achieved"]
+                roofline["ms_dominant_kernel"] = cnt["ms_trace"]
+                roofline["achieved"] = per_launch / (cnt["ms_trace"] * 1e-3) / 1e12
+                roofline["frac"] = roofline["achieved"] / roofline["peak"]
+                roofline["duration_source"] = ("rocprofv3 --kernel-trace of a child run of this bench (event-free block applies, last %d launches of the "
+                                               "dominant kernel); *_instrumented_steps: HIP events in this process" % cnt["trace_launches"])
+            if cnt.get("ms_alone"):
+                # secondary: the same kernel with the chip to itself (in the counter runs the kernels are serialised, so the
+                # sparse gathers that normally run on the low-priority stream UNDER the GEMM do not)
+                roofline["kernel_alone"] = dict(ms=cnt["ms_alone"], achieved=per_launch / (cnt["ms_alone"] * 1e-3) / 1e12,
+                                                frac=per_launch / (cnt["ms_alone"] * 1e-3) / 1e12 / roofline["peak"],
+                                                source="durations of the same launches in the two HBM-counter child runs (counters serialise the kernels)")
+            roofline["why"] = cnt.get("why")
             roofline["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child runs of this bench, 2 block applies "
                                           "each, right after the timed region): FETCH_SIZE x2 + WRITE_SIZE per launch of the dominant kernel")
         except Exception as e:  # no rocprofv3, counters busy, time-out: fall back to the committed passes
-            print("traffic measurement failed (%s); replaying profiles/" % e, file=sys.stderr)
+            print("counter measurement failed (%s); replaying profiles/" % e, file=sys.stderr)
             mode = "replay"
     if mode == "replay":
-        for rnd in ("r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             try:
                 if world == 1 and args.accum == "i8":
                     fn = "profiles/%s_pmc_summary_i8.json" % rnd
@@ -428,6 +497,37 @@ def main():
                            iters_per_step=b, generate_s=round(t_gen, 3)),
                roofline=roofline)
 
+    # ---- several ranks: the line validates itself ---------------------------------------------------------------------------
+    # Rank 0 additionally holds the WHOLE matrix in one context without a communicator (12.5 GB at the headline size) and applies
+    # it to the same block: multi_rank_parity = max |Y_N - Y_1| / max |Y_1| (Y_N: what the N ranks' shards + the all-reduce of
+    # the timed region produced; the shards of svdwide.cpp:48-62 summed in another order: ~1e-15).  The eigenvalues of the
+    # multi-rank solves (row-sharded solver, and the replicated one) are compared with the one-context solve of the same matrix
+    # further down.  A line that is fast and wrong says so: multi_rank_validation.passed = false.
+    whole = None
+    if world > 1 and not args.no_validate:
+        val = dict(passed=None)
+        par = torch.zeros(1, dtype=torch.float64, device="cuda")
+        if rank == 0:
+            whole = fp.Context.synthetic(N, P_done, snp_begin=0, n_pop=min(2 * k, 64), device=local_rank, accum=args.accum)
+            whole.set_total_snps(P_total)
+            Y1 = torch.zeros_like(Y)
+            whole.apply_xxt_dev(B.data_ptr(), b, Y1.data_ptr())
+            whole.synchronize()
+            par[0] = float((torch.max(torch.abs(Y - Y1)) / torch.max(torch.abs(Y1))).item())
+            del Y1
+        barrier()
+        dist.broadcast(par, src=0)
+        # every rank must hold the same all-reduced block: the largest deviation of any rank's Y from rank 0's
+        Y0 = Y.clone()
+        dist.broadcast(Y0, src=0)
+        dev = torch.max(torch.abs(Y - Y0)).reshape(1) / torch.max(torch.abs(Y0)).clamp_min(1e-300)
+        dist.all_reduce(dev, op=dist.ReduceOp.MAX)
+        del Y0
+        val["multi_rank_parity"] = float(par.item())
+        val["max_deviation_between_ranks"] = float(dev.item())
+        val["operator_ok"] = bool(val["multi_rank_parity"] < 1e-11 and val["max_deviation_between_ranks"] == 0.0)
+        out["multi_rank_validation"] = val
+
     # ---- side measurements of the same operator, each a bounded number of block applies -----------------------------------
     def side_apply(c, bw, steps_s):
         """steps_s timed block applies of width bw on context c (random block, warm): wall, cells/s, GEMM kernel times, roofline"""
@@ -438,7 +538,7 @@ def main():
             c.apply_xxt_dev(Bs.data_ptr(), bw, Ys.data_ptr())
         c.synchronize()
         barrier()
-        c.profile_begin(steps_s, sample_every=stride if steps_s >= 8 else 1)
+        c.profile_begin(steps_s, sample_every=4 if steps_s >= 8 else 1)  # (side blocks: events on every 4th step)
         t1 = time.perf_counter()
         for _ in range(steps_s):
             c.apply_xxt_dev(Bs.data_ptr(), bw, Ys.data_ptr())
@@ -526,9 +626,45 @@ def main():
                           wall_minus_apply_s=wall - info["seconds_apply"],
                           eigenvalue_1=float(r["d"][0]), eigenvalue_k=float(r["d"][-1]),
                           max_rel_residual=info["max_residual"])
+        out["pca"].update(cheap_applies=info["cheap_applies"], cheap_slices=info["cheap_slices"], seconds_apply_exact=info["seconds_exact"])
         if world > 1:
             out["pca"]["solver"] = "row-sharded (all-gather -> K2, K3 -> reduce-scatter per apply; every rank orthogonalises N / %d rows)" % world
             out["pca"]["collectives"] = dict(zip(("calls", "bytes"), ctx.collective_stats()))
+            if not args.no_validate:
+                # the same solve with round 2's replicated solver (one all-reduce per apply, every rank keeps the whole basis), and
+                # on rank 0 alone with the whole matrix in one context: three routes to the same eigenvalues
+                import numpy as np
+
+                barrier()
+                t1 = time.perf_counter()
+                rr = ctx.pca(ndim=k, allow_unconverged=True, replicated_solver=True)
+                ctx.synchronize()
+                barrier()
+                wall_r = time.perf_counter() - t1
+                dd = torch.zeros(3, dtype=torch.float64, device="cuda")
+                if rank == 0:
+                    r1 = whole.pca(ndim=k, allow_unconverged=True)
+                    t1 = time.perf_counter()
+                    r1 = whole.pca(ndim=k, allow_unconverged=True)
+                    whole.synchronize()
+                    wall_1 = time.perf_counter() - t1
+                    dd[0] = float(np.max(np.abs(r["d"] - r1["d"]) / r1["d"]))
+                    dd[1] = float(np.max(np.abs(rr["d"] - r1["d"]) / r1["d"]))
+                    # eigenvectors up to sign: |u_N . u_1| of the first and the k-th
+                    dd[2] = float(min(abs(float(r["U"][:, j] @ r1["U"][:, j])) for j in (0, k - 1)))
+                    val.update(one_context_pca_wall_s=wall_1, one_context_block_applies=r1["info"]["block_applies"])
+                    del r1
+                barrier()
+                dist.broadcast(dd, src=0)
+                val.update(eigenvalues_rowsharded_vs_one_context=float(dd[0].item()), eigenvalues_replicated_vs_one_context=float(dd[1].item()),
+                           eigenvector_alignment_min=float(dd[2].item()), replicated_solver_wall_s=wall_r,
+                           replicated_solver_block_applies=rr["info"]["block_applies"])
+                val["solver_ok"] = bool(dd[0].item() < 1e-9 and dd[1].item() < 1e-9 and dd[2].item() > 1 - 1e-6 and info["converged"])
+                del rr
+        if world > 1 and not args.no_validate:
+            val["passed"] = bool(val.get("operator_ok") and val.get("solver_ok", True))
+            if not val["passed"] and rank == 0:
+                print("MULTI-RANK VALIDATION FAILED: %s" % json.dumps(val), file=sys.stderr, flush=True)
     if watchdog is not None:
         watchdog.cancel()
 
@@ -561,7 +697,7 @@ def main():
             for _ in range(max(2, args.warmup)):
                 c2.apply_xxt_dev(B.data_ptr(), b, Y2.data_ptr())
             c2.synchronize()
-            c2.profile_begin(steps_alt, sample_every=stride if steps_alt >= 8 else 1)
+            c2.profile_begin(steps_alt, sample_every=4 if steps_alt >= 8 else 1)
             t1 = time.perf_counter()
             for _ in range(steps_alt):
                 c2.apply_xxt_dev(B.data_ptr(), b, Y2.data_ptr())
@@ -704,6 +840,8 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+    if whole is not None:
+        whole.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -258,7 +258,10 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    // Ritz blocks, those go through the EXACT operator one by one (rebuilding T = Y'AY from nothing), and the rule is judged
    // on the exact residuals || (I - YY') A Y s ||.  If it fails there, the iteration goes on from that state -- with cheap
    // passes towards a tighter threshold first, exact passes only after the third failure.
-   const bool can_cheap = o.mixed && be.set_cheap(true);
+   // (the blocks waiting after a verification need room: N dimensions hold fit + 1 blocks, and a restart in that phase keeps
+   //  up to nkv Ritz blocks + nkv waiting ones; tiny problems simply stay exact)
+   const int Mmax = fit + 1, nkv_max = std::max(2, nk_wide);
+   const bool can_cheap = o.mixed && Mmax >= 2 * nkv_max + 3 && be.set_cheap(true);
    if (can_cheap) be.set_cheap(false);
    bool cheap = false;        // mode of the passes being made
    bool tainted = false;      // T holds columns from cheap passes: convergence cannot be declared from it
@@ -458,7 +461,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       // orders of magnitude per block apply at best): it is skipped for a step (two when six orders away).  Convergence is
       // only ever declared by an actual test, so the worst case is one block apply more than strictly needed.
       if (n < k && skip_rr == 0) skip_rr = 1; // fewer basis columns than wanted pairs: nothing to test yet
-      if (skip_rr > 0 && res.block_applies < o.max_applies && na + 1 <= mcap) {
+      if (skip_rr > 0 && res.block_applies < o.max_applies && na + 1 <= mcap && Mn + 1 <= Mmax) {
          skip_rr--;
          host_s += since(t0);
          phase(PH_RR);
@@ -509,7 +512,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       }
       res.max_rel_residual = worst;
       const bool out_of_budget = res.block_applies >= o.max_applies;
-      const bool full = na + 1 > mcap;
+      const bool full = na + 1 > mcap || Mn + 1 > Mmax; // the applied part has reached its cap, or the next block would not fit in N dimensions
       // Cheap passes that stop making progress have reached their noise floor (an operand rounded too coarsely for this
       // spectrum): no 5 % gain of the worst residual over two basis lengths of passes ends them for good -- the iteration
       // continues from the current Ritz vectors with exact passes, as after a verification.
