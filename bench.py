@@ -124,7 +124,7 @@ def measure_counters(args, dom):
             rows = _dominant_rows(_child(args, ["--kernel-trace", "--pmc"] + sq, 2, tmp), args, dom)
         mean = lambda c: (lambda v: sum(v) / len(v) if v else None)([float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == c])
         dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp")]
-        g, busy, im, iv, lc, la = (mean(c) for c in sq)
+        busy, g, im, iv, lc, la = (mean(c) for c in sq)
         why = {}
         if g and dur:
             why["clock_ghz"] = g / 8 / (sum(dur) / len(dur))  # GRBM_GUI_ACTIVE sums the 8 XCDs
@@ -315,8 +315,22 @@ def main():
                 torch.cuda.synchronize()
                 return 0
 
+            def allgather(snd, rcv, count, stream):
+                ctx.synchronize()
+                dist.all_gather_into_tensor(torch.as_tensor(_Arr(rcv, count * world), device="cuda"), torch.as_tensor(_Arr(snd, count), device="cuda"))
+                torch.cuda.synchronize()
+                return 0
+
+            def reducescatter(snd, rcv, count, stream):
+                ctx.synchronize()
+                dist.reduce_scatter_tensor(torch.as_tensor(_Arr(rcv, count), device="cuda"), torch.as_tensor(_Arr(snd, count * world), device="cuda"))
+                torch.cuda.synchronize()
+                return 0
+
             ctx.set_allreduce(allreduce)
             ctx.set_rank(world, rank)  # (lets fpca_pca row-shard the solver over this transport too)
+            if backend == "nccl":
+                ctx.set_collectives(allgather, reducescatter)  # ... with the call sequence of the native path
 
     rows = ctx.block_rows()
     g = torch.Generator(device="cuda")

@@ -25,6 +25,7 @@ DIVISOR = {"none": 0, "n1": 1, "p": 2}
 UNIQUE_ID_BYTES = 128
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)  # all-gather / reduce-scatter
 
 
 class PcaOpts(C.Structure):
@@ -45,6 +46,11 @@ class PcaOpts(C.Structure):
         ("mixed", C.c_int),
         ("cheap_slices", C.c_int),
     ]
+
+
+class SynthModel(C.Structure):
+    _fields_ = [("n_pop", C.c_int), ("fst", C.c_double), ("missing_rate", C.c_double), ("maf_model", C.c_int), ("missing_model", C.c_int),
+                ("conc_frac", C.c_double)]
 
 
 class PcaInfo(C.Structure):
@@ -93,6 +99,7 @@ SIGNATURES = {
     "fpca_create": (_I, [C.POINTER(_P), _P, _U64, _U64, _I, _I, _I]),
     "fpca_create_from_bed": (_I, [C.POINTER(_P), C.c_char_p, _U64, _U64, _U64, _I, _I, _I, C.POINTER(_U64)]),
     "fpca_create_synthetic": (_I, [C.POINTER(_P), _U64, _U64, _U64, _U64, _I, _D, _D, _I, _I, _I]),
+    "fpca_create_synthetic_model": (_I, [C.POINTER(_P), _U64, _U64, _U64, _U64, C.POINTER(SynthModel), _I, _I, _I]),
     "fpca_create_dense": (_I, [C.POINTER(_P), _P, C.c_int64, _U64, _U64, _I, _I]),
     "fpca_destroy": (None, [_P]),
     "fpca_nsamples": (_U64, [_P]),
@@ -113,6 +120,7 @@ SIGNATURES = {
     "fpca_comm_unique_id": (_I, [_P]),
     "fpca_comm_init_rank": (_I, [_P, _I, _I, _P]),
     "fpca_set_allreduce": (_I, [_P, ALLREDUCE_FN, _P]),
+    "fpca_set_collectives": (_I, [_P, COLLECTIVE_FN, COLLECTIVE_FN, _P]),
     "fpca_set_total_snps": (_I, [_P, _U64]),
     "fpca_set_rank": (_I, [_P, _I, _I]),
     "fpca_collective_stats": (_I, [_P, C.POINTER(_U64), C.POINTER(_U64)]),

@@ -83,10 +83,13 @@ class Context:
 
     @classmethod
     def synthetic(cls, N, P, snp_begin=0, seed=20260928, n_pop=40, fst=0.05, missing_rate=0.001, stand="binom2", device=0,
-                  accum="fp64"):
+                  accum="fp64", realistic=False, maf_model=None, missing_model=None, conc_frac=0.05):
+        """realistic=True: the round-4 profile (synth.hpp) -- rare-variant allele-frequency spectrum, missing calls concentrated in
+        5 % of the SNPs (maf_model / missing_model = 1; either can be chosen alone)."""
         h = C.c_void_p()
-        check(lib().fpca_create_synthetic(C.byref(h), N, snp_begin, P, seed, n_pop, fst, missing_rate, STANDARDISE[stand],
-                                          device, ACCUM[accum]))
+        m = _lib.SynthModel(n_pop, fst, missing_rate, int(realistic if maf_model is None else maf_model),
+                            int(realistic if missing_model is None else missing_model), conc_frac)
+        check(lib().fpca_create_synthetic_model(C.byref(h), N, snp_begin, P, seed, C.byref(m), STANDARDISE[stand], device, ACCUM[accum]))
         return cls(h)
 
     def close(self):
@@ -151,6 +154,15 @@ class Context:
         cb = _lib.ALLREDUCE_FN(lambda user, ptr, count, stream: int(pyfunc(ptr, count, stream) or 0))
         self._keep.append(cb)
         check(lib().fpca_set_allreduce(self.h, cb, None))
+
+    def set_collectives(self, allgather, reducescatter):
+        """allgather(send_ptr, recv_ptr, count_per_rank, stream) / reducescatter(send_ptr, recv_ptr, count_per_rank, stream) -> 0:
+        fp64 collectives on raw device pointers beside set_allreduce (fpca_set_collectives); the row-sharded solver then issues
+        the call sequence it issues over RCCL."""
+        ag = _lib.COLLECTIVE_FN(lambda user, snd, rcv, count, stream: int(allgather(snd, rcv, count, stream) or 0))
+        rs = _lib.COLLECTIVE_FN(lambda user, snd, rcv, count, stream: int(reducescatter(snd, rcv, count, stream) or 0))
+        self._keep += [ag, rs]
+        check(lib().fpca_set_collectives(self.h, ag, rs, None))
 
     def set_rank(self, nranks, rank):
         """rank / size beside a caller-supplied all-reduce: lets fpca_pca row-shard the solver (fpca_set_rank)."""

@@ -245,6 +245,7 @@ struct Multi {
    double *slots = nullptr;                // FPCA_CLI_TEST_TRANSPORT=shm only: G x slot_cap doubles
    size_t slot_cap = 0;
    bool test_transport = false;
+   bool test_collectives = false; // ... with all-gather / reduce-scatter of its own (shm2)
 };
 
 // set in the children of a --gpus run: an exception there must not fall through to rank 0's output code
@@ -376,6 +377,34 @@ int shm_allreduce(void *user, double *dbuf, uint64_t count, void *stream)
    }
    if (!multi_barrier(m)) return -1; // nobody overwrites a slot before everyone has read it
    return hipMemcpy(dbuf, sum.data(), count * sizeof(double), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+// FPCA_CLI_TEST_TRANSPORT=shm2: all-gather and reduce-scatter of their own as well (fpca_set_collectives), so that the
+// row-sharded solver runs the call sequence it runs over RCCL -- per row chunk, on the communication stream -- on one device
+int shm_allgather(void *user, const double *send, double *recv, uint64_t count, void *stream)
+{
+   Multi &m = *static_cast<Multi *>(user);
+   if (count > m.slot_cap) return -1;
+   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+   if (hipMemcpy(m.slots + (size_t)m.rank * m.slot_cap, send, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+   if (!multi_barrier(m)) return -1;
+   for (int r = 0; r < m.ngpus; r++)
+      if (hipMemcpy(recv + (size_t)r * count, m.slots + (size_t)r * m.slot_cap, count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return -1;
+   return multi_barrier(m) ? 0 : -1;
+}
+int shm_reducescatter(void *user, const double *send, double *recv, uint64_t count, void *stream)
+{
+   Multi &m = *static_cast<Multi *>(user);
+   if (count * (uint64_t)m.ngpus > m.slot_cap) return -1;
+   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+   if (hipMemcpy(m.slots + (size_t)m.rank * m.slot_cap, send, count * m.ngpus * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+   if (!multi_barrier(m)) return -1;
+   std::vector<double> sum(count, 0.0);
+   for (int r = 0; r < m.ngpus; r++) {
+      const double *p = m.slots + (size_t)r * m.slot_cap + (size_t)m.rank * count;
+      for (uint64_t i = 0; i < count; i++) sum[i] += p[i];
+   }
+   if (!multi_barrier(m)) return -1;
+   return hipMemcpy(recv, sum.data(), count * sizeof(double), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -697,7 +726,8 @@ int main(int argc, char *argv[])
          const uint64_t P_file = (uint64_t)st.st_size > 3 ? ((uint64_t)st.st_size - 3) / np : 0; // data.cpp:165-170
          if (P_file < (uint64_t)ngpus) throw std::runtime_error("fewer SNPs than GPUs");
          const char *tt = FPCA_TEST_ENV("FPCA_CLI_TEST_TRANSPORT");
-         mg.test_transport = tt && std::string(tt) == "shm";
+         mg.test_transport = tt && (std::string(tt) == "shm" || std::string(tt) == "shm2");
+         mg.test_collectives = tt && std::string(tt) == "shm2";
          if (mg.test_transport)
             std::cerr << "[fpca-cli] FPCA_CLI_TEST_TRANSPORT=shm: all ranks share one device and exchange through host memory -- a test "
                          "hook for one-GPU boxes, not a way to run" << std::endl;
@@ -824,6 +854,7 @@ int main(int argc, char *argv[])
             }
             if (fpca_set_allreduce(ctx, shm_allreduce, &mg) != FPCA_OK || fpca_set_rank(ctx, ngpus, mg.rank) != FPCA_OK)
                multi_fail(mg, fpca_last_error());
+            if (mg.test_collectives && fpca_set_collectives(ctx, shm_allgather, shm_reducescatter, &mg) != FPCA_OK) multi_fail(mg, fpca_last_error());
          } else
 #endif
          {

@@ -165,11 +165,18 @@ struct fpca_ctx {
    hipEvent_t ev_chunk[4] = {nullptr, nullptr, nullptr, nullptr}, ev_comm_done = nullptr;
    fpca_allreduce_fn ar_fn = nullptr;
    void *ar_user = nullptr;
+   fpca_allgather_fn ag_fn = nullptr; // caller-supplied all-gather / reduce-scatter (fpca_set_collectives): the row-sharded
+   fpca_reducescatter_fn rs_fn = nullptr; // solver then runs exactly the call sequence it runs over RCCL
+   void *coll_user = nullptr;
+   // the transport has real all-gather / reduce-scatter (RCCL, or the caller's): the chunked, overlapped exchange of the
+   // row-sharded solver; otherwise both are built from the caller's sum
+   bool native_collectives() const { return (comm && !ar_fn) || (ar_fn && ag_fn && rs_fn); }
    bool rank_known = false; // nranks / rank are meaningful (fpca_comm_init_rank, or fpca_set_rank beside a caller's all-reduce)
    // row-sharded solver (backend.hpp RowShard): whole [full_rows][b] blocks either side of the operator
    double *d_full_in = nullptr, *d_full_out = nullptr;
    size_t full_in_cap = 0, full_out_cap = 0;
    uint64_t coll_calls = 0, coll_bytes = 0; // data-path collectives issued by this context (calls, payload bytes)
+   long exchange_tested = -1; // layout (ranks, chunks, width) whose all-gather / reduce-scatter have passed the self-test
    // live profiling (fpca_profile_begin/end)
    std::vector<hipEvent_t> prof_ev;
    int prof_used = 0, prof_calls = 0, prof_stride = 1; // every prof_stride-th apply carries the events
@@ -189,9 +196,12 @@ struct fpca_ctx {
    void all_gather(const RowShard &sh, const double *slice, double *full, int b, hipStream_t s)
    {
       const size_t piece = (size_t)sh.plen * b, chunk = (size_t)sh.L * b;
-      if (comm && !ar_fn) {
+      if (native_collectives()) {
          for (int c = 0; c < sh.nch; c++) {
-            RCCL_CHECK(rccl().AllGather(slice + c * piece, full + c * chunk, piece, ncclDouble, comm, s));
+            if (ag_fn) {
+               if (ag_fn(coll_user, slice + c * piece, full + c * chunk, piece, (void *)s) != 0) throw Error(FPCA_ECOMM, "caller-supplied all-gather failed");
+            } else
+               RCCL_CHECK(rccl().AllGather(slice + c * piece, full + c * chunk, piece, ncclDouble, comm, s));
             coll_calls++;
             coll_bytes += piece * sizeof(double);
          }
@@ -207,10 +217,13 @@ struct fpca_ctx {
    void reduce_scatter(const RowShard &sh, double *full, double *slice, int b, hipStream_t s, int only_chunk = -1)
    {
       const size_t piece = (size_t)sh.plen * b, chunk = (size_t)sh.L * b;
-      if (comm && !ar_fn) {
+      if (native_collectives()) {
          for (int c = 0; c < sh.nch; c++) {
             if (only_chunk >= 0 && c != only_chunk) continue;
-            RCCL_CHECK(rccl().ReduceScatter(full + c * chunk, slice + c * piece, piece, ncclDouble, ncclSum, comm, s));
+            if (rs_fn) {
+               if (rs_fn(coll_user, full + c * chunk, slice + c * piece, piece, (void *)s) != 0) throw Error(FPCA_ECOMM, "caller-supplied reduce-scatter failed");
+            } else
+               RCCL_CHECK(rccl().ReduceScatter(full + c * chunk, slice + c * piece, piece, ncclDouble, ncclSum, comm, s));
             coll_calls++;
             coll_bytes += piece * sizeof(double);
          }
@@ -382,6 +395,7 @@ constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_ZERO = 1920, I8W_MAXB = 
 
 void ensure_i8_alloc(fpca_ctx *c, int b);
 uint64_t ar_chunk_begin(const fpca_ctx *c, int nchunks, int i);
+int shard_chunks(const fpca_ctx *c);
 
 // true: the int8 path is ready for blocks of width b.  false (FPCA_ACCUM_AUTO only): its extra buffers did not fit, the
 // context has been switched to the fp64 kernels for good.
@@ -649,6 +663,17 @@ int ar_chunks(const fpca_ctx *c)
    while (n > 1 && c->N_pad / n < 512) n--;
    return n;
 }
+// row chunks of the row-sharded solver's exchange (all-gather -> K2, K3 chunk by chunk -> reduce-scatter of chunk i under
+// the computation of chunk i + 1): the same rule, for every transport that has real all-gather / reduce-scatter
+int shard_chunks(const fpca_ctx *c)
+{
+   if (!c->native_collectives() || !c->comm_stream) return 1;
+   const char *env = FPCA_TEST_ENV("FPCA_AR_CHUNKS");
+   int n = c->N_pad >= 400000 ? 4 : c->N_pad >= 200000 ? 2 : 1;
+   if (env && atoi(env) >= 1) n = std::min(atoi(env), 4);
+   while (n > 1 && c->N_pad / n < 512) n--;
+   return n;
+}
 uint64_t ar_chunk_begin(const fpca_ctx *c, int nchunks, int i) // multiples of 512 rows
 {
    const uint64_t per = round_up((c->N_pad + nchunks - 1) / nchunks, 512);
@@ -779,7 +804,7 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
 void apply_sharded(fpca_ctx *c, const RowShard &sh, const double *in_slice, int b, double *out_slice, hipStream_t s)
 {
    c->all_gather(sh, in_slice, c->d_full_in, b, s);
-   if (sh.nch > 1 && c->comm && !c->ar_fn && c->comm_stream) {
+   if (sh.nch > 1 && c->native_collectives() && c->comm_stream) {
       ensure_stats(c);
       if (c->i8_S && ensure_i8(c, b)) {
          c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
@@ -787,6 +812,10 @@ void apply_sharded(fpca_ctx *c, const RowShard &sh, const double *in_slice, int 
          xt_i8(c, c->d_full_in, b, s, true);
          for (int i = 0; i < sh.nch; i++) {
             const uint64_t r0 = std::min<uint64_t>((uint64_t)i * sh.L, c->N_pad), r1 = std::min<uint64_t>((uint64_t)(i + 1) * sh.L, c->N_pad);
+            if (r1 <= r0 && i > 0) { // a chunk wholly behind the last row (the same on every rank): no K3, no collective, zeros out
+               HIP_CHECK(hipMemsetAsync(out_slice + (size_t)i * sh.plen * b, 0, (size_t)sh.plen * b * sizeof(double), s));
+               continue;
+            }
             x_i8(c, b, c->d_full_out, s, true, i == 0, r0, r1); // (rows >= N_pad of d_full_out stay zero: nothing writes them)
             HIP_CHECK(hipEventRecord(c->ev_chunk[i], s));
             HIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_chunk[i], 0));
@@ -944,7 +973,7 @@ class HipBackend : public BlockBackend {
          const int G = (c->multi() && c->rank_known) ? c->nranks : 1;
          // (chunk count from N and the communicator only -- NOT from the arithmetic in effect: a rank whose int8 buffers did
          //  not fit runs the fp64 kernels but must issue the same sequence of collectives as the others)
-         const int nch = (c->comm && !c->ar_fn && c->comm_stream) ? ar_chunks(c) : 1;
+         const int nch = shard_chunks(c);
          sh_ = RowShard::make(c->N_pad, G, (c->multi() && c->rank_known) ? c->rank : 0, nch, 512);
          rows_ = sh_.slice_rows();
          const size_t need = (size_t)sh_.full_rows() * b;
@@ -956,6 +985,7 @@ class HipBackend : public BlockBackend {
          HIP_CHECK(hipMemsetAsync(c->d_full_in, 0, c->full_in_cap * sizeof(double), c->stream));
          HIP_CHECK(hipMemsetAsync(c->d_full_out, 0, c->full_out_cap * sizeof(double), c->stream));
       }
+      if (sharded() && sh_.G > 1) exchange_selftest();
       if (!d_ptrs_) HIP_CHECK(hipMalloc(&d_ptrs_, 1024 * sizeof(double *)));
       HIP_CHECK(hipEventCreate(&e0_));
       HIP_CHECK(hipEventCreate(&e1_));
@@ -971,6 +1001,69 @@ class HipBackend : public BlockBackend {
       (void)hipEventDestroy(ev_pin_);
       (void)hipEventDestroy(e0_);
       (void)hipEventDestroy(e1_);
+   }
+   // Once per context and layout (ranks, chunks, width): the all-gather and the reduce-scatter of the row-sharded solver, as
+   // apply_sharded issues them, on a block whose every entry is known -- the rows a rank keeps of the random block with seed
+   // 4711 go out, the whole block must come back (all-gather), and nranks times a rank's own rows out of the whole block on
+   // every rank (reduce-scatter, chunk by chunk on the communication stream).  A wrong chunk / piece offset or a collective
+   // that pairs the wrong buffers ends the solve here with FPCA_ECOMM instead of returning plausible-looking eigenvectors.
+   void exchange_selftest()
+   {
+      const long key = ((long)sh_.G * 8 + sh_.nch) * 128 + b_;
+      if (c_->exchange_tested == key) return;
+      hipStream_t s = c_->stream;
+      const uint64_t calls0 = c_->coll_calls, bytes0 = c_->coll_bytes; // (fpca_collective_stats counts the solver's data path only)
+      double *slice = nullptr, *ref = nullptr;
+      const size_t nslice = (size_t)sh_.slice_rows() * b_, nfull = (size_t)sh_.full_rows() * b_;
+      HIP_CHECK(hipMalloc(&slice, nslice * sizeof(double)));
+      HIP_CHECK(hipMalloc(&ref, nfull * sizeof(double)));
+      auto finish = [&] {
+         (void)hipFree(slice);
+         (void)hipFree(ref);
+      };
+      try {
+         unsigned long long *bits = reinterpret_cast<unsigned long long *>(c_->d_small + 64);
+         HIP_CHECK(hipMemsetAsync(bits, 0, 2 * sizeof(unsigned long long), s));
+         for (int c = 0; c < sh_.nch; c++)
+            kern::fill_random(slice + (size_t)c * sh_.plen * b_, c_->N, sh_.plen, b_, 4711, s, (uint64_t)c * sh_.L + (uint64_t)sh_.rank * sh_.plen);
+         kern::fill_random(ref, c_->N, sh_.full_rows(), b_, 4711, s, 0);
+         c_->all_gather(sh_, slice, c_->d_full_in, b_, s);
+         kern::max_abs_diff(c_->d_full_in, ref, 1.0, nfull, bits, s);
+         // reduce-scatter of the whole block (identical on every rank): every rank must get G x its own rows
+         HIP_CHECK(hipMemsetAsync(slice, 0xff, nslice * sizeof(double), s)); // NaNs: rows nobody writes would show
+         if (sh_.nch > 1 && c_->native_collectives() && c_->comm_stream) {
+            for (int i = 0; i < sh_.nch; i++) {
+               HIP_CHECK(hipEventRecord(c_->ev_chunk[i], s));
+               HIP_CHECK(hipStreamWaitEvent(c_->comm_stream, c_->ev_chunk[i], 0));
+               c_->reduce_scatter(sh_, ref, slice, b_, c_->comm_stream, i);
+            }
+            HIP_CHECK(hipEventRecord(c_->ev_comm_done, c_->comm_stream));
+            HIP_CHECK(hipStreamWaitEvent(s, c_->ev_comm_done, 0));
+         } else {
+            HIP_CHECK(hipMemcpyAsync(c_->d_full_out, ref, nfull * sizeof(double), hipMemcpyDeviceToDevice, s)); // (the sum-only route works in place)
+            c_->reduce_scatter(sh_, c_->d_full_out, slice, b_, s);
+            HIP_CHECK(hipMemsetAsync(c_->d_full_out, 0, nfull * sizeof(double), s));
+         }
+         for (int c = 0; c < sh_.nch; c++)
+            kern::max_abs_diff(slice + (size_t)c * sh_.plen * b_, ref + ((size_t)c * sh_.L + (size_t)sh_.rank * sh_.plen) * b_, (double)sh_.G,
+                               (size_t)sh_.plen * b_, bits + 1, s);
+         HIP_CHECK(hipMemsetAsync(c_->d_full_in, 0, nfull * sizeof(double), s));
+         double err[2] = {0, 0};
+         HIP_CHECK(hipMemcpyAsync(err, bits, sizeof(err), hipMemcpyDeviceToHost, s));
+         HIP_CHECK(hipStreamSynchronize(s));
+         // (entries are uniform in (-0.5, 0.5): the gathered block must be bit-equal, the sums of G equal terms within rounding)
+         if (err[0] != 0.0 || !(err[1] <= 1e-14 * sh_.G))
+            throw Error(FPCA_ECOMM, "self-test of the multi-rank exchange failed on rank " + std::to_string(sh_.rank) + " of " + std::to_string(sh_.G) + " (" +
+                                        std::to_string(sh_.nch) + " row chunks): all-gather error " + std::to_string(err[0]) + ", reduce-scatter error " +
+                                        std::to_string(err[1]));
+      } catch (...) {
+         finish();
+         throw;
+      }
+      finish();
+      c_->coll_calls = calls0;
+      c_->coll_bytes = bytes0;
+      c_->exchange_tested = key;
    }
    uint64_t nrows() const override { return c_->N; }
    int width() const override { return b_; }
@@ -1364,16 +1457,33 @@ int fpca_create_from_bed(fpca_ctx **out, const char *bed_path, uint64_t N, uint6
 int fpca_create_synthetic(fpca_ctx **out, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed, int n_pop,
                           double fst, double missing_rate, int stand_method, int device, int accum)
 {
+   fpca_synth_model m;
+   std::memset(&m, 0, sizeof(m));
+   m.n_pop = n_pop;
+   m.fst = fst;
+   m.missing_rate = missing_rate;
+   return fpca_create_synthetic_model(out, N, snp_begin, P_g, seed, &m, stand_method, device, accum);
+}
+
+int fpca_create_synthetic_model(fpca_ctx **out, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed, const fpca_synth_model *model,
+                                int stand_method, int device, int accum)
+{
    if (!out) return FPCA_EINVAL;
    *out = nullptr;
    fpca_ctx *c = new fpca_ctx();
    int rc = guarded([&] {
+      if (!model) throw Error(FPCA_EINVAL, "model is NULL");
+      const int n_pop = model->n_pop;
+      const double fst = model->fst, missing_rate = model->missing_rate;
       if (n_pop < 1 || n_pop > synth::MAX_POP) throw Error(FPCA_EINVAL, "n_pop must be in 1..64");
       if (!(fst >= 0 && fst < 1) || !(missing_rate >= 0 && missing_rate < 1)) throw Error(FPCA_EINVAL, "fst / missing_rate out of range");
+      if ((model->maf_model | 1) != 1 || (model->missing_model | 1) != 1 || !(model->conc_frac >= 0 && model->conc_frac <= 1))
+         throw Error(FPCA_EINVAL, "maf_model / missing_model must be 0 or 1, conc_frac in [0, 1]");
       ctx_alloc_common(c, N, P_g, stand_method, device, accum);
       const uint32_t fst_fp = (uint32_t)std::llround(fst * 65536.0);
       const uint32_t miss_thr = (uint32_t)std::llround(missing_rate * 65536.0);
-      kern::synth_generate(c->d_packed, c->pitch, N, snp_begin, P_g, seed, n_pop, fst_fp, miss_thr, c->stream);
+      kern::synth_generate(c->d_packed, c->pitch, N, snp_begin, P_g, seed, n_pop, fst_fp, miss_thr, c->stream, model->maf_model, model->missing_model,
+                           (uint32_t)std::llround(model->conc_frac * 65536.0));
       HIP_CHECK(hipStreamSynchronize(c->stream));
    });
    if (rc != FPCA_OK) {
@@ -1607,6 +1717,23 @@ int fpca_set_allreduce(fpca_ctx *ctx, fpca_allreduce_fn fn, void *user)
    ctx->ar_fn = fn;
    ctx->ar_user = user;
    return FPCA_OK;
+}
+
+int fpca_set_collectives(fpca_ctx *ctx, fpca_allgather_fn ag, fpca_reducescatter_fn rs, void *user)
+{
+   return guarded([&] {
+      if (!ctx || (ag == nullptr) != (rs == nullptr)) throw Error(FPCA_EINVAL, "bad argument to fpca_set_collectives");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      ctx->ag_fn = ag;
+      ctx->rs_fn = rs;
+      ctx->coll_user = user;
+      if (ag && !ctx->comm_stream) { // the stream on which a chunk's reduce-scatter runs while K3 computes the next chunk
+         HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+         for (hipEvent_t &e : ctx->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+         HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_comm_done, hipEventDisableTiming));
+      }
+      ctx->i8_ws_for_S = ctx->i8_ws_for_b = 0;
+   });
 }
 
 int fpca_set_rank(fpca_ctx *ctx, int nranks, int rank)

@@ -1138,6 +1138,27 @@ void fill_random(double *blk, uint64_t N, uint64_t rows, int b, uint64_t seed, h
    HIP_CHECK_LAUNCH();
 }
 
+// *out_bits = max(*out_bits, bit pattern of max_i |a[i] - scale b[i]|) -- non-negative doubles order like their bit patterns
+// (the self-test of the multi-rank exchange compares what the collectives delivered with what they should have)
+__global__ void k_max_abs_diff(const double *a, const double *b, double scale, uint64_t n, unsigned long long *out_bits)
+{
+   double m = 0;
+   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+      const double d = fabs(a[i] - scale * b[i]);
+      m = (d > m || d != d) ? (d != d ? __longlong_as_double(0x7ff0000000000000ll) : d) : m; // a NaN counts as +inf
+   }
+   for (int o = 32; o; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+   if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
+}
+
+void max_abs_diff(const double *a, const double *b, double scale, uint64_t n, unsigned long long *out_bits, hipStream_t stream)
+{
+   if (!n) return;
+   const unsigned blocks = (unsigned)std::min<uint64_t>(2048, (n + 255) / 256);
+   hipLaunchKernelGGL(k_max_abs_diff, dim3(blocks), dim3(256), 0, stream, a, b, scale, n, out_bits);
+   HIP_CHECK_LAUNCH();
+}
+
 __global__ void k_block_to_colmajor(const double *blk, uint64_t N, int b, int ncols, double *out, uint64_t ld)
 {
    const uint64_t total = N * ncols;
@@ -1222,12 +1243,14 @@ void colmajor_to_t(const double *in, uint64_t ld, uint64_t P_g, uint64_t P_pad, 
 // synthetic genotypes straight into HBM: one workgroup per SNP record, one 32-bit word (16 samples) per
 // thread per iteration; integer-only model of synth.hpp, so the host can reproduce any record bit for bit.
 __global__ __launch_bounds__(256) void k_synth_generate(uint8_t *packed, size_t pitch, uint64_t N, uint64_t snp_begin,
-                                                         uint64_t seed, int n_pop, uint32_t fst_fp, uint32_t miss_thr)
+                                                         uint64_t seed, int n_pop, uint32_t fst_fp, uint32_t miss_thr, int maf_model,
+                                                         int missing_model, uint32_t conc_fp)
 {
    __shared__ uint32_t thr[synth::MAX_POP];
    __shared__ uint64_t bnd[synth::MAX_POP + 1];
    const uint64_t snp = snp_begin + blockIdx.x;
-   const uint32_t pj = synth::snp_freq(seed, snp);
+   const uint32_t pj = maf_model == 1 ? synth::snp_freq_rare(seed, snp) : synth::snp_freq(seed, snp);
+   if (missing_model == 1) miss_thr = synth::snp_miss_thr_concentrated(seed, snp, conc_fp);
    if ((int)threadIdx.x < n_pop) thr[threadIdx.x] = synth::pop_freq(seed, snp, pj, fst_fp, (int)threadIdx.x);
    if ((int)threadIdx.x <= n_pop) bnd[threadIdx.x] = synth::pop_boundary(N, n_pop, (int)threadIdx.x);
    __syncthreads();
@@ -1262,11 +1285,11 @@ __global__ __launch_bounds__(256) void k_synth_generate(uint8_t *packed, size_t 
 }
 
 void synth_generate(uint8_t *packed, size_t pitch, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed,
-                    int n_pop, uint32_t fst_fp, uint32_t miss_thr, hipStream_t stream)
+                    int n_pop, uint32_t fst_fp, uint32_t miss_thr, hipStream_t stream, int maf_model, int missing_model, uint32_t conc_fp)
 {
    if (P_g == 0) return;
    hipLaunchKernelGGL(k_synth_generate, dim3((unsigned)P_g), dim3(256), 0, stream, packed, pitch, N, snp_begin, seed,
-                      n_pop, fst_fp, miss_thr);
+                      n_pop, fst_fp, miss_thr, maf_model, missing_model, conc_fp);
    HIP_CHECK_LAUNCH();
 }
 

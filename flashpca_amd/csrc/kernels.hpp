@@ -58,6 +58,8 @@ void block_gemm(const double *const *blocks, int nq, const double *C, const doub
                 int b, hipStream_t stream);
 // uniform(-0.5, 0.5) entries for rows < N, zero for rows in [N, N_pad)
 void fill_random(double *blk, uint64_t N, uint64_t rows, int b, uint64_t seed, hipStream_t stream, uint64_t row0 = 0);
+// *out_bits = max(*out_bits, bits of max |a - scale b|) over n doubles (NaN counts as +inf); out_bits zeroed by the caller
+void max_abs_diff(const double *a, const double *b, double scale, uint64_t n, unsigned long long *out_bits, hipStream_t stream);
 // row-major [N_pad][b] block <-> column-major N x ncols (ld) device staging buffer
 void block_to_colmajor(const double *blk, uint64_t N, int b, int ncols, double *out, uint64_t ld, hipStream_t stream);
 void colmajor_to_block(const double *in, uint64_t ld, uint64_t N, uint64_t N_pad, int b, int ncols, double *blk,
@@ -69,8 +71,12 @@ void colmajor_to_t(const double *in, uint64_t ld, uint64_t P_g, uint64_t P_pad, 
                    hipStream_t stream);
 
 // synthetic genotype generator (synth.hpp model), one workgroup per SNP record
+//   maf_model 0: ancestral frequency uniform in [0.05, 0.95); 1: rare-variant spectrum 0.001 + 0.499 u^3
+//   missing_model 0: every call missing with probability miss_thr / 65536; 1: concentrated in a fraction conc_fp / 65536 of
+//   the SNPs (10-30 % of their calls), the others at most 0.1 %  (synth.hpp)
 void synth_generate(uint8_t *packed, size_t pitch, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed,
-                    int n_pop, uint32_t fst_fp, uint32_t miss_thr, hipStream_t stream);
+                    int n_pop, uint32_t fst_fp, uint32_t miss_thr, hipStream_t stream, int maf_model = 0, int missing_model = 0,
+                    uint32_t conc_fp = 0);
 
 // diagnostic: D(16x16) = A(16x4) B(4x16) through v_mfma_f64_16x16x4_f64 with this file's operand mapping
 void mfma_layout_probe(const double *A, const double *B, double *D, hipStream_t stream);

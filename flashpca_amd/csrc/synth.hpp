@@ -69,6 +69,29 @@ FPCA_HD uint32_t snp_freq(uint64_t seed, uint64_t snp)
    return 3277u + ((u * 58982u) >> 16);
 }
 
+// ---- "realistic" profile (round 4): what array / sequencing genotypes look like and the uniform model above does not ------
+//   allele frequencies  a rare-variant spectrum: minor-allele frequency 0.001 + 0.499 u^3 (u uniform): half of the SNPs below
+//                       6 %, an eighth below 0.2 % -- per-SNP sd = sqrt(2p(1-p)) spans 0.045 .. 0.71 (16x; the uniform
+//                       model's 0.31 .. 0.71 is 2.3x), SNPs that are monomorphic in a small sample occur (sd <= 1e-9 -> zero
+//                       column, data.cpp:299-320)
+//   missing calls       concentrated in few SNPs, as failed assays are: a fraction conc_frac of the SNPs (default 5 %) lose
+//                       10-30 % of their calls, every other SNP at most 0.1 % -- ~1 % overall, but 95 % of the SNPs are
+//                       (nearly) complete
+FPCA_HD uint32_t snp_freq_rare(uint64_t seed, uint64_t snp)
+{
+   const uint64_t u = rnd64(seed, 1, snp, 0) >> 48; // 16 bits
+   const uint64_t u3 = (((u * u) >> 16) * u) >> 16;  // u^3 in 0.16
+   return 66u + (uint32_t)((u3 * 32702u) >> 16);     // 16.16: [0.001, 0.5)
+}
+// per-SNP missing-call threshold (16-bit uniform < thr) of the concentrated model; conc_fp = fraction of affected SNPs in 0.16
+FPCA_HD uint32_t snp_miss_thr_concentrated(uint64_t seed, uint64_t snp, uint32_t conc_fp)
+{
+   const uint64_t h = rnd64(seed, 4, snp, 0);
+   const uint32_t pick = (uint32_t)(h & 0xFFFF), lvl = (uint32_t)((h >> 16) & 0xFFFF);
+   if (pick < conc_fp) return 6554u + ((lvl * 13107u) >> 16); // 10 % .. 30 %
+   return (lvl * 66u) >> 16;                                  // 0 .. 0.1 %
+}
+
 // frequency of SNP j in population c (16.16 fixed point threshold for 16-bit uniforms)
 FPCA_HD uint32_t pop_freq(uint64_t seed, uint64_t snp, uint32_t pj, uint32_t fst_fp /*16.16*/, int c)
 {
@@ -82,7 +105,8 @@ FPCA_HD uint32_t pop_freq(uint64_t seed, uint64_t snp, uint32_t pj, uint32_t fst
    }
    int64_t z = zsum - 6 * 65535; // mean 0, std 65536 (i.e. 1.0 in 16.16)
    int64_t p = (int64_t)pj + (((int64_t)sd * z) >> 16);
-   if (p < 655) p = 655;
+   const int64_t lo = pj < 3277u ? 7 : 655; // (rare-variant spectrum: down to 0.0001 instead of 0.01)
+   if (p < lo) p = lo;
    if (p > 64880) p = 64880;
    return (uint32_t)p;
 }

@@ -104,6 +104,20 @@ int fpca_create_from_bed(fpca_ctx **out, const char *bed_path, uint64_t N, uint6
 int fpca_create_synthetic(fpca_ctx **out, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed,
                           int n_pop, double fst, double missing_rate, int stand_method, int device, int accum);
 
+/* The same generator with the knobs that make the matrix look like array / sequencing data instead of the survey's uniform model
+ * (flashpca_amd/csrc/synth.hpp): maf_model 1 = rare-variant spectrum (minor-allele frequency 0.001 + 0.499 u^3: per-SNP sd over a
+ * 16x range, SNPs monomorphic in small samples); missing_model 1 = missing calls concentrated in `conc_frac` of the SNPs (10-30 %
+ * of their calls; every other SNP <= 0.1 %; missing_rate is ignored).  maf_model = missing_model = 0 is fpca_create_synthetic. */
+typedef struct fpca_synth_model {
+   int n_pop;            /* sub-populations (1..64): n_pop - 1 structured eigenvalues */
+   double fst;
+   double missing_rate;  /* missing_model 0 */
+   int maf_model, missing_model;
+   double conc_frac;     /* missing_model 1: fraction of SNPs with 10-30 % missing calls (e.g. 0.05) */
+} fpca_synth_model;
+int fpca_create_synthetic_model(fpca_ctx **out, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed, const fpca_synth_model *model,
+                                int stand_method, int device, int accum);
+
 /* In-memory matrix input: replaces RandomPCA::pca_fast(MatrixXd& X, ...) + standardise(X, method) (randompca.cpp:121-166,
  * util.cpp:24-192; the R entry flashpca(X) for a numeric matrix, flashpcaR/src/flashpca.cpp:17-93).  X is N x P_g fp64
  * column-major with leading dimension ldx, NaN = missing.  It is copied to HBM and standardised there column by column
@@ -168,6 +182,14 @@ int fpca_comm_init_rank(fpca_ctx *ctx, int nranks, int rank, const uint8_t id[FP
  * (e.g. torch.distributed over RCCL).  Must return 0 on success. */
 typedef int (*fpca_allreduce_fn)(void *user, double *dbuf, uint64_t count, void *stream);
 int fpca_set_allreduce(fpca_ctx *ctx, fpca_allreduce_fn fn, void *user);
+/* ... and, optionally beside it, the caller's all-gather and reduce-scatter (sum) of fp64 on device buffers, ordered on `stream`:
+ * `send` holds count_per_rank doubles (all-gather) / nranks * count_per_rank (reduce-scatter), `recv` the opposite; rank r's
+ * piece sits at offset r * count_per_rank of the long buffer.  With all three callbacks installed (and fpca_set_rank) the
+ * row-sharded solver issues exactly the sequence of collectives it issues over RCCL -- per row chunk, the reduce-scatter of
+ * chunk i on a second stream under the K3 of chunk i + 1 -- instead of building both from the sum (twice the bytes). */
+typedef int (*fpca_allgather_fn)(void *user, const double *send, double *recv, uint64_t count_per_rank, void *stream);
+typedef int (*fpca_reducescatter_fn)(void *user, const double *send, double *recv, uint64_t count_per_rank, void *stream);
+int fpca_set_collectives(fpca_ctx *ctx, fpca_allgather_fn allgather, fpca_reducescatter_fn reducescatter, void *user);
 /* rank / size of this context among the shards when the transport is a caller's all-reduce (fpca_comm_init_rank sets
  * them itself).  Once they are known and nranks > 1, fpca_pca ROW-SHARDS the eigensolver's N-sized work: the operator becomes
  * all-gather -> K2, K3 -> reduce-scatter (the bytes of the one all-reduce, built from the caller's all-reduce if that is all

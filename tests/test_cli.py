@@ -194,6 +194,45 @@ def test_cli_gpus_launcher(tmp_path, built_lib, golden_dir):
 
 
 @pytest.mark.gpu
+def test_cli_gpus_launcher_rccl_shaped_exchange(tmp_path, built_lib):
+    """The row-sharded solver with a transport that HAS all-gather / reduce-scatter (FPCA_CLI_TEST_TRANSPORT=shm2 installs
+    fpca_set_collectives over host shared memory): the very call sequence of the RCCL path -- per row chunk, the reduce-scatter
+    of chunk i on the communication stream under the K3 of chunk i + 1, the chunk-interleaved slice layout, chunks wholly behind
+    the last row skipped -- with 2 and 3 processes on one device and 1 / 2 / 4 row chunks (5,000 samples: 5,120 padded rows, so
+    the chunks are whole, clipped and empty).  The exchange self-test (HipBackend::exchange_selftest) runs inside every one of
+    these; every output must equal the single-process run."""
+    import flashpca_amd as fp
+
+    N, P, k = 5000, 3000, 8
+    pre = str(tmp_path / "syn")
+    with fp.Context.synthetic(N, P, n_pop=6, accum="fp64") as c:
+        packed = c.download_packed()
+    with open(pre + ".bed", "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x01]))
+        packed.tofile(f)
+    open(pre + ".fam", "w").write("".join("F%d I%d 0 0 0 -9\n" % (i, i) for i in range(N)))
+    open(pre + ".bim", "w").write("".join("1 rs%d 0 %d A C\n" % (j, j + 1) for j in range(P)))
+    base = ["--bfile", pre, "--ndim", str(k), "--outload", "load.txt", "--outmeansd", "ms.txt", "--precision", "12"]
+    d1 = tmp_path / "one"
+    d1.mkdir()
+    r = subprocess.run([fp.CLI_PATH] + base, cwd=d1, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    e1 = np.loadtxt(d1 / "eigenvalues.txt")
+    U1, V1, m1 = _tab(d1 / "eigenvectors.txt"), _tab(d1 / "load.txt"), _tab(d1 / "ms.txt")
+    for g, chunks in ((2, 1), (2, 4), (3, 2), (3, 4)):
+        d = tmp_path / ("g%dc%d" % (g, chunks))
+        d.mkdir()
+        env = dict(os.environ, FPCA_CLI_TEST_TRANSPORT="shm2", FPCA_AR_CHUNKS=str(chunks))
+        r = subprocess.run([fp.HOOKS_CLI_PATH] + base + ["--gpus", str(g)], cwd=d, capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, (g, chunks, r.stdout[-1500:] + r.stderr[-1500:])
+        e, U, V, m = np.loadtxt(d / "eigenvalues.txt"), _tab(d / "eigenvectors.txt"), _tab(d / "load.txt"), _tab(d / "ms.txt")
+        sg = np.sign(np.sum(U1 * U, axis=0))
+        assert np.max(np.abs(e - e1) / e1) < 1e-10, (g, chunks)
+        assert np.max(np.abs(U * sg - U1)) < 1e-8 and np.max(np.abs(V * sg - V1)) < 1e-8, (g, chunks)
+        assert np.array_equal(m, m1)
+
+
+@pytest.mark.gpu
 def test_cli_gpus_launcher_failures_do_not_hang(tmp_path, built_lib, golden_dir):
     """A rank that dies (SIGKILL: what an OOM kill looks like), or rank 0 failing after the fork, must end the whole --gpus
     run promptly with a message and a non-zero status; what can be refused from the file sizes is refused before the fork."""

@@ -377,6 +377,40 @@ def test_config3_full_size_properties(fp):
         assert np.max(np.abs(r8["d"] - d64) / d64) < 1e-10
 
 
+def test_config4_eight_way_shards_vs_oracle(fp, orc):
+    """BASELINE configs[3]: 500,000 x 100,000 SNP-sharded across 8 GPUs = 12,500 SNPs per rank.  Every one of the eight shard
+    contexts (the plan / instantiation `bench.py --workload cfg4shard` times: a 12,500-row K2, a 12,500-deep K3) on one GPU:
+    the eight partial products of a 16-column block add up to the whole matrix's (svdwide.cpp:48-62, what the all-reduce of the
+    8-rank run sums), shard 5's product and its X'B / X T halves meet the oracle on the same 12,500 SNPs entry by entry, and
+    its statistics are bit-equal."""
+    N, P, G, b = 500000, 100000, 8, 16
+    per = P // G
+    rng = np.random.default_rng(44)
+    B = rng.standard_normal((N, b))
+    with fp.Context.synthetic(N, P, accum="auto") as whole:
+        Z = whole.apply_xxt(B)
+    acc = np.zeros_like(Z)
+    for g in range(G):
+        with fp.Context.synthetic(N, per, snp_begin=g * per, accum="auto") as sh:
+            sh.set_total_snps(P)
+            Zg = sh.apply_xxt(B)
+            acc += Zg
+            if g == 5:
+                packed = sh.download_packed()
+                od = orc.OracleData(packed=packed, N=N, P=per, stand="binom2")
+                op = orc.OracleOp(od, 1000, nthreads=orc.host_threads())
+                for c in (0, 9, 15):
+                    y = op.perform_op(np.ascontiguousarray(B[:, c]))
+                    assert np.max(np.abs(Zg[:, c] - y)) <= 1e-11 * np.max(np.abs(y)), c
+                t = op.crossprod(np.ascontiguousarray(B[:, 9]))
+                assert np.max(np.abs(sh.apply_xt(B[:, 9:10])[:, 0] - t)) <= 1e-11 * np.max(np.abs(t))
+                Tin = rng.standard_normal((per, 1))
+                y = op.prod(np.ascontiguousarray(Tin[:, 0]))
+                assert np.max(np.abs(sh.apply_x(Tin)[:, 0] - y)) <= 1e-11 * np.max(np.abs(y))
+                assert np.array_equal(sh.stats()[0], od.meansd())
+    assert np.max(np.abs(acc - Z)) <= 1e-12 * np.max(np.abs(Z))
+
+
 def test_config5_full_size_properties(fp):
     """BASELINE config 5 (1,000,000 x 200,000, k=50 -> b=64) at full size on ONE GPU (50 GB packed + the sample-major
     copy): the default exact-integer path against the fp64 kernels on the same block, operator symmetry, the multi-GPU
