@@ -60,6 +60,10 @@ WORKLOADS = {
 STEPS = {"cfg2": 400, "tiny": 400, "cfg3": 80, "cfg5": 24, "cfg4shard": 200, "cfg5shard": 60}
 
 
+MISSING_PATH = {0: "dense (MFMA)", 1: "dense, empty blocks skipped", 2: "none missing", 3: "sparse fp64 gathers",
+                4: "hybrid: sparse fp64 gathers + a compacted dense sub-matrix (MFMA) for the SNPs above 0.5 % missing calls"}
+
+
 def solver_blockvec(k):
     """fpca::choose_blockvec (pca_driver.cpp): the width fpca_pca picks when the caller leaves it open."""
     return 16 if k <= 64 else 32 if k <= 128 else 64
@@ -423,11 +427,11 @@ def main():
     if args.accum.startswith("i8"):
         S = int(args.accum[3:]) if len(args.accum) > 2 else 7
         mm = ctx.missing_mode(b)  # 0/1: two integer matrices on the matrix cores; 2/3: G.M alone (+ sparse gathers for E)
-        nmat = 1 if mm in (2, 3) else 2
+        nmat = 1 if mm in (2, 3, 4) else 2
         ops_launch = nmat * flops_launch * S  # integer matrices x S slices of every operand column
         roofline.update(achieved=ops_launch / (ms_dom * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s", slices=S,
                         integer_matrices_on_mfma=nmat,
-                        missing_call_path={0: "dense (MFMA)", 1: "dense, empty blocks skipped", 2: "none missing", 3: "sparse fp64 gathers"}[mm],
+                        missing_call_path=MISSING_PATH[mm],
                         ops_per_launch=ops_launch, fp64_equivalent_tflops=flops_launch / (ms_dom * 1e-3) / 1e12,
                         peak_measured_pure_mfma_stream=mfma_stream_peak(11))  # random operands; power-limited (measured in this run)
         del roofline["flops_per_launch"]
@@ -566,9 +570,9 @@ def main():
         if args.accum.startswith("i8"):
             S = int(args.accum[3:]) if len(args.accum) > 2 else 7
             mm = c.missing_mode(bw)
-            nm = 1 if mm in (2, 3) else 2
+            nm = 1 if mm in (2, 3, 4) else 2
             ops = nm * 2.0 * N * P_rank * bw * S
-            sw["missing_call_path"] = {0: "dense (MFMA)", 1: "dense, empty blocks skipped", 2: "none missing", 3: "sparse fp64 gathers"}[mm]
+            sw["missing_call_path"] = MISSING_PATH[mm]
             sw["roofline"] = dict(bound="mfma", achieved=ops / (ms_s * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s",
                                   frac=ops / (ms_s * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, ops_per_launch=ops, integer_matrices_on_mfma=nm,
                                   note="S b = %d slice-columns fill %.1f of %d column tiles" % (S * bw, S * bw / 32.0, -(-S * bw // 32)))
@@ -699,8 +703,39 @@ def main():
             out["pca_hard_spectrum"] = dict(n_pop=4, wall_s=wall_h, converged=bool(ih["converged"]), block_applies=ih["block_applies"],
                                             vector_ops=ih["vector_ops"], restarts=ih["restarts"], seconds_apply=ih["seconds_apply"],
                                             seconds_ortho=ih["seconds_ortho"], seconds_host=ih["seconds_host"],
+                                            cheap_applies=ih["cheap_applies"], cheap_slices=ih["cheap_slices"], seconds_apply_exact=ih["seconds_exact"],
                                             eigenvalue_1=float(rh["d"][0]), eigenvalue_k=float(rh["d"][-1]),
                                             max_rel_residual=ih["max_residual"])
+
+    # ---- ... and on the REALISTIC profile (flashpca_amd/csrc/synth.hpp, round 4): allele frequencies from a rare-variant spectrum
+    # (per-SNP sd over a 16x range instead of 2.3x), missing calls concentrated in 5 % of the SNPs at 10-30 % (~1 % overall: the
+    # dense missing-indicator route for those SNPs), 10 sub-populations = 9 structured eigenvalues with 11 of the 20 wanted ones in
+    # the bulk -- what a PCA of array genotypes looks like (HapMap3's tenth eigenvalue sits 1 % above its bulk) ---------
+    if world == 1 and not args.no_pca and not args.no_pca_hard:
+        with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=10, realistic=True, device=local_rank, accum=args.accum) as cr:
+            cr.set_total_snps(P_total)
+            ms_r, _ = cr.stats()
+            cr.pca(ndim=k, allow_unconverged=True, max_applies=-(-k // solver_blockvec(k)) + 1)
+            cr.synchronize()
+            t1 = time.perf_counter()
+            rr_ = cr.pca(ndim=k, allow_unconverged=True)
+            cr.synchronize()
+            wall_r = time.perf_counter() - t1
+            ir = rr_["info"]
+            sr = side_apply(cr, b, max(4, args.steps // 8))
+            import numpy as np
+
+            sd_r = ms_r[:, 1]
+            out["pca_realistic"] = dict(n_pop=10, profile="rare-variant allele-frequency spectrum, missing calls concentrated in 5 % of the SNPs",
+                                        wall_s=wall_r, converged=bool(ir["converged"]), block_applies=ir["block_applies"], cheap_applies=ir["cheap_applies"],
+                                        cheap_slices=ir["cheap_slices"], vector_ops=ir["vector_ops"], restarts=ir["restarts"],
+                                        seconds_apply=ir["seconds_apply"], seconds_apply_exact=ir["seconds_exact"], seconds_ortho=ir["seconds_ortho"],
+                                        seconds_host=ir["seconds_host"], eigenvalue_1=float(rr_["d"][0]), eigenvalue_k=float(rr_["d"][-1]),
+                                        max_rel_residual=ir["max_residual"],
+                                        sd_min=float(np.nanmin(sd_r[sd_r > 1e-9])), sd_median=float(np.nanmedian(sd_r)), sd_max=float(np.nanmax(sd_r)),
+                                        missing_call_path=sr.get("missing_call_path"), apply_ms_per_step=sr["ms_per_step"],
+                                        apply_slowdown_vs_value=sr["ms_per_step"] / (elapsed / args.steps * 1e3))
+            del rr_
 
     # ---- the same workload through the other exact path (fp64 MFMA kernels <-> int8 slices): timing and agreement ------
     if world == 1 and args.accum in ("fp64", "i8") and not args.no_alt:
@@ -722,7 +757,7 @@ def main():
             diff = float(torch.max(torch.abs(Y2 - Y)).item())
             ms2 = max(p2["ms_gemm_xt"], p2["ms_gemm_x"])
             if other == "i8":
-                ops = (1 if c2.missing_mode(b) in (2, 3) else 2) * flops_launch * 7
+                ops = (1 if c2.missing_mode(b) in (2, 3, 4) else 2) * flops_launch * 7
                 rf = dict(bound="mfma", achieved=ops / (ms2 * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s",
                           frac=ops / (ms2 * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, peak_measured_pure_mfma_stream=mfma_stream_peak(11))
             else:

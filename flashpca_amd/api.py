@@ -40,7 +40,8 @@ class Context:
 
     def missing_mode(self, b=32):
         """How the exact-integer path treats the missing-call indicator (fpca_missing_mode): 0 full, 1 skip empty blocks,
-        2 nothing missing, 3 sparse gathers; -1 for the fp64 / fp32 kernels."""
+        2 nothing missing, 3 sparse gathers, 4 hybrid (sparse gathers + a dense sub-matrix for the SNPs that hold most of the
+        missing calls); -1 for the fp64 / fp32 kernels."""
         return int(lib().fpca_missing_mode(self.h, b))
 
     def allreduce_chunks(self):

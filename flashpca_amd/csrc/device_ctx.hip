@@ -145,6 +145,23 @@ struct fpca_ctx {
    size_t eplane_cap = 0;
    bool sparse_ready = false;
    bool sparse_failed = false; // the index lists did not fit in device memory: the dense missing-indicator route is used
+   // hybrid missing-indicator route: the SNPs whose missing calls are too many for the gathers (hyb_idx, hyb_n of them, padded
+   // to hyb_pad) keep their indicator matrix E on the matrix cores as a compacted sub-matrix (SNP-major d_packedE, sample-major
+   // d_packedET); the sample-major copy d_packedT then holds the VIEW of the matrix in which their missing calls read "dosage
+   // 0" (same G.M), and the sparse lists hold the other SNPs' missing calls only
+   int hyb_class = -1;        // -1 not classified yet, 0 no, 1 the shard qualifies
+   bool hyb_view = false;     // d_packedT is that view (any route but the hybrid one needs the plain copy back: plain_view())
+   bool hyb_failed = false;
+   uint32_t hyb_n = 0, hyb_pad = 0;
+   uint64_t hyb_sparse_nnz = 0;
+   std::vector<uint32_t> h_hyb_idx;
+   uint32_t *d_hyb_idx = nullptr;
+   uint8_t *d_packedE = nullptr, *d_packedET = nullptr;
+   size_t pitchET = 0;
+   double *d_hyb_T = nullptr, *d_hyb_plane = nullptr;
+   size_t hyb_T_cap = 0, hyb_plane_cap = 0;
+   int8_t *d_Qd = nullptr;
+   int hyb_qd_rows = 0, hyb_qd_zeroed_for = -1;
    hipStream_t aux_stream = nullptr; // the gather-sums run here, under the (MFMA-bound) GEMM of the same stage
    hipEvent_t ev_aux_go = nullptr, ev_aux_done = nullptr;
    // Krylov basis blocks of finished solves, kept for the next one (bytes, pointer): allocating and freeing a dozen
@@ -334,7 +351,7 @@ void ctx_free(fpca_ctx *c)
    void *ptrs[] = {c->d_Xd, c->d_packed, c->d_lut, c->d_mean, c->d_sd,   c->d_sumsq, c->d_T,
                    c->d_part,   c->d_stage, c->d_io_a, c->d_io_b, c->d_small, c->d_packedT, c->d_inv_sd, c->d_mu_inv_sd,
                    c->d_i8w, c->d_Qb, c->d_Qg, c->d_Qm, c->d_i8ws, c->d_snp_ptr, c->d_snp_idx, c->d_smp_ptr, c->d_smp_idx, c->d_eplane,
-                   c->d_full_in, c->d_full_out};
+                   c->d_full_in, c->d_full_out, c->d_hyb_idx, c->d_packedE, c->d_packedET, c->d_hyb_T, c->d_hyb_plane, c->d_Qd};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (auto &pb : c->block_pool) (void)hipFree(pb.second);
@@ -389,10 +406,14 @@ void ensure_stats(fpca_ctx *c)
 // ---- exact-integer mode --------------------------------------------------------------------------------
 // layout of d_i8w in 8-byte words: three weight vectors (S*b <= 9*64 = 576 entries each, padded), then the region that is
 // zeroed once per apply: column maxima (bit patterns) of the three operands and the column sums of the two M operands
-constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_ZERO = 1920, I8W_MAXB = I8W_ZERO, I8W_MAXG = I8W_MAXB + 64 * kern::I8_SHARDS,
-              I8W_MAXM = I8W_MAXG + 64 * kern::I8_SHARDS, I8W_CSB = I8W_MAXM + 64 * kern::I8_SHARDS,
+// (I8W_D / I8W_MAXD: the K3 operand of the hybrid route's dense SNPs)
+constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_D = 1920, I8W_ZERO = 2560, I8W_MAXB = I8W_ZERO, I8W_MAXG = I8W_MAXB + 64 * kern::I8_SHARDS,
+              I8W_MAXM = I8W_MAXG + 64 * kern::I8_SHARDS, I8W_MAXD = I8W_MAXM + 64 * kern::I8_SHARDS, I8W_CSB = I8W_MAXD + 64 * kern::I8_SHARDS,
               I8W_CSM = I8W_CSB + kern::I8_CS_STRIDE * kern::I8_SHARDS, I8W_TOTAL = I8W_CSM + kern::I8_CS_STRIDE * kern::I8_SHARDS;
 
+constexpr int I8M_FULL = 0, I8M_SKIP = 1, I8M_NONE = 2, I8M_SPARSE = 3, I8M_HYBRID = 4; // (see i8_mode)
+constexpr double SPARSE_BREAK_EVEN = 0.005; // missing-call rate at which the gathers cost what the E half of the GEMMs costs
+void hybrid_classify(fpca_ctx *c);
 void ensure_i8_alloc(fpca_ctx *c, int b);
 uint64_t ar_chunk_begin(const fpca_ctx *c, int nchunks, int i);
 int shard_chunks(const fpca_ctx *c);
@@ -438,7 +459,44 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
       if (!c->d_mu_inv_sd) HIP_ALLOC(hipMalloc(&c->d_mu_inv_sd, c->P_pad * sizeof(double)));
       if (!c->d_i8w) HIP_ALLOC(hipMalloc(&c->d_i8w, I8W_TOTAL * sizeof(double)));
       HIP_ALLOC(hipMalloc(&c->d_packedT, c->pitchT * c->N_pad));
+      // hybrid missing-indicator route (decided from K1's per-SNP counts, whatever b will be): the records of the dense SNPs are
+      // copied out, their missing calls are rewritten to "dosage 0" for the duration of the transposition -- the sample-major
+      // copy then IS the view the sparse lists and K3's G.M kernel want -- and the records are put back
+      bool hyb = false;
+      {
+         const char *env = FPCA_TEST_ENV("FPCA_I8_MODE");
+         hybrid_classify(c);
+         hyb = c->hyb_class == 1 && !c->hyb_failed && !c->sparse_failed && (!env || atoi(env) == I8M_HYBRID);
+      }
+      if (hyb) {
+         try {
+            HIP_ALLOC(hipMalloc(&c->d_hyb_idx, c->hyb_pad * sizeof(uint32_t)));
+            HIP_ALLOC(hipMalloc(&c->d_packedE, (size_t)c->hyb_pad * c->pitch));
+            c->pitchET = (size_t)c->hyb_pad / 4;
+            HIP_ALLOC(hipMalloc(&c->d_packedET, c->pitchET * c->N_pad));
+         } catch (const Error &e) {
+            if (e.code != FPCA_ENOMEM) throw;
+            (void)hipGetLastError();
+            for (void **q : {(void **)&c->d_hyb_idx, (void **)&c->d_packedE, (void **)&c->d_packedET})
+               if (*q) {
+                  (void)hipFree(*q);
+                  *q = nullptr;
+               }
+            c->hyb_failed = true;
+            hyb = false;
+         }
+      }
+      if (hyb) {
+         HIP_CHECK(hipMemcpyAsync(c->d_hyb_idx, c->h_hyb_idx.data(), c->hyb_n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+         kern::gather_packed_rows(c->d_packed, c->pitch, c->d_hyb_idx, c->hyb_n, c->hyb_pad, c->d_packedE, s);
+         kern::patch_missing_rows(c->d_packed, c->pitch, c->d_hyb_idx, c->hyb_n, s);
+      }
       kern::transpose_packed(c->d_packed, c->pitch, c->N_pad, c->P_pad, c->d_packedT, c->pitchT, s);
+      if (hyb) {
+         kern::scatter_packed_rows(c->d_packedE, c->pitch, c->d_hyb_idx, c->hyb_n, c->d_packed, s);
+         kern::transpose_packed(c->d_packedE, c->pitch, c->N_pad, c->hyb_pad, c->d_packedET, c->pitchET, s);
+         c->hyb_view = true;
+      }
       c->i8_transposed = true;
    }
    if (!c->i8_scales_done) {
@@ -506,20 +564,57 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
 // how the int8 GEMMs treat the missing-indicator matrix (kernels_i8.hip: I8_FULL / I8_SKIP_EMPTY / I8_NO_MISSING)
 // 0 both matrices on the matrix cores; 1 the same, skipping blocks of E without a missing call; 2 no missing call in the
 // shard: G.M alone; 3 G.M alone on the matrix cores + the missing-indicator products as sparse fp64 gathers
-constexpr int I8M_FULL = 0, I8M_SKIP = 1, I8M_NONE = 2, I8M_SPARSE = 3;
-int i8_mode(const fpca_ctx *c, int b)
+// 4 = hybrid: G.M on the matrix cores; the missing-indicator products as sparse gathers for most SNPs and as a small
+// integer GEMM over a compacted sub-matrix for the few SNPs that hold most of the missing calls (real arrays: failed assays)
+
+// Per-SNP choice of the route (from K1's per-SNP counts): a SNP above the break-even rate goes dense.  The shard qualifies
+// for the hybrid route when that leaves the rest at or below the break-even and the dense set is a minority of the SNPs.
+void hybrid_classify(fpca_ctx *c)
 {
+   if (c->hyb_class >= 0) return;
+   c->hyb_class = 0;
+   if (!c->missing_known || c->h_nmiss.size() != c->P_g || c->P_g == 0) return;
+   const double thr = SPARSE_BREAK_EVEN * (double)c->N;
+   uint64_t dense_nnz = 0;
+   std::vector<uint32_t> idx;
+   for (uint64_t j = 0; j < c->P_g; j++)
+      if ((double)c->h_nmiss[j] > thr) {
+         idx.push_back((uint32_t)j);
+         dense_nnz += c->h_nmiss[j];
+      }
+   const uint64_t rest = c->n_missing - dense_nnz;
+   if (idx.empty() || idx.size() * 4 > c->P_g) return;
+   if ((double)rest > SPARSE_BREAK_EVEN * (double)c->N * (double)(c->P_g - idx.size()) || rest >= (1ull << 31)) return;
+   c->hyb_n = (uint32_t)idx.size();
+   c->hyb_pad = (uint32_t)round_up(c->hyb_n, SNP_ALIGN);
+   c->hyb_sparse_nnz = rest;
+   c->h_hyb_idx.swap(idx);
+   c->hyb_class = 1;
+}
+
+int i8_mode(const fpca_ctx *c_, int b)
+{
+   fpca_ctx *c = const_cast<fpca_ctx *>(c_);
    const char *env = FPCA_TEST_ENV("FPCA_I8_MODE"); // force (tests; 2 is wrong unless nothing is missing); read on every call
    const bool sparse_ok = c->missing_known && !c->sparse_failed && c->n_missing < (1ull << 31) && (b == 16 || b == 32 || b == 64);
+   const bool lists_ok = c->missing_known && !c->sparse_failed && (b == 16 || b == 32 || b == 64);
+   if (env && atoi(env) == I8M_HYBRID) {
+      hybrid_classify(c);
+      return (lists_ok && c->hyb_class == 1 && !c->hyb_failed) ? I8M_HYBRID : I8M_FULL;
+   }
    if (env) return (atoi(env) == I8M_SPARSE && !sparse_ok) ? I8M_FULL : atoi(env);
    if (!c->missing_known) return I8M_FULL;
    if (c->n_missing == 0) return I8M_NONE;
    const double rate = (double)c->n_missing / ((double)c->N * (double)std::max<uint64_t>(c->P_g, 1));
+   if (lists_ok && rate > SPARSE_BREAK_EVEN && !c->hyb_failed) {
+      hybrid_classify(c);
+      if (c->hyb_class == 1) return I8M_HYBRID;
+   }
    // a gathered fp64 row costs 8 b bytes per missing call; the E half of the int8 GEMMs costs the same whatever the rate.
    // Measured at 500k x 100k (scripts/sparse_breakeven.py, profiles/r03_sparse_breakeven.txt; K2 / K3 stage in ms, sparse |
    // dense): b = 16: 0.3 % 6.8 / 7.4 | 9.0 / 9.8, 0.5 % 8.5 / 9.1 | 9.0 / 9.9, 1 % 12.6 / 13.0 | 9.0 / 9.8; b = 32: 0.3 % 12.7 / 13.7 |
    // 16.2 / 18.8, 0.5 % 15.9 / 16.8 | 16.1 / 18.8, 1 % 23.9 / 24.7 | 16.2 / 18.8 -- the lines cross at 0.51-0.63 % for both widths
-   if (sparse_ok && rate <= 0.005) return I8M_SPARSE;
+   if (sparse_ok && rate <= SPARSE_BREAK_EVEN) return I8M_SPARSE;
    return rate < 3e-4 ? I8M_SKIP : I8M_FULL; // (block skipping: only where the sparse path does not apply)
 }
 
@@ -530,7 +625,7 @@ int i8_mode(const fpca_ctx *c, int b)
 bool sparse_on_side_stream(const fpca_ctx *c, int b)
 {
    static const double thr = FPCA_TEST_ENV("FPCA_SPARSE_SIDE_BYTES") ? atof(FPCA_TEST_ENV("FPCA_SPARSE_SIDE_BYTES")) : 2e9;
-   return (double)c->n_missing * b * 8.0 > thr;
+   return (double)(c->hyb_view ? c->hyb_sparse_nnz : c->n_missing) * b * 8.0 > thr;
 }
 
 // index lists of the missing calls, built once (by SNP from the SNP-major stream, by sample from the sample-major copy)
@@ -554,9 +649,18 @@ void ensure_sparse(fpca_ctx *c, int b)
       HIP_CHECK(hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming));
       HIP_CHECK(hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming));
    }
-   const uint64_t nnz = c->n_missing;
+   // (hybrid view: the dense SNPs' missing calls are not listed -- their counts are zero here, and fill_missing leaves a record
+   //  with an empty list untouched; the sample-major copy does not show them in the first place)
+   const uint64_t nnz = c->hyb_view ? c->hyb_sparse_nnz : c->n_missing;
    std::vector<uint32_t> ptr(c->P_g + 1, 0);
-   for (uint64_t j = 0; j < c->P_g; j++) ptr[j + 1] = ptr[j] + c->h_nmiss[j];
+   {
+      size_t d = 0;
+      for (uint64_t j = 0; j < c->P_g; j++) {
+         const bool dense = c->hyb_view && d < c->h_hyb_idx.size() && c->h_hyb_idx[d] == j;
+         if (dense) d++;
+         ptr[j + 1] = ptr[j] + (dense ? 0u : c->h_nmiss[j]);
+      }
+   }
    HIP_ALLOC(hipMalloc(&c->d_snp_ptr, (c->P_g + 1) * sizeof(uint32_t)));
    HIP_ALLOC(hipMalloc(&c->d_snp_idx, std::max<uint64_t>(nnz, 1) * sizeof(uint32_t)));
    HIP_CHECK(hipMemcpyAsync(c->d_snp_ptr, ptr.data(), (c->P_g + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -580,14 +684,81 @@ void ensure_sparse(fpca_ctx *c, int b)
    c->sparse_ready = true;
 }
 
+// Any route but the hybrid one reads the sample-major copy as the plain transpose of the matrix: if it currently holds the
+// hybrid view, it is transposed again (6 ms at 500,000 x 100,000) and the lists made for the view are dropped.  Rare: a
+// block width without a gather kernel (48), a forced mode (tests), or the view's buffers not fitting after all.
+void plain_view(fpca_ctx *c)
+{
+   if (!c->hyb_view) return;
+   kern::transpose_packed(c->d_packed, c->pitch, c->N_pad, c->P_pad, c->d_packedT, c->pitchT, c->stream);
+   HIP_CHECK(hipStreamSynchronize(c->stream));
+   for (void **q : {(void **)&c->d_snp_ptr, (void **)&c->d_snp_idx, (void **)&c->d_smp_ptr, (void **)&c->d_smp_idx, (void **)&c->d_packedE,
+                    (void **)&c->d_packedET, (void **)&c->d_hyb_idx})
+      if (*q) {
+         (void)hipFree(*q);
+         *q = nullptr;
+      }
+   c->sparse_ready = false;
+   c->hyb_view = false;
+   c->hyb_failed = true;
+}
+
+// the hybrid route's per-width buffers: the dense SNPs' operand Td [hyb_pad][b] and its slices, one plane of E products
+void ensure_hybrid(fpca_ctx *c, int b)
+{
+   const size_t need_t = (size_t)c->hyb_pad * b, need_p = (size_t)std::max<uint64_t>(c->hyb_pad, c->N_pad) * b;
+   if (need_t > c->hyb_T_cap) {
+      if (c->d_hyb_T) HIP_CHECK(hipFree(c->d_hyb_T));
+      c->d_hyb_T = nullptr;
+      c->hyb_T_cap = 0;
+      HIP_ALLOC(hipMalloc(&c->d_hyb_T, need_t * sizeof(double)));
+      c->hyb_T_cap = need_t;
+   }
+   if (need_p > c->hyb_plane_cap) {
+      if (c->d_hyb_plane) HIP_CHECK(hipFree(c->d_hyb_plane));
+      c->d_hyb_plane = nullptr;
+      c->hyb_plane_cap = 0;
+      HIP_ALLOC(hipMalloc(&c->d_hyb_plane, need_p * sizeof(double)));
+      c->hyb_plane_cap = need_p;
+   }
+   const int Sc = c->cur_S(), nsc = std::max(kern::gemm_i8_nsc_pad(Sc, b), kern::gemm_i8_nsc_pad(c->i8_S, b));
+   if (nsc > c->hyb_qd_rows) {
+      if (c->d_Qd) HIP_CHECK(hipFree(c->d_Qd));
+      c->d_Qd = nullptr;
+      c->hyb_qd_rows = 0;
+      HIP_ALLOC(hipMalloc(&c->d_Qd, (size_t)nsc * c->hyb_pad));
+      c->hyb_qd_rows = nsc;
+      c->hyb_qd_zeroed_for = -1;
+   }
+   if (c->hyb_qd_zeroed_for != Sc * b) { // rows behind S b are multiplied like any other: zero (small buffer: all of it)
+      HIP_CHECK(hipMemsetAsync(c->d_Qd, 0, (size_t)c->hyb_qd_rows * c->hyb_pad, c->stream));
+      c->hyb_qd_zeroed_for = Sc * b;
+   }
+   const size_t ws = std::max(kern::gemm_i8_workspace_doubles(c->hyb_pad, c->N_pad, Sc, b, false), kern::gemm_i8_workspace_doubles(c->N_pad, c->hyb_pad, Sc, b, false));
+   if (ws > c->i8ws_cap) {
+      HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (c->d_i8ws) HIP_CHECK(hipFree(c->d_i8ws));
+      c->d_i8ws = nullptr;
+      c->i8ws_cap = 0;
+      HIP_ALLOC(hipMalloc(&c->d_i8ws, ws * sizeof(double)));
+      c->i8ws_cap = ws;
+   }
+}
+
 // The sparse route needs 8 bytes per missing call (2 GB at 500k x 100k and 0.5 %) plus one N x b plane.  If that does not
 // fit, the context takes the dense missing-indicator route (both integer matrices on the matrix cores) from here on --
 // out-of-memory only; any other failure is reported.  Returns the mode to use.
-int sparse_or_dense(fpca_ctx *c, int b)
+int sparse_or_dense(fpca_ctx *c, int b, int want = I8M_SPARSE)
 {
    try {
+      if (want == I8M_HYBRID && !c->hyb_view) { // (the shard qualified after the sample-major copy was made -- e.g. forced late)
+         c->hyb_failed = true;
+         return i8_mode(c, b);
+      }
+      if (want != I8M_HYBRID) plain_view(c);
       ensure_sparse(c, b);
-      return I8M_SPARSE;
+      if (want == I8M_HYBRID) ensure_hybrid(c, b);
+      return want;
    } catch (const Error &e) {
       if (e.code != FPCA_ENOMEM) throw;
       (void)hipGetLastError();
@@ -601,6 +772,7 @@ int sparse_or_dense(fpca_ctx *c, int b)
       c->eplane_cap = 0;
       c->sparse_ready = false;
       c->sparse_failed = true;
+      plain_view(c);
       return i8_mode(c, b);
    }
 }
@@ -632,16 +804,27 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipE
    hipEvent_t wait = nullptr;
    kern::i8_colmax(dB, c->N, b, 1, &ob, s);
    kern::i8_slice(dB, c->N_pad, c->N, b, c->cur_S(), 1, &ob, s);
-   if (mode == I8M_SPARSE) mode = sparse_or_dense(c, b);
-   if (mode == I8M_SPARSE) { // E'B: for every SNP the sum of the B rows of its missing samples, on the (low-priority) side
-      if (sparse_on_side_stream(c, b)) { // stream, released together with the GEMM
+   if (mode == I8M_SPARSE || mode == I8M_HYBRID)
+      mode = sparse_or_dense(c, b, mode);
+   else
+      plain_view(c);
+   const bool hyb = mode == I8M_HYBRID;
+   if (hyb) // E_d' B of the dense SNPs on the matrix cores: their compacted records x the same slices of B -> [hyb_pad][b]
+      kern::gemm_i8(c->d_packedE, c->pitch, c->d_Qb, c->d_Qb, ob.colw, ob.colw, nullptr, nullptr, nullptr, c->d_hyb_plane, c->d_i8ws, c->hyb_pad, c->N_pad,
+                    c->hyb_n, I8M_NONE, nullptr, b, c->cur_S(), nullptr, s, nullptr, nullptr, true);
+   if (mode == I8M_SPARSE || hyb) { // E'B: for every SNP the sum of the B rows of its missing samples, on the (low-priority) side
+      hipStream_t gs = s;            // stream, released together with the GEMM
+      if (sparse_on_side_stream(c, b)) {
          HIP_CHECK(hipEventRecord(c->ev_aux_go, s));
          HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_aux_go, 0));
-         kern::sparse_rows_sum(c->d_snp_ptr, c->d_snp_idx, dB, nullptr, b, c->P_g, c->P_pad, c->d_eplane, c->aux_stream);
+         gs = c->aux_stream;
+      }
+      kern::sparse_rows_sum(c->d_snp_ptr, c->d_snp_idx, dB, nullptr, b, c->P_g, c->P_pad, c->d_eplane, gs);
+      if (hyb) kern::scatter_rows(c->d_hyb_plane, c->d_hyb_idx, c->hyb_n, b, c->d_eplane, gs); // (the gather wrote zeros there: empty lists)
+      if (gs != s) {
          HIP_CHECK(hipEventRecord(c->ev_aux_done, c->aux_stream));
          wait = c->ev_aux_done;
-      } else
-         kern::sparse_rows_sum(c->d_snp_ptr, c->d_snp_idx, dB, nullptr, b, c->P_g, c->P_pad, c->d_eplane, s);
+      }
       eplane = c->d_eplane;
       mode = I8M_NONE;
    }
@@ -687,18 +870,34 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_
    kern::SliceOp ot[2];
    i8_ops_t(c, ot);
    int mode = i8_mode(c, b);
-   if (mode == I8M_SPARSE) mode = sparse_or_dense(c, b);
+   if (mode == I8M_SPARSE || mode == I8M_HYBRID)
+      mode = sparse_or_dense(c, b, mode);
+   else
+      plain_view(c);
+   const bool hyb = mode == I8M_HYBRID;
+   if (hyb) mode = I8M_SPARSE; // (from here on the two routes differ only in what the gathered plane starts from)
    if (do_slice) {
       if (!have_max) kern::i8_colmax(c->d_T, c->P_g, b, 2, ot, s);
       kern::i8_slice(c->d_T, c->P_pad, c->P_g, b, c->cur_S(), 2, ot, s);
+      if (hyb) {
+         // E_d (mean T / sd)_d: the dense SNPs' rows of the operand, gathered and scaled, sliced on their own (own column
+         // scale), against the sample-major copy of their records -> one plane [N_pad][b] the gather below starts from
+         kern::SliceOp od{nullptr, reinterpret_cast<unsigned long long *>(c->d_i8w + I8W_MAXD), c->d_Qd, c->d_i8w + I8W_D, nullptr};
+         kern::gather_scaled_rows(c->d_T, c->d_mu_inv_sd, c->d_hyb_idx, c->hyb_n, c->hyb_pad, b, c->d_hyb_T, s);
+         kern::i8_colmax(c->d_hyb_T, c->hyb_n, b, 1, &od, s);
+         kern::i8_slice(c->d_hyb_T, c->hyb_pad, c->hyb_n, b, c->cur_S(), 1, &od, s);
+         kern::gemm_i8(c->d_packedET, c->pitchET, c->d_Qd, c->d_Qd, od.colw, od.colw, nullptr, nullptr, nullptr, c->d_hyb_plane, c->d_i8ws, c->N_pad,
+                       c->hyb_pad, c->N, I8M_NONE, nullptr, b, c->cur_S(), nullptr, s, nullptr, nullptr, true);
+      }
+      const double *init = hyb ? c->d_hyb_plane : nullptr;
       if (mode == I8M_SPARSE) { // E (mean T / sd): for every sample the sum of the scaled T rows of its missing SNPs
          if (sparse_on_side_stream(c, b)) {
             HIP_CHECK(hipEventRecord(c->ev_aux_go, s)); // T is complete on s here (and the K2 combine has consumed the plane)
             HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_aux_go, 0));
-            kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, c->d_T, c->d_mu_inv_sd, b, c->N, c->N_pad, c->d_eplane, c->aux_stream);
+            kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, c->d_T, c->d_mu_inv_sd, b, c->N, c->N_pad, c->d_eplane, c->aux_stream, init);
             HIP_CHECK(hipEventRecord(c->ev_aux_done, c->aux_stream));
          } else
-            kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, c->d_T, c->d_mu_inv_sd, b, c->N, c->N_pad, c->d_eplane, s);
+            kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, c->d_T, c->d_mu_inv_sd, b, c->N, c->N_pad, c->d_eplane, s, init);
       }
    }
    if (r1 == 0) r1 = c->N_pad;

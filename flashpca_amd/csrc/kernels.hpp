@@ -106,12 +106,19 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
              const long long *colsum_m, const double *mean, const double *sd, double *out, double *ws, uint64_t rows_pad, uint64_t k_pad,
              uint64_t rows_valid, int mode /* 0 full, 1 skip E blocks without a missing genotype, 2 G.M alone */,
              const double *eplane /* with mode 2: E'Q [rows_pad][b] from sparse_rows_sum, or null if nothing is missing */, int b, int S,
-             const SliceOp *next_ops, hipStream_t stream, hipEvent_t *gemm_events = nullptr, hipEvent_t before_combine = nullptr);
+             const SliceOp *next_ops, hipStream_t stream, hipEvent_t *gemm_events = nullptr, hipEvent_t before_combine = nullptr,
+             bool e_only = false /* mode 2 only: multiply the missing-indicator matrix E instead of G.M; out = E Q */);
+// the hybrid missing-indicator route's row shuffles (kernels_i8.hip)
+void gather_packed_rows(const uint8_t *src, size_t pitch, const uint32_t *idx, uint32_t nidx, uint32_t rows_out, uint8_t *dst, hipStream_t stream);
+void patch_missing_rows(uint8_t *packed, size_t pitch, const uint32_t *idx, uint32_t nidx, hipStream_t stream);
+void scatter_packed_rows(const uint8_t *src, size_t pitch, const uint32_t *idx, uint32_t nidx, uint8_t *packed, hipStream_t stream);
+void gather_scaled_rows(const double *V, const double *scale, const uint32_t *idx, uint32_t nidx, uint64_t rows_out, int b, double *dst, hipStream_t stream);
+void scatter_rows(const double *src, const uint32_t *idx, uint32_t nidx, int b, double *dst, hipStream_t stream);
 // index lists of the missing calls of 2-bit records (positions < ncols), and the gather-sum over them
 void count_missing(const uint8_t *packed, size_t pitch, uint64_t ncols, uint64_t nrec, uint32_t *cnt, hipStream_t stream);
 void fill_missing(const uint8_t *packed, size_t pitch, uint64_t ncols, uint64_t nrec, const uint32_t *ptr, uint32_t *idx, hipStream_t stream);
 void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, const double *rowscale, int b, uint64_t nrec,
-                     uint64_t rows_out, double *out, hipStream_t stream);
+                     uint64_t rows_out, double *out, hipStream_t stream, const double *init = nullptr /* [rows_out][b] added to the sums */);
 void i8_rowscales(const double *mean, const double *sd, uint64_t P_g, uint64_t P_pad, double *inv_sd, double *mu_inv_sd,
                   hipStream_t stream);
 void transpose_packed(const uint8_t *in, size_t pitch_in, uint64_t N_pad, uint64_t P_pad, uint8_t *out, size_t pitch_out,

@@ -336,12 +336,14 @@ struct I8Cfg {
 // returns (MODE == I8_SKIP_EMPTY) whether any lane of the wave holds a missing genotype in this 32-row x 32-k block
 // (wave-uniform), else true
 template <int MODE>
-__device__ __forceinline__ bool i8_decode(uint32_t w, v4i &ag, v4i &am)
+__device__ __forceinline__ bool i8_decode(uint32_t w, v4i &ag, v4i &am, uint32_t tab1)
 {
    // byte[code] of the two integer matrices: G.M (dosage, 0 if missing) and E = 1 - M (missing indicator): code 0 -> (2,0),
    // 1 (missing) -> (0,1), 2 -> (1,0), 3 -> (0,0).  E instead of M because E is almost all zeros: the products vanish and
    // the power-limited matrix pipe clocks higher; M'Q is recovered exactly in the combine as 1'Q - E'Q.
-   const uint32_t tabG = 0x00010002u, tabM = 0x00000100u;
+   // (the one-matrix kernel takes its table as an argument: G.M for the genotype products, E for the missing-indicator
+   //  products of the SNPs whose missing calls are too many for the sparse route -- gemm_i8 `e_only`)
+   const uint32_t tabG = MODE == I8_NO_MISSING ? tab1 : 0x00010002u, tabM = 0x00000100u;
 #pragma unroll
    for (int q = 0; q < 4; q++) {
       const uint32_t sel = (w >> (2 * q)) & 0x03030303u;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
                                                      const int8_t *__restrict__ Qg, const int8_t *__restrict__ Qm,
                                                      uint64_t k_pad, const double *__restrict__ wg, const double *__restrict__ wm, int bw,
                                                      double *__restrict__ part, uint64_t rows_pad, int chunks_total, int zb,
-                                                     int nA, int sB, int cpsB, uint64_t rowB0, uint64_t rowsB)
+                                                     int nA, int sB, int cpsB, uint64_t rowB0, uint64_t rowsB, uint32_t tab1)
 {
    constexpr bool TWO = C::TWO;
    constexpr int MODE = C::MODE, MATS = C::MATS;
@@ -502,13 +504,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
          }
       };
       read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-      enz[0] = i8_decode<MODE>(pk[0][0][0], ag[0], am[0]);
+      enz[0] = i8_decode<MODE>(pk[0][0][0], ag[0], am[0], tab1);
       wait_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       if constexpr ((C::ABL & 4) != 0) {
          read_b(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
          wait_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
       }
-      if constexpr ((C::ABL & 2) != 0) enz[1] = i8_decode<MODE>(pk[0][0][1], ag[1], am[1]);
+      if constexpr ((C::ABL & 2) != 0) enz[1] = i8_decode<MODE>(pk[0][0][1], ag[1], am[1], tab1);
       __builtin_amdgcn_sched_barrier(0);
 
       static_for<NSTEP>([&](auto ss) {
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
                   acc[1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(am[akey & AMASK], bq[bkey & 1][NQ - 1][j], acc[1][m][n], 0, 0, 0);
             }
             if constexpr (j == 0 && akey1 != akey && !(C::ABL & 2))
-               enz[akey1 & AMASK] = i8_decode<MODE>(pk[m1][ks1 >> 2][ks1 & 3], ag[akey1 & AMASK], am[akey1 & AMASK]);
+               enz[akey1 & AMASK] = i8_decode<MODE>(pk[m1][ks1 >> 2][ks1 & 3], ag[akey1 & AMASK], am[akey1 & AMASK], tab1);
          });
          if constexpr (HALF && (ks & 1) == 1) {
             // the 16 remaining columns over k-steps ks - 1 and ks: row group r of the even / odd fragment = rows 16 (r & 1) ..
@@ -684,7 +686,8 @@ __global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ p
    const int c = threadIdx.x % b, r_in = threadIdx.x / b, r_step = 256 / b;
    double m0 = 0.0, m1 = 0.0;
    // 1'Qm recombined once per block: sum_s w[s,c] colsum[s,c] (shards folded), small terms first
-   for (int t = threadIdx.x; t < S * b; t += 256) sw[t] = wm[t] * (double)colsum_fold(colsum_m, t);
+   // (mats == -1: the plain product of ONE integer matrix -- out = sum of its partials, rows >= rows_valid zero)
+   for (int t = threadIdx.x; t < S * b; t += 256) sw[t] = (mats < 0 || !colsum_m) ? 0.0 : wm[t] * (double)colsum_fold(colsum_m, t);
    __syncthreads();
    if ((int)threadIdx.x < b) {
       double o = 0.0;
@@ -714,7 +717,9 @@ __global__ __launch_bounds__(256) void k_i8_combine(const double *__restrict__ p
          if (mats == 1) acce = row >= rows_valid ? ones : (eplane ? eplane[row * b + c] : 0.0);
          const double accm = ones - acce;
          double v;
-         if (mean) {
+         if (mats < 0)
+            v = row < rows_valid ? accg : 0.0;
+         else if (mean) {
             const double sdv = sd[row];
             v = (sdv > 1e-9) ? (accg - mean[row] * accm) / sdv : 0.0;
          } else
@@ -862,7 +867,7 @@ size_t gemm_i8_workspace_doubles(uint64_t rows_pad, uint64_t k_pad, int S, int b
 
 template <class C>
 static void launch_i8(const I8Plan &pl, hipStream_t stream, const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm,
-                      uint64_t k_pad, const double *wg, const double *wm, int bw, double *ws, uint64_t rows_pad, int chunks_total, int zb)
+                      uint64_t k_pad, const double *wg, const double *wm, int bw, double *ws, uint64_t rows_pad, int chunks_total, int zb, uint32_t tab1)
 {
    static bool attr_set = false, attr_set2 = false;
    if (!attr_set) {
@@ -876,7 +881,7 @@ static void launch_i8(const I8Plan &pl, hipStream_t stream, const uint8_t *packe
       attr_set2 = true;
    }
    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm_i8<C>), dim3(pl.grid), dim3(256), C::LDS_BYTES + lds_pad, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw,
-                      ws, rows_pad, chunks_total, zb, pl.nA, pl.sB, pl.cpsB, pl.rowB0, pl.rowsB);
+                      ws, rows_pad, chunks_total, zb, pl.nA, pl.sB, pl.cpsB, pl.rowB0, pl.rowsB, tab1);
 }
 
 void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t *Qm, const double *wg, const double *wm,
@@ -884,14 +889,16 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
              uint64_t rows_valid, int mode, const double *eplane /* I8_NO_MISSING kernel + E'Q computed elsewhere, or null */, int b,
              int S, const SliceOp *next_ops /* null, or the two operands whose column maxima the combine should leave */,
              hipStream_t stream, hipEvent_t *gemm_events /* null, or 2 events recorded around the GEMM kernel itself */,
-             hipEvent_t before_combine /* null, or an event the combine must wait for (eplane produced on another stream) */)
+             hipEvent_t before_combine /* null, or an event the combine must wait for (eplane produced on another stream) */,
+             bool e_only /* mode 2 only: the missing-indicator matrix E alone, out = E Q (no statistics, no column sums) */)
 {
    const bool two = (Qg != Qm);
+   if (e_only && (mode != I8_NO_MISSING || two)) throw Error(-1, "gemm_i8: e_only goes with the one-matrix kernel");
    const I8Shape sh = i8_shape(S, b, two, mode);
    const int bw = i8_bw(b); // Q holds gemm_i8_nsc_pad(S, b) rows; rows >= S*b are zero and carry zero weights
    const I8Plan pl = i8_plan(rows_pad, k_pad, sh, bw);
    const int chunks_total = (int)(k_pad / sh.kc);
-#define FPCA_I8_ARGS pl, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws, rows_pad, chunks_total, sh.zb
+#define FPCA_I8_ARGS pl, stream, packed, pitch, Qg, Qm, k_pad, wg, wm, bw, ws, rows_pad, chunks_total, sh.zb, (e_only ? 0x00000100u : 0x00010002u)
    if (gemm_events) (void)hipEventRecord(gemm_events[0], stream);
    if (two && mode == I8_NO_MISSING) throw Error(-1, "gemm_i8: without missing genotypes both matrices share one operand (pass Qm == Qg)");
 #define FPCA_I8_K3(NT_, MODE_) launch_i8<I8Cfg<true, 2, NT_, 4, 1, 256, 1, MODE_>>(FPCA_I8_ARGS)
@@ -967,7 +974,7 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
    if (gemm_events) (void)hipEventRecord(gemm_events[1], stream);
    if (before_combine) (void)hipStreamWaitEvent(stream, before_combine, 0);
    const unsigned blocks = (unsigned)std::min<uint64_t>(1024, (rows_pad + (256 / b) - 1) / (256 / b));
-   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, sh.zb, sh.rows, pl.nA, pl.sB, pl.rowB0, pl.rowsB, rows_pad, rows_valid, mode == I8_NO_MISSING ? 1 : 2, eplane, b, bw, S, wm, colsum_m,
+   hipLaunchKernelGGL(k_i8_combine, dim3(blocks), dim3(256), 0, stream, ws, sh.zb, sh.rows, pl.nA, pl.sB, pl.rowB0, pl.rowsB, rows_pad, rows_valid, e_only ? -1 : mode == I8_NO_MISSING ? 1 : 2, eplane, b, bw, S, wm, colsum_m,
                       mean, sd, out,
                       next_ops ? next_ops[0].rowscale : nullptr, next_ops ? next_ops[0].maxbits : nullptr,
                       next_ops ? next_ops[1].rowscale : nullptr, next_ops ? next_ops[1].maxbits : nullptr);
@@ -1045,6 +1052,8 @@ __global__ __launch_bounds__(256) void k_fill_missing(const uint8_t *__restrict_
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    __shared__ uint32_t wsum[4];
    uint32_t base = ptr[blockIdx.x];
+   if (ptr[blockIdx.x + 1] == base) return; // nothing to list: a record without a missing call -- or one whose missing calls go the
+                                            // dense route (its count was set to zero on purpose, device_ctx.hip ensure_hybrid)
    for (uint64_t q0 = 0; q0 < nq; q0 += 256) {
       const uint64_t q = q0 + threadIdx.x;
       uint32_t m[4] = {0u, 0u, 0u, 0u};
@@ -1109,7 +1118,7 @@ void fill_missing(const uint8_t *packed, size_t pitch, uint64_t ncols, uint64_t 
 template <int B>
 __global__ __launch_bounds__(256) void k_sparse_rows_sum(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
                                                           const double *__restrict__ V, const double *__restrict__ rowscale, uint64_t nrec,
-                                                          uint64_t rows_out, double *__restrict__ out)
+                                                          uint64_t rows_out, double *__restrict__ out, const double *__restrict__ init)
 {
    constexpr int EPW = 64 / B;
    const int lane = threadIdx.x & 63, c = lane % B, e0 = lane / B;
@@ -1137,7 +1146,7 @@ __global__ __launch_bounds__(256) void k_sparse_rows_sum(const uint32_t *__restr
       double a = (a0 + a1) + (a2 + a3);
 #pragma unroll
       for (int o = 32; o >= B; o >>= 1) a += __shfl_down(a, o);
-      if (lane < B) out[r * B + c] = a;
+      if (lane < B) out[r * B + c] = init ? init[r * B + c] + a : a;
    }
 }
 
@@ -1148,7 +1157,7 @@ __global__ __launch_bounds__(256) void k_sparse_rows_sum(const uint32_t *__restr
 template <int B>
 __global__ __launch_bounds__(256) void k_sparse_rows_sum_batched(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
                                                                   const double *__restrict__ V, const double *__restrict__ rowscale,
-                                                                  uint64_t nrec, uint64_t rows_out, double *__restrict__ out)
+                                                                  uint64_t nrec, uint64_t rows_out, double *__restrict__ out, const double *__restrict__ init)
 {
    constexpr int EPW = 64 / B, U = 8;
    const int lane = threadIdx.x & 63, c = lane % B, e0 = lane / B;
@@ -1176,12 +1185,12 @@ __global__ __launch_bounds__(256) void k_sparse_rows_sum_batched(const uint32_t 
       double a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 #pragma unroll
       for (int o = 32; o >= B; o >>= 1) a += __shfl_down(a, o);
-      if (lane < B) out[r * B + c] = a;
+      if (lane < B) out[r * B + c] = init ? init[r * B + c] + a : a;
    }
 }
 
 void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, const double *rowscale, int b, uint64_t nrec,
-                     uint64_t rows_out, double *out, hipStream_t stream)
+                     uint64_t rows_out, double *out, hipStream_t stream, const double *init)
 {
    if (!rows_out) return;
    const unsigned blocks = (unsigned)std::min<uint64_t>(65536, (rows_out + 3) / 4);
@@ -1194,9 +1203,9 @@ void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, 
 #define FPCA_GATHER_CASE(B_)                                                                                                    \
    case B_:                                                                                                                     \
       if (variant == 1)                                                                                                         \
-         hipLaunchKernelGGL(k_sparse_rows_sum<B_>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out); \
+         hipLaunchKernelGGL(k_sparse_rows_sum<B_>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out, init); \
       else                                                                                                                      \
-         hipLaunchKernelGGL(k_sparse_rows_sum_batched<B_>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out); \
+         hipLaunchKernelGGL(k_sparse_rows_sum_batched<B_>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out, init); \
       break;
    switch (b) {
       FPCA_GATHER_CASE(16)
@@ -1205,6 +1214,97 @@ void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, 
    default: throw Error(-1, "sparse_rows_sum: block width must be 16, 32 or 64");
    }
 #undef FPCA_GATHER_CASE
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Helpers of the hybrid missing-indicator route (device_ctx.hip ensure_hybrid): the few SNPs whose missing calls are too many
+// for the sparse gathers get their indicator matrix E on the matrix cores, as a compacted sub-matrix.
+//   gather_packed_rows  dst[r] = src[idx[r]] (records of `pitch` bytes), rows r >= nidx filled with 0xff = "dosage 0, not missing"
+//   patch_missing_rows  in the records idx[r] of `packed`: code 01 (missing) -> 11 (dosage 0): G.M is unchanged, E becomes 0 --
+//                       the view of the matrix whose remaining missing calls the sparse lists hold
+//   scatter_packed_rows packed[idx[r]] = src[r]  (puts the original records back)
+//   gather_scaled_rows  dst[r][c] = V[idx[r]][c] * scale[idx[r]], rows >= nidx zero        (fp64, [.][b])
+//   scatter_rows        dst[idx[r]][c] = src[r][c]
+__global__ __launch_bounds__(256) void k_gather_packed_rows(const uint8_t *__restrict__ src, size_t pitch, const uint32_t *__restrict__ idx,
+                                                             uint32_t nidx, uint8_t *__restrict__ dst)
+{
+   const u4 *s = blockIdx.x < nidx ? reinterpret_cast<const u4 *>(src + (size_t)idx[blockIdx.x] * pitch) : nullptr;
+   u4 *d = reinterpret_cast<u4 *>(dst + (size_t)blockIdx.x * pitch);
+   const u4 fill = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+   for (size_t i = threadIdx.x; i < pitch / 16; i += 256) d[i] = s ? s[i] : fill;
+}
+__global__ __launch_bounds__(256) void k_patch_missing_rows(uint8_t *__restrict__ packed, size_t pitch, const uint32_t *__restrict__ idx)
+{
+   u4 *row = reinterpret_cast<u4 *>(packed + (size_t)idx[blockIdx.x] * pitch);
+   for (size_t i = threadIdx.x; i < pitch / 16; i += 256) {
+      u4 x = row[i];
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[k] |= (x[k] & ~(x[k] >> 1) & 0x55555555u) << 1;
+      row[i] = x;
+   }
+}
+__global__ __launch_bounds__(256) void k_scatter_packed_rows(const uint8_t *__restrict__ src, size_t pitch, const uint32_t *__restrict__ idx,
+                                                              uint8_t *__restrict__ packed)
+{
+   const u4 *s = reinterpret_cast<const u4 *>(src + (size_t)blockIdx.x * pitch);
+   u4 *d = reinterpret_cast<u4 *>(packed + (size_t)idx[blockIdx.x] * pitch);
+   for (size_t i = threadIdx.x; i < pitch / 16; i += 256) d[i] = s[i];
+}
+__global__ __launch_bounds__(256) void k_gather_scaled_rows(const double *__restrict__ V, const double *__restrict__ scale,
+                                                             const uint32_t *__restrict__ idx, uint32_t nidx, uint64_t rows_out, int b,
+                                                             double *__restrict__ dst)
+{
+   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < rows_out * b; i += (uint64_t)gridDim.x * 256) {
+      const uint64_t r = i / b;
+      const int c = (int)(i % b);
+      double v = 0.0;
+      if (r < nidx) {
+         const uint32_t j = idx[r];
+         v = V[(uint64_t)j * b + c] * (scale ? scale[j] : 1.0);
+      }
+      dst[i] = v;
+   }
+}
+__global__ __launch_bounds__(256) void k_scatter_rows(const double *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t nidx, int b,
+                                                       double *__restrict__ dst)
+{
+   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < (uint64_t)nidx * b; i += (uint64_t)gridDim.x * 256) {
+      const uint64_t r = i / b;
+      dst[(uint64_t)idx[r] * b + (i % b)] = src[i];
+   }
+}
+void gather_packed_rows(const uint8_t *src, size_t pitch, const uint32_t *idx, uint32_t nidx, uint32_t rows_out, uint8_t *dst, hipStream_t stream)
+{
+   if (!rows_out) return;
+   hipLaunchKernelGGL(k_gather_packed_rows, dim3(rows_out), dim3(256), 0, stream, src, pitch, idx, nidx, dst);
+   HIP_CHECK_LAUNCH();
+}
+void patch_missing_rows(uint8_t *packed, size_t pitch, const uint32_t *idx, uint32_t nidx, hipStream_t stream)
+{
+   if (!nidx) return;
+   hipLaunchKernelGGL(k_patch_missing_rows, dim3(nidx), dim3(256), 0, stream, packed, pitch, idx);
+   HIP_CHECK_LAUNCH();
+}
+void scatter_packed_rows(const uint8_t *src, size_t pitch, const uint32_t *idx, uint32_t nidx, uint8_t *packed, hipStream_t stream)
+{
+   if (!nidx) return;
+   hipLaunchKernelGGL(k_scatter_packed_rows, dim3(nidx), dim3(256), 0, stream, src, pitch, idx, packed);
+   HIP_CHECK_LAUNCH();
+}
+void gather_scaled_rows(const double *V, const double *scale, const uint32_t *idx, uint32_t nidx, uint64_t rows_out, int b, double *dst,
+                        hipStream_t stream)
+{
+   if (!rows_out) return;
+   const unsigned blocks = (unsigned)std::min<uint64_t>(4096, (rows_out * b + 255) / 256);
+   hipLaunchKernelGGL(k_gather_scaled_rows, dim3(blocks), dim3(256), 0, stream, V, scale, idx, nidx, rows_out, b, dst);
+   HIP_CHECK_LAUNCH();
+}
+void scatter_rows(const double *src, const uint32_t *idx, uint32_t nidx, int b, double *dst, hipStream_t stream)
+{
+   if (!nidx) return;
+   const unsigned blocks = (unsigned)std::min<uint64_t>(4096, ((uint64_t)nidx * b + 255) / 256);
+   hipLaunchKernelGGL(k_scatter_rows, dim3(blocks), dim3(256), 0, stream, src, idx, nidx, b, dst);
    HIP_CHECK_LAUNCH();
 }
 

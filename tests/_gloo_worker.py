@@ -21,6 +21,8 @@ from tests.test_host_solver import hostsim  # noqa: E402
 def main():
     bed, fam, k, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     replicated = len(sys.argv) > 5 and sys.argv[5] == "replicated"  # round 2's scheme: whole blocks everywhere, one all-reduce per apply
+    cheap_bits = int(sys.argv[6]) if len(sys.argv) > 6 else 0       # > 0: the backend offers cheap passes (mixed-precision solver)
+    tol = float(sys.argv[7]) if len(sys.argv) > 7 else 1e-8
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     N = O.count_fam_rows(fam)
@@ -52,16 +54,16 @@ def main():
     Px = np.zeros((N, k), order="F")
     pve = np.zeros(k)
     tr = C.c_double()
-    info = (C.c_int * 4)()
-    rc = L.hostsim_pca(d.h, k, 0, 500, 1e-8, 2, 0, 1, 0, P_total, allreduce, None, U.ctypes.data, dv.ctypes.data,
-                       Px.ctypes.data, pve.ctypes.data, C.byref(tr), info, 1 if replicated else world, rank)
+    info = (C.c_int * 6)()
+    rc = L.hostsim_pca2(d.h, k, 0, 500, tol, 2, 0, 1, 0, P_total, allreduce, None, U.ctypes.data, dv.ctypes.data,
+                        Px.ctypes.data, pve.ctypes.data, C.byref(tr), info, 1 if replicated else world, rank, cheap_bits)
     # every rank must hold the same answer (replicated host algebra, deterministic)
     t = torch.from_numpy(dv.copy())
     gathered = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(gathered, t)
     same = all(torch.equal(gathered[0], g) for g in gathered)
     if rank == 0:
-        json.dump(dict(rc=rc, d=dv.tolist(), pve=pve.tolist(), trace=tr.value, applies=info[1], b=info[3], same=same,
+        json.dump(dict(rc=rc, d=dv.tolist(), pve=pve.tolist(), trace=tr.value, applies=info[1], b=info[3], same=same, cheap_applies=info[4],
                        allreduce_calls=calls["n"], allreduce_elems=calls["elems"], small_calls=calls["small"],
                        small_elems=calls["small_elems"], shard=[lo, hi], P_total=P_total, N=N,
                        U0=U[:, 0].tolist(), Ulast=U[:, k - 1].tolist()), open(out_path, "w"))

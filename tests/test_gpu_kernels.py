@@ -285,6 +285,100 @@ def test_i8_slicing_extreme_columns(golden_dir, S, fp, orc):
     assert np.all(np.isfinite(T))
 
 
+@pytest.mark.parametrize("S", [7, 5])
+@pytest.mark.parametrize("preloaded", [False, True])
+def test_i8_slicing_extreme_columns_k3_side(S, preloaded, fp, orc):
+    """The K3 twin of the test above: Y = X T where the int8 operands are T / sd and mean T / sd (kernels_i8.hip k_slice with a
+    per-ROW scale) -- T columns at the ends of the double range / zero / single-entry / constant / alternating, AND rows whose
+    scale 1/sd spans orders of magnitude: the rare-variant spectrum of the realistic generator (sd 0.03 .. 0.71, singletons and
+    SNPs monomorphic in this sample -> zero rows, data.cpp:299-320), and, preloaded (data.cpp:293-297, the --project route:
+    dense missing-indicator kernels), sd from 1e-4 to 1 with means anywhere in [0, 2].  Against the oracle's dense matrix,
+    column by column, each with its own relative accuracy."""
+    N, P, b = 3001, 2000, 16
+    rng = np.random.default_rng(100 + S)
+    with fp.Context.synthetic(N, P, n_pop=5, realistic=True, accum="fp64") as gen:
+        packed = gen.download_packed().reshape(P, -1).copy()
+    packed[7, :] = 0xFF   # a SNP that is monomorphic in this sample (every dosage 0): sd = 0 -> a zero column (data.cpp:299-320)
+    packed[11, :] = 0x55  # ... and one with every call missing (mean = NaN)
+    packed = packed.reshape(-1)
+    with fp.Context.from_packed(packed, N, P, accum="i8x%d" % S) as ctx:
+        od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+        if preloaded:
+            ms = np.column_stack([rng.uniform(0.0, 2.0, P), 10.0 ** rng.uniform(-4, 0, P)])
+            ms[:5, 1] = [1e-4, 1.0, 3e-4, 0.5, 1e-3]
+            od.set_preloaded_meansd(ms)
+            ctx.set_meansd(ms)
+        X = od.dense()
+        if not preloaded:
+            sd = od.meansd()[:, 1]
+            assert np.sum(~(sd > 1e-9)) >= 2 and np.nanmin(sd[sd > 1e-9]) < 0.05 and np.nanmax(sd) > 0.69  # the spread this test is about
+        T = rng.standard_normal((P, b))
+        T[:, 0] *= 1e-290
+        T[:, 1] *= 1e280
+        T[:, 2] = 0.0
+        T[:, 3] = 0.0
+        T[P // 3, 3] = -3.75
+        T[:, 4] = 0.999999999999
+        T[:, 5] = -np.abs(T[:, 5]) - 1.0
+        T[:, 6] = np.where(np.arange(P) % 2 == 0, 1.0, -1.0) * (2.0 - 2.0 ** -52)
+        T[:, 7] *= 2.0 ** -1000
+        Y = ctx.apply_x(T)
+        assert ctx.missing_mode(b) == (0 if preloaded else 4)  # preloaded statistics: two-matrix kernels; else the hybrid route
+    Y_ref = X @ T
+    # what the integer path rounds is T / sd and mean T / sd, each entry by at most 2^-(8S-1) of ITS operand's column maximum;
+    # pushed through the integer matrices (dosage <= 2, indicator <= 1, P terms per row) that bounds the error of a row by
+    # 2^-(8S-1) P (2 max|T/sd| + max|mean T/sd|); the numpy reference adds its own ~P eps of |X| |T|
+    msd = od.meansd()
+    isd = np.where(msd[:, 1] > 1e-9, 1.0 / np.where(msd[:, 1] > 1e-9, msd[:, 1], 1.0), 0.0)
+    with np.errstate(under="ignore", over="ignore"):
+        for c in range(b):
+            tg, tm = np.abs(T[:, c]) * isd, np.abs(T[:, c]) * isd * np.abs(msd[:, 0])
+            bound = 2.0 ** -(8 * S - 2) * P * (2.0 * tg.max() + tm.max()) + 1e-13 * (np.abs(X) @ np.abs(T[:, c]))
+            err = np.abs(Y[:, c] - Y_ref[:, c])
+            if not np.any(T[:, c]):
+                assert np.all(Y[:, c] == 0.0), c
+            else:
+                assert np.all(err <= bound + 5e-324), (c, float(np.max(err / np.maximum(bound, 1e-300))))
+                # ... and the bound is not vacuous: a column's result is resolved to well below its own scale
+                assert np.max(bound) < 1e-6 * np.max(np.abs(Y_ref[:, c])) * (256.0 ** (7 - S)), c
+    assert np.all(np.isfinite(Y))
+
+
+@pytest.mark.parametrize("S", [7, 4])
+def test_i8_hybrid_missing_route(S, fp, orc):
+    """Missing calls concentrated in few SNPs (the realistic generator: 5 % of the SNPs lose 10-30 % of their calls, the rest
+    <= 0.1 %; ~1 % overall, above the sparse route's break-even): per SNP choice of the route -- the dense SNPs'
+    indicator matrix as a compacted integer GEMM, everybody else's missing calls as sparse gathers, data.cpp:300-320 ([1] -> 0)
+    either way.  All three products at 16 / 32 / 64 columns against the oracle's dense matrix; then a width without a gather
+    kernel (48) on the same context, which must fall back to the two-matrix kernels WITH the plain sample-major copy, and the
+    widths again after that."""
+    N, P = 5003, 3001
+    with fp.Context.synthetic(N, P, n_pop=5, realistic=True, accum="i8x%d" % S) as ctx:
+        packed = ctx.download_packed()
+        od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+        X = od.dense()
+        nmiss = np.sum(X == 0.0, axis=0)  # (includes monomorphic columns; only the spread matters here)
+        assert np.sum(nmiss > 0.05 * N) > 0.02 * P and np.median(nmiss) < 0.005 * N
+        rng = np.random.default_rng(S)
+        tol = 1e-11 if S == 7 else 1e-7  # (S = 4: 30-bit operands, rounded once per operand and stage)
+        fell_back = False
+        for b in (16, 32, 64, 48, 16):
+            B = rng.standard_normal((N, b))
+            Tin = rng.standard_normal((P, b))
+            fell_back = fell_back or b == 48
+            mode = ctx.missing_mode(b)
+            assert mode == (0 if fell_back else 4), (b, mode)
+            Z, T, Y = ctx.apply_xxt(B), ctx.apply_xt(B), ctx.apply_x(Tin)
+            Zr, Tr, Yr = X @ (X.T @ B), X.T @ B, X @ Tin
+            assert np.max(np.abs(Z - Zr)) <= tol * np.max(np.abs(Zr)), (b, mode)
+            assert np.max(np.abs(T - Tr)) <= tol * np.max(np.abs(Tr)), (b, mode)
+            assert np.max(np.abs(Y - Yr)) <= tol * np.max(np.abs(Yr)), (b, mode)
+        assert ctx.missing_mode(16) == 0  # after the fallback the context stays on the dense route
+        ms, tr = ctx.stats()
+        assert np.array_equal(ms, od.meansd(), equal_nan=True)
+        assert np.array_equal(ctx.download_packed(), packed)  # the records whose missing calls were masked are back, bit for bit
+
+
 @pytest.mark.parametrize("N,P", [(1, 3), (5, 7), (257, 300), (2051, 129)])
 def test_i8_mode_ragged_shapes(N, P, fp, orc):
     rng = np.random.default_rng(N * 1000 + P)

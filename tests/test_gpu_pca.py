@@ -536,3 +536,60 @@ def test_config2_slow_spectrum_oracle_solve(fp, orc):
     assert abs(r["info"]["trace"] - ref["trace"]) <= 1e-12 * ref["trace"]
     for c in range(3):  # the three structured pairs are isolated: eigenvectors up to sign
         assert abs(abs(ref["U"][:, c] @ r["U"][:, c]) - 1.0) < 1e-8, c
+
+
+def test_config2_realistic_data_oracle_solve(fp, orc):
+    """50,000 x 20,000, k = 20 on the REALISTIC profile (synth.hpp: rare-variant allele-frequency spectrum -- per-SNP sd over a
+    16x range --, missing calls concentrated in 5 % of the SNPs at 10-30 %, 10 sub-populations = 9 structured eigenvalues and 11
+    in the bulk): the whole problem solved by the restated reference (data.cpp:257-322 statistics with the mean over non-missing
+    calls, Spectra-style IRLM) and by the GPU in the default arithmetic with its default mixed-precision solver.  Eigenvalues,
+    pve, trace, the per-SNP statistics bit for bit, the reference's --check quantity on the GPU's pairs."""
+    N, P, k = 50000, 20000, 20
+    with fp.Context.synthetic(N, P, n_pop=10, realistic=True, accum="auto") as ctx:
+        packed = ctx.download_packed()
+        r = ctx.pca(ndim=k)
+        assert r["info"]["converged"] == 1
+        err, mse, rmse = ctx.check(r["U"], r["d"])
+        assert np.all(np.sqrt(err) <= 1.01e-6 * r["d"])
+        rex = ctx.pca(ndim=k, mixed=-1)  # every pass exact: the cheap passes must not have moved anything
+        assert np.max(np.abs(r["d"] - rex["d"]) / rex["d"]) < 1e-9
+    od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+    ref = orc.pca_fast(od, k, tol=1e-6, nthreads=orc.host_threads())
+    assert np.array_equal(r["meansd"], od.meansd(), equal_nan=True)  # (the oracle's statistics exist after its first pass)
+    sd = od.meansd()[:, 1]
+    assert np.nanmin(sd[sd > 1e-9]) < 0.06 and np.mean(sd < 0.3) > 0.3  # (the spectrum the profile promises)
+    rel = np.abs(r["d"] - ref["d"]) / ref["d"]
+    assert np.max(rel) < 1e-6, rel
+    assert np.max(np.abs(r["pve"] - ref["pve"])) < 1e-9
+    assert abs(r["info"]["trace"] - ref["trace"]) <= 1e-12 * ref["trace"]
+    for c in range(5):
+        assert abs(abs(ref["U"][:, c] @ r["U"][:, c]) - 1.0) < 1e-7, c
+
+
+def test_config3_realistic_data_oracle_columns(fp, orc):
+    """500,000 x 100,000 on the realistic profile: one operator column, X'b and X t against the oracle over all 100,000 SNPs
+    (rare variants: K3's row scales 1/sd up to ~30; concentrated missingness: 5 % of the SNPs lose 10-30 % of their calls),
+    statistics bit-equal, the default solve judged by the oracle's residual on the first and the k-th pair."""
+    N, P, k = 500000, 100000, 20
+    nt = orc.host_threads()
+    rng = np.random.default_rng(7)
+    with fp.Context.synthetic(N, P, n_pop=10, realistic=True, accum="auto") as ctx:
+        packed = ctx.download_packed()
+        od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+        op = orc.OracleOp(od, 1000, nthreads=nt)
+        b1 = rng.standard_normal((N, 1))
+        t1 = rng.standard_normal((P, 1))
+        y = op.perform_op(np.ascontiguousarray(b1[:, 0]))
+        assert np.max(np.abs(ctx.apply_xxt(b1)[:, 0] - y)) <= 1e-11 * np.max(np.abs(y))
+        t = op.crossprod(np.ascontiguousarray(b1[:, 0]))
+        assert np.max(np.abs(ctx.apply_xt(b1)[:, 0] - t)) <= 1e-11 * np.max(np.abs(t))
+        y = op.prod(np.ascontiguousarray(t1[:, 0]))
+        assert np.max(np.abs(ctx.apply_x(t1)[:, 0] - y)) <= 1e-11 * np.max(np.abs(y))
+        r = ctx.pca(ndim=k)
+        assert r["info"]["converged"] == 1
+        assert np.array_equal(r["meansd"], od.meansd(), equal_nan=True)
+        for c in (0, k - 1):
+            u = np.ascontiguousarray(r["U"][:, c])
+            res = np.linalg.norm(op.perform_op(u) / P - r["d"][c] * u)
+            assert res <= 1e-6 * r["d"][c], (c, res, r["d"][c])
+

@@ -22,13 +22,13 @@ def free_port():
     return p
 
 
-def run_world(world, bed, fam, k, out, mode):
+def run_world(world, bed, fam, k, out, mode, extra=()):
     port = free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), bed, fam, str(k), out, mode],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), bed, fam, str(k), out, mode] + [str(x) for x in extra],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
@@ -94,3 +94,23 @@ def test_sharded_pca_matches_golden(golden_dir, tmp_path, world, k, mode):
         assert r["allreduce_calls"] == 2 * r["applies"] + kb and r["allreduce_elems"] == (2 * r["applies"] + kb) * nb
         assert r["small_calls"] >= 3 * r["applies"] + 3
         assert r["small_elems"] <= (3 * r["applies"] + 8) * (r["applies"] + 1) * r["b"] ** 2 + 1
+
+
+@pytest.mark.parametrize("world,mode", [(2, "rowshard"), (3, "rowshard"), (2, "replicated")])
+def test_sharded_mixed_precision_solver(golden_dir, tmp_path, world, mode):
+    """The mixed-precision solver with several ranks (k = 30 at tol 1e-6 on data_chr1: slow enough for cheap passes): every decision
+    -- exact -> cheap passes, the verification through the exact operator, its verdict -- is taken from Ritz data that is
+    identical on all ranks, so the ranks walk through the same sequence of collectives; the answer is the dense one."""
+    from oracle import oracle as O
+
+    name, k = "data_chr1", 30
+    bed, fam = os.path.join(golden_dir, name + ".bed"), os.path.join(golden_dir, name + ".fam")
+    r = run_world(world, bed, fam, k, str(tmp_path / "res.json"), mode, extra=(30, 1e-6))
+    assert r["rc"] == 0 and r["same"]
+    assert 0 < r["cheap_applies"] < r["applies"]
+    N = O.count_fam_rows(fam)
+    d = O.OracleData(bed, N, "binom2")
+    X = d.dense()
+    w = np.linalg.eigvalsh(X @ X.T)[::-1][:k] / d.P
+    assert np.max(np.abs(np.array(r["d"]) - w) / w) < 1e-9
+
