@@ -1,10 +1,14 @@
 // common.hpp -- shared constants and error plumbing for libfpca (MI355X / gfx950 only).
 #pragma once
+#include <sched.h>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 namespace fpca {
 
@@ -39,5 +43,37 @@ struct Error : std::runtime_error {
 };
 
 void set_last_error(const std::string &msg);
+
+// CPUs this process may actually run on at once: hardware threads, affinity mask and cgroup CPU quota (a container on a
+// 256-thread host may own 16 of them; 256 threads against that quota only queue up).  Sizes every helper-thread pool of
+// the library (pinned-download scatter, .bed readers) and of the CLI (text writers).
+inline unsigned usable_cpus()
+{
+   unsigned n = std::thread::hardware_concurrency();
+   if (n == 0) n = 1;
+   cpu_set_t set;
+   if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+      const unsigned a = (unsigned)CPU_COUNT(&set);
+      if (a >= 1 && a < n) n = a;
+   }
+   {
+      std::ifstream f("/sys/fs/cgroup/cpu.max"); // cgroup v2: "<quota|max> <period>"
+      std::string q;
+      long long per = 0;
+      if (f >> q >> per && q != "max" && per > 0) {
+         const long long c = std::atoll(q.c_str()) / per;
+         if (c >= 1 && (unsigned)c < n) n = (unsigned)c;
+      }
+   }
+   {
+      std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us"); // cgroup v1
+      long long q = 0, per = 0;
+      if (fq >> q && fp >> per && q > 0 && per > 0) {
+         const long long c = q / per;
+         if (c >= 1 && (unsigned)c < n) n = (unsigned)c;
+      }
+   }
+   return n;
+}
 
 } // namespace fpca

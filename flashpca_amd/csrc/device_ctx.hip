@@ -14,6 +14,8 @@
 #include <cstring>
 #include <string>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -317,7 +319,25 @@ void ctx_alloc_common(fpca_ctx *c, uint64_t N, uint64_t P_g, int stand, int devi
       HIP_CHECK(hipMalloc(&c->d_Xd, (size_t)c->P_pad * c->N_pad * sizeof(double)));
       HIP_CHECK(hipMemsetAsync(c->d_Xd, 0, (size_t)c->P_pad * c->N_pad * sizeof(double), c->stream));
    } else {
-      HIP_CHECK(hipMalloc(&c->d_packed, c->pitch * c->P_pad));
+      // The matrix is RESIDENT (the reference streams any size from disk, svdwide.h:57-68): if it does not fit, say what would
+      const size_t need = c->pitch * c->P_pad;
+      const hipError_t e = hipMalloc(&c->d_packed, need);
+      if (e == hipErrorOutOfMemory) {
+         (void)hipGetLastError();
+         size_t fr = 0, tot = 0;
+         (void)hipMemGetInfo(&fr, &tot);
+         const double gb = 1.0 / (1024.0 * 1024.0 * 1024.0);
+         const int g1 = (int)std::ceil((double)need * 1.05 / std::max<double>((double)fr, 1.0)), g2 = (int)std::ceil((double)need * 2.1 / std::max<double>((double)fr, 1.0));
+         char msg[640];
+         std::snprintf(msg, sizeof(msg),
+                       "the packed genotypes of this shard need %.1f GiB of device memory (%llu samples x %llu SNPs at 2 bits), %.1f of %.1f GiB are free "
+                       "on device %d.  What fits: the SNPs sharded over at least %d GPUs (--gpus %d; %d for the default exact-integer arithmetic, "
+                       "which keeps a second, sample-major copy -- --accum fp64 does not)",
+                       (double)need * gb, (unsigned long long)N, (unsigned long long)P_g, (double)fr * gb, (double)tot * gb, device, std::max(g1, 2),
+                       std::max(g1, 2), std::max(g2, 2));
+         throw Error(FPCA_ENOMEM, msg);
+      }
+      if (e != hipSuccess) throw Error(FPCA_EHIP, std::string("hipMalloc of the packed genotypes failed: ") + hipGetErrorString(e));
       HIP_CHECK(hipMemsetAsync(c->d_packed, PAD_BYTE, c->pitch * c->P_pad, c->stream));
    }
    lap("hipMalloc packed + memset");
@@ -426,6 +446,18 @@ bool ensure_i8(fpca_ctx *c, int b)
       ensure_i8_alloc(c, b);
       return true;
    } catch (const Error &e) {
+      if (!c->i8_auto && e.code == FPCA_ENOMEM) { // asked for explicitly: no silent change of arithmetic -- say what would fit
+         size_t fr = 0, tot = 0;
+         (void)hipMemGetInfo(&fr, &tot);
+         const double gb = 1.0 / (1024.0 * 1024.0 * 1024.0), copy = (double)c->N_pad * (double)c->P_pad / 4.0;
+         char msg[640];
+         std::snprintf(msg, sizeof(msg),
+                       "the exact-integer arithmetic needs a second, sample-major copy of the packed genotypes (%.1f GiB) and its int8 operands; %.1f "
+                       "of %.1f GiB are free (%s).  What fits: --accum auto (falls back to the fp64 kernels, which need no second copy: same "
+                       "results, ~4x slower), --accum fp64, or the SNPs sharded over more GPUs (--gpus)",
+                       copy * gb, (double)fr * gb, (double)tot * gb, e.what());
+         throw Error(FPCA_ENOMEM, msg);
+      }
       if (!c->i8_auto || e.code != FPCA_ENOMEM) throw; // only "does not fit"; a kernel or launch failure is not masked
       (void)hipGetLastError();
       std::fprintf(stderr, "[fpca] exact-integer mode needs more device memory than is free (%s); using the fp64 kernels\n", e.what());
@@ -1114,41 +1146,72 @@ void staged_download(fpca_ctx *c_, const double *d_img, uint64_t N, int ncols, d
    for (hipEvent_t &e : c_->dl_ev)
       if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
    const size_t nch = (total + CH - 1) / CH;
-   const int T = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-   std::atomic<size_t> ready(0); // pieces [0, ready) have landed in their slots
-   std::vector<std::atomic<int>> done(nch);
-   for (auto &x : done) x.store(0);
+   // helper threads: only for results of three pieces and more (24 MB: below that the copies are over before a thread has
+   // started), as many as this process may run at once (cgroup quota / affinity, not the host's hardware threads), at most 8;
+   // they sleep on a condition variable until their piece has landed -- no spinning beside the thread that issues the copies
+   static const unsigned cpus = usable_cpus();
+   const int T = nch >= 3 ? (int)std::max(1u, std::min(8u, cpus > 1 ? cpus - 1 : 1u)) : 0;
+   if (T == 0) {
+      for (size_t c = 0; c < nch; c++) {
+         const size_t c0 = c * CH, len = std::min(CH, total - c0);
+         HIP_CHECK(hipMemcpyAsync(c_->dl_pin, d_img + c0, len * sizeof(double), hipMemcpyDeviceToHost, c_->stream));
+         HIP_CHECK(hipStreamSynchronize(c_->stream));
+         scatter(c0, c0 + len, pin);
+      }
+      return;
+   }
+   std::mutex mu;
+   std::condition_variable cv_ready, cv_done;
+   size_t ready = 0;                  // pieces [0, ready) have landed in their slots      (under mu)
+   std::vector<int> done(nch, 0);     // workers finished with piece c                      (under mu)
    std::vector<std::thread> workers;
    for (int t = 0; t < T; t++)
       workers.emplace_back([&, t] {
          for (size_t c = 0; c < nch; c++) {
-            while (ready.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+            {
+               std::unique_lock<std::mutex> lk(mu);
+               cv_ready.wait(lk, [&] { return ready > c; });
+            }
             const size_t c0 = c * CH, len = std::min(CH, total - c0);
             const size_t lo = c0 + len * t / T, hi = c0 + len * (t + 1) / T;
             scatter(lo, hi, pin + (c % DL_SLOTS) * CH + (lo - c0));
-            done[c].fetch_add(1, std::memory_order_release);
+            bool last;
+            {
+               std::lock_guard<std::mutex> lk(mu);
+               last = ++done[c] == T;
+            }
+            if (last) cv_done.notify_one();
          }
       });
+   auto publish = [&](size_t upto) {
+      {
+         std::lock_guard<std::mutex> lk(mu);
+         ready = upto;
+      }
+      cv_ready.notify_all();
+   };
    try {
       for (size_t c = 0; c < nch; c++) {
          const size_t slot = c % DL_SLOTS, c0 = c * CH, len = std::min(CH, total - c0);
-         if (c >= DL_SLOTS)
-            while (done[c - DL_SLOTS].load(std::memory_order_acquire) < T) std::this_thread::yield();
+         if (c >= DL_SLOTS) { // the slot's previous piece has been scattered by every worker
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return done[c - DL_SLOTS] == T; });
+         }
          HIP_CHECK(hipMemcpyAsync(static_cast<char *>(c_->dl_pin) + slot * DL_CHUNK, d_img + c0, len * sizeof(double), hipMemcpyDeviceToHost,
                                   c_->stream));
          HIP_CHECK(hipEventRecord(c_->dl_ev[slot], c_->stream));
          if (c >= 1) {
             HIP_CHECK(hipEventSynchronize(c_->dl_ev[(c - 1) % DL_SLOTS]));
-            ready.store(c, std::memory_order_release);
+            publish(c);
          }
       }
       HIP_CHECK(hipEventSynchronize(c_->dl_ev[(nch - 1) % DL_SLOTS]));
    } catch (...) {
-      ready.store(nch, std::memory_order_release); // let the workers run out (what they copy is discarded with the error)
+      publish(nch); // let the workers run out (what they copy is discarded with the error)
       for (auto &w : workers) w.join();
       throw;
    }
-   ready.store(nch, std::memory_order_release);
+   publish(nch);
    for (auto &w : workers) w.join();
 }
 
@@ -1537,7 +1600,7 @@ namespace {
 // PCIe link takes; 16 threads reading disjoint slices of the chunk reach 17-23 GB/s (measured on the overlay file system of the test box).
 bool parallel_pread(int fd, uint8_t *buf, uint64_t want, off_t off)
 {
-   const unsigned hw = std::thread::hardware_concurrency();
+   static const unsigned hw = usable_cpus(); // (the CPUs this process may run on at once, not the host's hardware threads)
    static const int cap = getenv("FPCA_READ_THREADS") ? std::max(1, atoi(getenv("FPCA_READ_THREADS"))) : 16;
    const int nt = want < (8u << 20) ? 1 : (int)std::min<unsigned>((unsigned)cap, hw ? hw : 1);
    std::atomic<bool> ok(true);

@@ -169,35 +169,6 @@ uint64_t read_fam(const std::string &filename, std::vector<std::string> &fam_ids
    return i;
 }
 
-unsigned usable_cpus()
-{
-   unsigned n = std::thread::hardware_concurrency();
-   if (n == 0) n = 1;
-   cpu_set_t set;
-   if (sched_getaffinity(0, sizeof(set), &set) == 0) {
-      const unsigned a = (unsigned)CPU_COUNT(&set);
-      if (a >= 1 && a < n) n = a;
-   }
-   {
-      std::ifstream f("/sys/fs/cgroup/cpu.max"); // cgroup v2: "<quota|max> <period>"
-      std::string q;
-      long long per = 0;
-      if (f >> q >> per && q != "max" && per > 0) {
-         const long long c = std::atoll(q.c_str()) / per;
-         if (c >= 1 && (unsigned)c < n) n = (unsigned)c;
-      }
-   }
-   {
-      std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us"); // cgroup v1
-      long long q = 0, per = 0;
-      if (fq >> q && fp >> per && q > 0 && per > 0) {
-         const long long c = q / per;
-         if (c >= 1 && (unsigned)c < n) n = (unsigned)c;
-      }
-   }
-   return n;
-}
-
 void read_plink_fam(const std::string &filename, std::vector<std::string> &fam_ids, std::vector<std::string> &indiv_ids)
 {
    std::ifstream in(filename, std::ios::in);
@@ -267,7 +238,9 @@ namespace {
 void format_rows(const double *M, uint64_t rows, uint64_t cols, const std::vector<std::string> &rownames, uint64_t r0,
                  uint64_t r1, unsigned precision, std::string &out)
 {
-   const size_t numw = (size_t)std::max(32u, precision + 10u);
+   // (a double has at most 767 significant decimal digits -- the smallest denormal -- so %.{p}g never writes more than
+   //  min(p, 767) + 8 characters whatever --precision says)
+   const size_t numw = (size_t)std::max(32u, std::min(precision, 767u) + 10u);
    size_t bound = 0;
    for (uint64_t j = r0; j < r1; j++) bound += (rownames.empty() ? 0 : rownames[j].size() + 1) + cols * (numw + 1) + 1;
    out.resize(bound);
@@ -317,7 +290,10 @@ bool save_text(const double *M, uint64_t rows, uint64_t cols, const std::vector<
       header += (i == colnames.size() - 1) ? "\n" : "\t";
    }
    out.write(header.data(), (std::streamsize)header.size());
-   const uint64_t chunk = 4096;
+   // rows per chunk: 4096 at ordinary precisions; fewer when --precision asks for numbers hundreds of characters wide, so that
+   // the 2 T chunk buffers (worst-case sized, see format_rows) stay around 8 MB each whatever the precision
+   const uint64_t numw = std::max<uint64_t>(32, std::min<uint64_t>(precision, 767) + 10);
+   const uint64_t chunk = std::max<uint64_t>(16, std::min<uint64_t>(4096, (8ull << 20) / std::max<uint64_t>(1, cols * (numw + 1))));
    const uint64_t nchunks = (rows + chunk - 1) / chunk;
    uint64_t T = max_threads ? max_threads : usable_cpus();
    if (T > 32) T = 32;

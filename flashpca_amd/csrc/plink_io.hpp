@@ -1,6 +1,7 @@
 // plink_io.hpp -- text-side I/O of the flashpca drop-in CLI: .fam/.bim readers, the whitespace matrix reader used by
 // --check / --project, and the tab-separated writers (byte-compatible with the reference's save_text).
 #pragma once
+#include "common.hpp"
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -31,9 +32,7 @@ std::vector<double> read_maf(const std::string &filename, const std::vector<std:
 // 504-586) -- and read_plink_fam's two id columns (data.cpp:639-672); same errors as the two calls in that order.
 uint64_t read_fam(const std::string &filename, std::vector<std::string> &fam_ids, std::vector<std::string> &indiv_ids);
 
-// CPUs this process may actually run on at once: hardware threads, affinity mask and cgroup CPU quota (a container on a
-// 256-thread host may own 16 of them; 256 threads against that quota only queue up)
-unsigned usable_cpus();
+// (usable_cpus(): common.hpp -- the library sizes its own helper threads with it too)
 
 // save_text (util.h:69-108): header line (if colnames non-empty), then per row  [rowname TAB] v1 TAB v2 ...
 // numbers through operator<< with std::setprecision(precision).  M is column-major rows x cols (ld = rows).
