@@ -51,6 +51,11 @@ class BlockBackend {
 
    // out = sum over ranks g of X_g X_g' in    (K2 + K3 + all-reduce); in != out
    virtual void apply(int in, int out) = 0;
+   // The same in two halves, for a backend that can run the operator while the caller does something else: apply_begin
+   // enqueues it, apply_end waits for it (at most one apply in flight).  The solver launches the next pass before it solves
+   // the projected eigenproblem of the current one whenever that test is unlikely to end the iteration.
+   virtual void apply_begin(int in, int out) { apply(in, out); }
+   virtual void apply_end() {}
    // Arithmetic of the following apply() calls: cheap = the backend's reduced-precision passes (exact-integer mode: fewer
    // byte slices of the fp64 operand), else its exact ones.  Returns false -- and changes nothing -- when the backend has
    // no cheaper arithmetic than the one it runs; the solver then never asks again.

@@ -1160,43 +1160,45 @@ void staged_download(fpca_ctx *c_, const double *d_img, uint64_t N, int ncols, d
       }
       return;
    }
+   // (waiting = a short spin on an atomic -- a piece lands every ~150 us, and with T <= cpus - 1 helpers every thread has a CPU
+   //  of its own -- then a sleep on the condition variable: nobody spins through a stall of the copy engine or a descheduled peer)
    std::mutex mu;
    std::condition_variable cv_ready, cv_done;
-   size_t ready = 0;                  // pieces [0, ready) have landed in their slots      (under mu)
-   std::vector<int> done(nch, 0);     // workers finished with piece c                      (under mu)
+   std::atomic<size_t> ready(0);              // pieces [0, ready) have landed in their slots
+   std::vector<std::atomic<int>> done(nch);   // workers finished with piece c
+   for (auto &x : done) x.store(0);
+   auto wait_for = [&](std::condition_variable &cv, auto &&pred) {
+      for (int spin = 0; spin < 4000; spin++) {
+         if (pred()) return;
+         __builtin_ia32_pause();
+      }
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, pred);
+   };
    std::vector<std::thread> workers;
    for (int t = 0; t < T; t++)
       workers.emplace_back([&, t] {
          for (size_t c = 0; c < nch; c++) {
-            {
-               std::unique_lock<std::mutex> lk(mu);
-               cv_ready.wait(lk, [&] { return ready > c; });
-            }
+            wait_for(cv_ready, [&] { return ready.load(std::memory_order_acquire) > c; });
             const size_t c0 = c * CH, len = std::min(CH, total - c0);
             const size_t lo = c0 + len * t / T, hi = c0 + len * (t + 1) / T;
             scatter(lo, hi, pin + (c % DL_SLOTS) * CH + (lo - c0));
-            bool last;
-            {
-               std::lock_guard<std::mutex> lk(mu);
-               last = ++done[c] == T;
+            if (done[c].fetch_add(1, std::memory_order_acq_rel) + 1 == T) {
+               { std::lock_guard<std::mutex> lk(mu); } // (pairs with the sleeper's predicate check under the mutex)
+               cv_done.notify_one();
             }
-            if (last) cv_done.notify_one();
          }
       });
    auto publish = [&](size_t upto) {
-      {
-         std::lock_guard<std::mutex> lk(mu);
-         ready = upto;
-      }
+      ready.store(upto, std::memory_order_release);
+      { std::lock_guard<std::mutex> lk(mu); }
       cv_ready.notify_all();
    };
    try {
       for (size_t c = 0; c < nch; c++) {
          const size_t slot = c % DL_SLOTS, c0 = c * CH, len = std::min(CH, total - c0);
-         if (c >= DL_SLOTS) { // the slot's previous piece has been scattered by every worker
-            std::unique_lock<std::mutex> lk(mu);
-            cv_done.wait(lk, [&] { return done[c - DL_SLOTS] == T; });
-         }
+         if (c >= DL_SLOTS) // the slot's previous piece has been scattered by every worker
+            wait_for(cv_done, [&] { return done[c - DL_SLOTS].load(std::memory_order_acquire) == T; });
          HIP_CHECK(hipMemcpyAsync(static_cast<char *>(c_->dl_pin) + slot * DL_CHUNK, d_img + c0, len * sizeof(double), hipMemcpyDeviceToHost,
                                   c_->stream));
          HIP_CHECK(hipEventRecord(c_->dl_ev[slot], c_->stream));
@@ -1371,17 +1373,29 @@ class HipBackend : public BlockBackend {
    }
    void apply(int in, int out) override
    {
+      apply_begin(in, out);
+      apply_end();
+   }
+   void apply_begin(int in, int out) override
+   {
       HIP_CHECK(hipEventRecord(e0_, c_->stream));
       if (sharded())
          apply_sharded(c_, sh_, blocks_[in], b_, blocks_[out], c_->stream);
       else
          apply_xxt_dev(c_, blocks_[in], b_, blocks_[out], c_->stream, nullptr);
       HIP_CHECK(hipEventRecord(e1_, c_->stream));
+      inflight_ = true;
+      inflight_exact_ = !c_->i8_Sc;
+   }
+   void apply_end() override
+   {
+      if (!inflight_) return;
+      inflight_ = false;
       HIP_CHECK(hipEventSynchronize(e1_));
       float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, e0_, e1_));
       sec_apply_ += ms * 1e-3;
-      if (!c_->i8_Sc) sec_exact_ += ms * 1e-3;
+      if (inflight_exact_) sec_exact_ += ms * 1e-3;
    }
    bool set_cheap(bool cheap) override
    {
@@ -1511,7 +1525,7 @@ class HipBackend : public BlockBackend {
    size_t &C_cap_, &gpart_cap_;
    void *&h_pin_;
    size_t &pin_cap_;
-   bool pin_busy_ = false;
+   bool pin_busy_ = false, inflight_ = false, inflight_exact_ = false;
    hipEvent_t e0_, e1_, ev_pin_;
    double sec_apply_ = 0, sec_other_ = 0, sec_exact_ = 0;
 };

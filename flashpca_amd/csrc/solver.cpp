@@ -289,15 +289,39 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    int skip_rr = 0; // Rayleigh-Ritz tests to skip (set after a test that ended far from convergence)
    double prev_worst = 0; // worst relative residual of the previous test and the apply count it was made at
    int prev_step = 0;
+   double rho_last = 0;   // decay of the worst residual per pass, measured between the last two tests (0: not known)
+
+   // The pass of the NEXT step is launched before this step's projected eigenproblem is solved whenever that solve is unlikely
+   // to end the iteration (no test at this step, or the last test was far from the threshold): the block it applies -- the
+   // oldest one waiting -- and the block it fills are the same whether this step ends in a push or in a thick restart; only
+   // convergence, the end of the budget or a verification discard it.  pend_*: that pass (in flight on the backend).
+   int pend_in = -1, pend_out = -1;
+   bool pend_cheap = false;
+   auto drop_pending = [&] { // (a pass that ran for nothing is still a pass over the matrix: it is counted)
+      if (pend_out < 0) return;
+      be.apply_end();
+      res.block_applies++;
+      if (pend_cheap) res.cheap_applies++;
+      res.discarded_applies++;
+      be.free_block(pend_out);
+      pend_in = pend_out = -1;
+   };
 
    while (res.block_applies < o.max_applies) {
       const int M = (int)V.size(); // blocks in the basis; V[na] goes through the operator now, W becomes block M
       if (na >= M) throw Error(-3, "solver: internal error (no block waiting)");
       phase(PH_RESTART);
-      be.apply(V[na], W);
+      bool this_cheap = cheap;
+      if (pend_out >= 0) {
+         if (pend_in != V[na] || pend_out != W) throw Error(-3, "solver: internal error (speculative pass on the wrong block)");
+         be.apply_end();
+         this_cheap = pend_cheap;
+         pend_in = pend_out = -1;
+      } else
+         be.apply(V[na], W);
       phase(PH_APPLY);
       res.block_applies++;
-      if (cheap) {
+      if (this_cheap) {
          res.cheap_applies++;
          tainted = true;
       }
@@ -365,22 +389,55 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       update_with(M1);
       phase(PH_SVQB);
 
-      gram_vw();
-      t0 = clk::now();
-      // H += C3 * R1   (C: [q][p][c] row-major b x b per q; R1 column-major)
-      for (int q = 0; q < M; q++)
-         for (int p = 0; p < b; p++) {
-            const double *cr = &C[((size_t)q * b + p) * b];
-            for (int c = 0; c < b; c++) {
-               double sacc = 0;
-               for (int j = 0; j < b; j++) sacc += cr[j] * R1[(size_t)j + (size_t)c * b];
-               H[((size_t)q * b + p) * b + c] += sacc;
+      // The third projection exists because the normalisation of pass 2 amplifies whatever component along V the first two
+      // left behind (~eps of the column's norm BEFORE normalisation) by  max column norm / smallest pivot of the triangular
+      // factor.  When that factor is small -- a well-conditioned block of comparable columns: every step of a slowly
+      // converging solve except the last few -- the amplified component stays below 1e-12 and pass 3 only re-normalises W
+      // (one Gram + one update of W alone instead of the whole basis: a third of the orthogonalisation's traffic).  Decided
+      // from the factor only, i.e. from data every rank holds identically.
+      bool light3 = false;
+      if (ndead == 0) {
+         bool upper = true; // (the Cholesky route of svqb_factor; the eigen route's factor is not triangular)
+         double cmax = 0, pmin = 1e300;
+         for (int c = 0; c < b && upper; c++) {
+            double cn = 0;
+            for (int r = 0; r < b; r++) {
+               const double x = R1[(size_t)r + (size_t)c * b];
+               if (r > c && x != 0.0) upper = false;
+               cn += x * x;
             }
+            cmax = std::max(cmax, std::sqrt(cn));
+            pmin = std::min(pmin, std::fabs(R1[(size_t)c + (size_t)c * b]));
          }
-      minus_ctc();
-      int nd2 = svqb_factor(b, Gw, 0.0, M2, R2, dead2);
-      host_s += since(t0);
-      update_with(M2);
+         light3 = upper && pmin > 0 && cmax / pmin < 1e4;
+      }
+      int nd2;
+      if (light3) {
+         std::vector<double> &G3 = Gw;
+         G3.assign((size_t)b * b, 0.0);
+         be.gram(&W, 1, W, G3.data());
+         t0 = clk::now();
+         nd2 = svqb_factor(b, G3, 0.0, M2, R2, dead2);
+         host_s += since(t0);
+         be.gemm(&W, 1, M2.data(), -1, W);
+      } else {
+         gram_vw();
+         t0 = clk::now();
+         // H += C3 * R1   (C: [q][p][c] row-major b x b per q; R1 column-major)
+         for (int q = 0; q < M; q++)
+            for (int p = 0; p < b; p++) {
+               const double *cr = &C[((size_t)q * b + p) * b];
+               for (int c = 0; c < b; c++) {
+                  double sacc = 0;
+                  for (int j = 0; j < b; j++) sacc += cr[j] * R1[(size_t)j + (size_t)c * b];
+                  H[((size_t)q * b + p) * b + c] += sacc;
+               }
+            }
+         minus_ctc();
+         nd2 = svqb_factor(b, Gw, 0.0, M2, R2, dead2);
+         host_s += since(t0);
+         update_with(M2);
+      }
       phase(PH_SVQB);
       // R = R2 * R1
       matmul(b, b, b, R2.data(), b, R1.data(), b, R.data(), b);
@@ -430,6 +487,23 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          }
       }
 
+      // ---- the next pass, ahead of this step's Rayleigh-Ritz (see pend_* above) ---------------------------------------------
+      {
+         const int na1 = na + 1, Mn1 = M + 1;
+         const bool no_test = ((skip_rr > 0) || (na1 * b < k)) && res.block_applies < o.max_applies && na1 + 1 <= mcap && Mn1 + 1 <= Mmax;
+         const double tol_est = cheap ? tol_cheap : o.tol;
+         // (a test IS due: the worst residual expected at it, from the last test and the decay measured between the last two,
+         //  must still be well above the threshold -- residuals of a fast solve fall by orders of magnitude per pass, and a
+         //  pass launched before the test that ends it is a pass wasted)
+         const double expected = (prev_worst > 0 && rho_last > 0 && rho_last < 1) ? prev_worst * std::pow(rho_last, (double)(res.block_applies - prev_step)) : 0.0;
+         if (res.block_applies + 1 < o.max_applies && (no_test || expected > 30.0 * tol_est)) {
+            pend_in = na1 < M ? V[na1] : W;
+            pend_out = be.alloc_block();
+            pend_cheap = cheap;
+            be.apply_begin(pend_in, pend_out);
+         }
+      }
+
       // ---- projected matrix: column block na of T = V'AV over ALL blocks, and the coupling R of the new block M --------
       phase(PH_RESTART);
       t0 = clk::now();
@@ -466,7 +540,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          host_s += since(t0);
          phase(PH_RR);
          V.push_back(W);
-         W = be.alloc_block();
+         W = pend_out >= 0 ? pend_out : be.alloc_block();
          continue;
       }
       if (n < k) throw Error(-5, "solver: maxiter allows fewer basis vectors than the wanted number of eigenpairs");
@@ -551,6 +625,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          break;
       }
       if (out_of_budget) break;
+      if (verify) drop_pending();
       if (!verify) {
          skip_rr = worst > 1e6 * tol_now ? 2 : worst > 1e3 * tol_now ? 1 : 0;
          // Slowly converging spectra (k reaching into the bulk: 150+ applies) spend their host time in tests that cannot
@@ -560,6 +635,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          double n_est = -1;
          if (prev_worst > 0 && worst < prev_worst && worst > tol_now && res.block_applies > prev_step) {
             const double rho = std::pow(worst / prev_worst, 1.0 / (double)(res.block_applies - prev_step));
+            rho_last = rho;
             if (rho < 1.0 && rho > 0.0) {
                n_est = std::log(tol_now / worst) / std::log(rho);
                const int rate_skip = (int)std::min(8.0, std::max(0.0, std::floor(n_est / 2.0) - 1.0));
@@ -610,6 +686,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          for (int i = 0; i < n; i++) S[(size_t)i + (size_t)i * n] = 1.0;
          skip_rr = 0;
          prev_worst = 0;
+         rho_last = 0;
          keep.n = 0;
          if (o.verbose)
             std::fprintf(stderr, "[fpca] apply %3d: %s; %d Ritz block(s) go through the exact operator\n", res.block_applies,
@@ -647,7 +724,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          V.clear();
          for (int j = 0; j < nk; j++) V.push_back(Y[j]);
          for (int h : waiting) V.push_back(h);
-         W = be.alloc_block();
+         W = pend_out >= 0 ? pend_out : be.alloc_block();
          std::fill(T.begin(), T.end(), 0.0);
          for (int i = 0; i < nk * b; i++) Tat(i, i) = theta[i];
          for (int r = 0; r < nu; r++)
@@ -659,8 +736,12 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          res.restarts++;
       } else {
          V.push_back(W);
-         W = be.alloc_block();
+         W = pend_out >= 0 ? pend_out : be.alloc_block();
       }
+   }
+   if (pend_out >= 0) { // the iteration ended with a pass in flight (convergence, budget): wait for it; its block is not W yet
+      if (pend_out == W) throw Error(-3, "solver: internal error (pending pass owns W)");
+      drop_pending();
    }
 
    // ---- Ritz vectors of the last Rayleigh-Ritz: U_j = V_applied S[:, j b : (j+1) b], j < kb ------------------

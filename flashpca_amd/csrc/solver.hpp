@@ -26,6 +26,7 @@ struct SolverResult {
    int restarts = 0;
    int cheap_applies = 0;        // of block_applies: passes in the backend's cheap arithmetic
    int verifications = 0;        // times the leading Ritz blocks were put through the exact operator after cheap passes
+   int discarded_applies = 0;    // of block_applies: passes launched ahead of a Rayleigh-Ritz test that then ended the iteration
    double max_rel_residual = 0;  // max_i res_i / max(eps^(2/3), |theta_i|)
    double seconds_host = 0;      // projected eigenproblem + small dense algebra
    std::vector<double> evals;    // k eigenvalues of A, descending
