@@ -1,6 +1,6 @@
 # Regenerates the committed profile evidence of a round:  bash scripts/gpu_profile_round.sh r02
 # (run through gpurun; writes under gpurun_out/<round>/, scripts/copy_profiles.sh copies the summaries into profiles/)
-R=${1:-r03}
+R=${1:-r04}
 mkdir -p gpurun_out/$R; export TMPDIR=/tmp
 PMC_SQ="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 Q="--no-cpu-baseline --no-pca-hard --no-e2e"
@@ -8,11 +8,12 @@ Q="--no-cpu-baseline --no-pca-hard --no-e2e"
 # fp64_mode, the CPU baseline and both PCA solves), then the other workloads and the explicit modes
 python bench.py > gpurun_out/$R/bench_cfg3_n1.json 2> gpurun_out/$R/bench_cfg3_n1.err
 python bench.py --workload cfg2 > gpurun_out/$R/bench_cfg2_n1.json 2>/dev/null
-for a in fp64 fp32 i8x6; do
+for a in fp64 fp32 i8x4; do
   python bench.py --workload cfg2 --accum $a $Q --no-alt > gpurun_out/$R/bench_cfg2_n1_$a.json 2>/dev/null
   python bench.py --workload cfg3 --accum $a $Q --no-alt > gpurun_out/$R/bench_cfg3_n1_$a.json 2>/dev/null
 done
 for wl in cfg4shard cfg5shard; do python bench.py --workload $wl $Q > gpurun_out/$R/bench_${wl}_n1.json 2>/dev/null; done
+python bench.py --workload cfg4shard --accum i8x4 $Q --no-alt > gpurun_out/$R/bench_cfg4shard_n1_i8x4.json 2>/dev/null   # the cheap passes' kernels on the shard
 python bench.py --workload cfg5shard --accum fp32 $Q --no-alt > gpurun_out/$R/bench_cfg5shard_n1_fp32.json 2>/dev/null
 for a in i8 fp64; do
   # kernel trace of the driver's command line itself for the default mode (same flags), of --accum fp64 for the other
@@ -41,6 +42,8 @@ python bench.py --blockvec 32 $Q --no-e2e --no-alt > gpurun_out/$R/bench_cfg3_n1
 python scripts/ortho_slice_cost.py > gpurun_out/$R/ortho_slice_cost.txt 2>&1
 python scripts/mfma_mix_probe.py > gpurun_out/$R/mfma_mix_probe.txt 2>&1
 python scripts/hard_spectrum_once.py > gpurun_out/$R/hard_spectrum.txt 2>&1
+python scripts/r4_mixed_probe.py > gpurun_out/$R/mixed_probe.txt 2>&1
+bash scripts/r4_narrow_probe.sh > /dev/null 2>&1; cp gpurun_out/r4_narrow_probe.txt gpurun_out/$R/narrow_probe.txt
 FPCA_TIMING=1 bash scripts/gpu_cli_e2e.sh 500000 100000 3 > gpurun_out/$R/cli_e2e_cfg3.txt 2>&1
 bash scripts/power_sample.sh i8 > gpurun_out/$R/power_sample.txt 2>&1
 # slim the raw traces before they travel back (the stats CSVs are what profiles/ keeps)
