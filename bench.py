@@ -685,6 +685,8 @@ def main():
                 print("MULTI-RANK VALIDATION FAILED: %s" % json.dumps(val), file=sys.stderr, flush=True)
     if watchdog is not None:
         watchdog.cancel()
+    if world > 1 and not args.no_validate and out["multi_rank_validation"].get("passed") is None:
+        out["multi_rank_validation"]["passed"] = bool(out["multi_rank_validation"].get("operator_ok"))  # (--no-pca: the operator only)
 
     # ---- the same solve on a slowly converging spectrum: 4 sub-populations, so that 17 of the 20 wanted eigenvalues sit in
     # the bulk (231 single-vector ops instead of 42 in the probe) -- the cost of a PCA whose k reaches past the

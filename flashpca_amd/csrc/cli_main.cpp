@@ -111,6 +111,7 @@ const OptSpec OPTS[] = {
    {"gpus", 0, true, "number of GPUs for PCA [1]: the SNPs are split into that many contiguous shards, one process per GPU, partial products summed by an RCCL all-reduce", true},
    {"blockvec", 0, true, "block width of the eigensolver: 16, 32, 48 or 64 [16; 32 / 64 for ndim > 64 / > 128]", true},
    {"maxblocks", 0, true, "basis cap (in blocks) before a thick restart [automatic]", true},
+   {"passes", 0, true, "arithmetic of the eigensolver's passes in the exact-integer modes [mixed | exact]: mixed (default) = a solve that needs many passes makes most of them on 4 byte slices of the fp64 operand and puts the Ritz vectors through the exact operator before it declares convergence; exact = every pass on all slices", true},
    {"accum", 0, true, "arithmetic of the two genotype GEMMs [auto | fp64 | fp32 | i8 | i8xS]: i8 = exact-integer int8 MFMA on S = 7 (i8xS: S = 2..8) byte slices of the fp64 operand, results equal to fp64; fp32 = fp32 MFMA products, fp64 long accumulation; auto (default) = i8, or fp64 if the int8 buffers do not fit", true},
 };
 
@@ -625,6 +626,17 @@ int main(int argc, char *argv[])
          }
       }
 
+      int mixed = 0;
+      if (has("passes")) {
+         const std::string m = vm["passes"];
+         if (m == "mixed") mixed = 1;
+         else if (m == "exact") mixed = -1;
+         else {
+            std::cerr << "Error: unknown --passes mode (mixed | exact): " << m << std::endl;
+            return EXIT_FAILURE;
+         }
+      }
+
       // ---- end of command line parsing -------------------------------------------------------------------
       std::cout << timestamp() << "Start flashpca (version " << FLASHPCA_VERSION << ")" << std::endl;
       verbose && std::cout << timestamp() << "seed: " << seed << std::endl;
@@ -893,6 +905,7 @@ int main(int argc, char *argv[])
          o.divisor = divisor;
          o.do_loadings = do_loadings ? 1 : 0;
          o.max_blocks = maxblocks;
+         o.mixed = mixed;
          o.verbose = verbose ? 1 : 0;
          o.seed = (uint64_t)seed;
          d.resize(n_dim);
@@ -940,6 +953,8 @@ int main(int argc, char *argv[])
             throw std::runtime_error("Spectra eigen-decomposition was not successful, status: not converging");
          fpca_ok(rc);
          verbose && std::cout << timestamp() << "GRM trace: " << info.trace << std::endl;
+         if (verbose && info.cheap_applies > 0)
+            std::cout << timestamp() << info.cheap_applies << " of them on " << info.cheap_slices << " byte slices of the operand, verified by exact passes" << std::endl;
          verbose && std::cout << timestamp() << info.block_applies << " block applies of width " << info.blockvec << " (" << info.vector_ops
                               << " vector operations), " << info.restarts << " restarts, device " << info.seconds_apply + info.seconds_ortho
                               << " s, host " << info.seconds_host << " s" << std::endl;

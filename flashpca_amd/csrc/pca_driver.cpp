@@ -44,8 +44,11 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
    // (op count = 1 + (ncv-1) + sum over restarts of (ncv - nev_adjusted)) -- is spent here b at a time.
    {
       const long long mi = o.maxiter > 0 ? o.maxiter : 500;
-      const long long ops = 2LL * k + 1 + mi * (k + 1LL), b = be.width();
-      so.max_applies = (int)std::min<long long>((ops + b - 1) / b, 1LL << 30);
+      // ... 16 at a time whatever the width: a wide block needs about as many PASSES as a narrow one (120 / 102 / 87+ passes for
+      // b = 16 / 32 / 64 at k = 10 on the realistic profile), so dividing the budget by b would make the explicit wide widths run
+      // out where the automatic one does not (profiles/r04_realistic_choices.txt: b = 64, k = 10 stopped at its 87 passes)
+      const long long ops = 2LL * k + 1 + mi * (k + 1LL), b = be.width(), unit = std::min<long long>(b, 16);
+      so.max_applies = (int)std::min<long long>((ops + unit - 1) / unit, 1LL << 30);
       if (o.max_applies > 0) so.max_applies = o.max_applies; // explicit cap in block applies (tests, bench warm-up)
       if ((long long)so.max_applies * b < k)
          throw Error(FPCA_EINVAL, "max_applies = " + std::to_string(so.max_applies) + " block applies of " + std::to_string((int)b) +

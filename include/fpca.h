@@ -222,7 +222,8 @@ typedef struct fpca_pca_opts {
                      * factorisation (flashpca.cpp:423-433 default 500, randompca.cpp:178 compute(maxiter, tol)).  A restart
                      * re-applies the operator to at most ndim + 1 vectors, so the reference's budget is
                      * 2 ndim + 1 + maxiter (ndim + 1) operator applications; the block solver stops after
-                     * ceil(that / b) block applies (b vector operations each) -- the same budget in the same unit */
+                     * ceil(that / 16) block applies -- 16 at a time whatever the width, because a wide block needs about as
+                     * many passes as a narrow one (max_applies is the explicit cap in passes) */
    double tol;      /* --tol (flashpca.cpp:440 default 1e-6) */
    int divisor;     /* FPCA_DIVISOR_* (flashpca.cpp:484 default p) */
    int do_loadings; /* --outload given */

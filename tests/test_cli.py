@@ -35,6 +35,7 @@ def test_cli_flag_errors(built_lib):
                        (["--check", "--project"], "conflicting modes requested"),
                        (["--project"], "SNP-loadings must be specified using --inload"),
                        (["--accum", "bf16"], "unknown accumulate mode (--accum): bf16"),
+                       (["--passes", "cheap"], "unknown --passes mode (mixed | exact): cheap"),
                        (["--scca"], "outside the PCA path")):
         r = run(["--bfile", DATA, "--notime"] + extra)
         assert r.returncode == 1, (extra, r.stderr)
@@ -67,6 +68,8 @@ def test_cli_option_prefixes(built_lib):
     assert r.returncode == 1 and "--maxiter can't be less than 1" in r.stderr
     r = run(["--bfile", DATA, "--notime", "--dev", "0"])
     assert r.returncode == 0 and "unrecognised option '--dev'" in r.stderr
+    r = run(["--bfile", DATA, "--notime", "--pass", "exact"])  # (--passes is this build's: full name only)
+    assert r.returncode == 0 and "unrecognised option '--pass'" in r.stderr
     # CCA-only options of the reference are accepted (and ignored) like any other registered option
     r = run(["--bfile", DATA, "--notime", "--lambda1", "0.1", "--outpcx", "a", "--save-vinit", "--ndim", "0"])
     assert r.returncode == 1 and "--ndim can't be less than 1" in r.stderr
