@@ -81,7 +81,7 @@ def _child(args, prof_args, steps, tmp):
     cmd = ["rocprofv3"] + prof_args + ["--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
            os.path.abspath(__file__), "--workload", args.workload, "--accum", args.accum, "--blockvec", str(args.blockvec),
            "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-pca", "--no-alt", "--no-e2e", "--traffic", "none"]
-    subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True,
+    subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True,  # (a healthy child takes ~10 s)
                    env={k: v for k, v in dict(os.environ, TMPDIR="/tmp").items() if k != "LD_PRELOAD"})
     pat = "*kernel_trace.csv" if "--pmc" not in prof_args else "*counter_collection.csv"
     fs = glob.glob(os.path.join(tmp, "**", pat), recursive=True)
