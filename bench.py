@@ -512,7 +512,9 @@ def main():
                data="synthetic",
                config=dict(workload=args.workload + ": " + w["desc"], samples=N, snps_total=P_total, snps_per_gpu=P_rank,
                            k=k, blockvec=b, solver_default_blockvec=solver_blockvec(k), missing_call_rate=0.001, parallelism="snp-shard x%d + all-reduce(N x b) [%s]" % (world, transport),
-                           iters_per_step=b, generate_s=round(t_gen, 3)),
+                           iters_per_step=b, generate_s=round(t_gen, 3),
+                           solver_passes="`value` and every fpca_apply_* call: exact (7 slices).  fpca_pca (`pca*` blocks): exact passes until the measured "
+                                         "decay predicts a long solve, then 4-slice passes verified by exact ones (see cheap_applies there)"),
                roofline=roofline)
 
     # ---- several ranks: the line validates itself ---------------------------------------------------------------------------

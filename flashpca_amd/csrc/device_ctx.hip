@@ -624,9 +624,8 @@ void hybrid_classify(fpca_ctx *c)
    c->hyb_class = 1;
 }
 
-int i8_mode(const fpca_ctx *c_, int b)
+int i8_mode(fpca_ctx *c, int b) // (classifies the SNPs the first time a rate above the break-even makes the hybrid route a candidate)
 {
-   fpca_ctx *c = const_cast<fpca_ctx *>(c_);
    const char *env = FPCA_TEST_ENV("FPCA_I8_MODE"); // force (tests; 2 is wrong unless nothing is missing); read on every call
    const bool sparse_ok = c->missing_known && !c->sparse_failed && c->n_missing < (1ull << 31) && (b == 16 || b == 32 || b == 64);
    const bool lists_ok = c->missing_known && !c->sparse_failed && (b == 16 || b == 32 || b == 64);
