@@ -1145,11 +1145,11 @@ void staged_download(fpca_ctx *c_, const double *d_img, uint64_t N, int ncols, d
    for (hipEvent_t &e : c_->dl_ev)
       if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
    const size_t nch = (total + CH - 1) / CH;
-   // helper threads: only for results of three pieces and more (24 MB: below that the copies are over before a thread has
-   // started), as many as this process may run at once (cgroup quota / affinity, not the host's hardware threads), at most 8;
+   // helper threads: for results of two pieces and more (a single piece is scattered by the caller: the copy is over before a
+   // thread has started), as many as this process may run at once (cgroup quota / affinity, not the host's hardware threads), at most 8;
    // they sleep on a condition variable until their piece has landed -- no spinning beside the thread that issues the copies
    static const unsigned cpus = usable_cpus();
-   const int T = nch >= 3 ? (int)std::max(1u, std::min(8u, cpus > 1 ? cpus - 1 : 1u)) : 0;
+   const int T = nch >= 2 ? (int)std::max(1u, std::min(8u, cpus > 1 ? cpus - 1 : 1u)) : 0;
    if (T == 0) {
       for (size_t c = 0; c < nch; c++) {
          const size_t c0 = c * CH, len = std::min(CH, total - c0);
@@ -1167,7 +1167,7 @@ void staged_download(fpca_ctx *c_, const double *d_img, uint64_t N, int ncols, d
    std::vector<std::atomic<int>> done(nch);   // workers finished with piece c
    for (auto &x : done) x.store(0);
    auto wait_for = [&](std::condition_variable &cv, auto &&pred) {
-      for (int spin = 0; spin < 4000; spin++) {
+      for (int spin = 0; spin < 40000; spin++) { // (~0.5 ms: three pieces' worth; a longer wait is a stall, and stalls are slept through)
          if (pred()) return;
          __builtin_ia32_pause();
       }
