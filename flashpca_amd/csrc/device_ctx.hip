@@ -143,8 +143,10 @@ struct fpca_ctx {
    // sparse missing indicator: index lists of the missing calls per SNP (sample indices) and per sample (SNP indices)
    std::vector<uint32_t> h_nmiss; // per-SNP counts from K1
    uint32_t *d_snp_ptr = nullptr, *d_snp_idx = nullptr, *d_smp_ptr = nullptr, *d_smp_idx = nullptr;
-   double *d_eplane = nullptr; // E'Q of the current stage, [max(N_pad, P_pad)][b]
-   size_t eplane_cap = 0;
+   double *d_eplane = nullptr; // E'Q of the current stage, [max(N_pad, P_pad)][b]; behind it, as much again: the row-major copy
+   size_t eplane_cap = 0;      // of the scaled operand the gathers read (gather_src(): fp64, or fp32 under <= 4 slices)
+   void *gather_src() const { return d_eplane + eplane_cap; }
+   bool gather_f32() const { return cur_S() <= 4; } // the slices carry 30 bits: 24-bit rows of the (small) E term lose nothing
    bool sparse_ready = false;
    bool sparse_failed = false; // the index lists did not fit in device memory: the dense missing-indicator route is used
    // hybrid missing-indicator route: the SNPs whose missing calls are too many for the gathers (hyb_idx, hyb_n of them, padded
@@ -669,7 +671,7 @@ void ensure_sparse(fpca_ctx *c, int b)
       if (c->d_eplane) HIP_CHECK(hipFree(c->d_eplane));
       c->d_eplane = nullptr;
       c->eplane_cap = 0;
-      HIP_ALLOC(hipMalloc(&c->d_eplane, need * sizeof(double)));
+      HIP_ALLOC(hipMalloc(&c->d_eplane, 2 * need * sizeof(double)));
       c->eplane_cap = need;
    }
    if (c->sparse_ready) return;
@@ -833,13 +835,15 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipE
    int mode = i8_mode(c, b);
    const double *eplane = nullptr;
    hipEvent_t wait = nullptr;
-   kern::i8_colmax(dB, c->N, b, 1, &ob, s);
-   kern::i8_slice(dB, c->N_pad, c->N, b, c->cur_S(), 1, &ob, s);
    if (mode == I8M_SPARSE || mode == I8M_HYBRID)
       mode = sparse_or_dense(c, b, mode);
    else
       plain_view(c);
    const bool hyb = mode == I8M_HYBRID;
+   const bool g32 = (mode == I8M_SPARSE || hyb) && c->gather_f32();
+   if (g32) ob.copy32 = static_cast<float *>(c->gather_src()); // the slicing pass leaves the fp32 rows the gather reads
+   kern::i8_colmax(dB, c->N, b, 1, &ob, s);
+   kern::i8_slice(dB, c->N_pad, c->N, b, c->cur_S(), 1, &ob, s);
    if (hyb) // E_d' B of the dense SNPs on the matrix cores: their compacted records x the same slices of B -> [hyb_pad][b]
       kern::gemm_i8(c->d_packedE, c->pitch, c->d_Qb, c->d_Qb, ob.colw, ob.colw, nullptr, nullptr, nullptr, c->d_hyb_plane, c->d_i8ws, c->hyb_pad, c->N_pad,
                     c->hyb_n, I8M_NONE, nullptr, b, c->cur_S(), nullptr, s, nullptr, nullptr, true);
@@ -850,7 +854,10 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipE
          HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_aux_go, 0));
          gs = c->aux_stream;
       }
-      kern::sparse_rows_sum(c->d_snp_ptr, c->d_snp_idx, dB, nullptr, b, c->P_g, c->P_pad, c->d_eplane, gs);
+      if (g32)
+         kern::sparse_rows_sum_f32(c->d_snp_ptr, c->d_snp_idx, ob.copy32, ob.colw, b, c->P_g, c->P_pad, c->d_eplane, gs);
+      else
+         kern::sparse_rows_sum(c->d_snp_ptr, c->d_snp_idx, dB, nullptr, b, c->P_g, c->P_pad, c->d_eplane, gs);
       if (hyb) kern::scatter_rows(c->d_hyb_plane, c->d_hyb_idx, c->hyb_n, b, c->d_eplane, gs); // (the gather wrote zeros there: empty lists)
       if (gs != s) {
          HIP_CHECK(hipEventRecord(c->ev_aux_done, c->aux_stream));
@@ -909,6 +916,13 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_
    if (hyb) mode = I8M_SPARSE; // (from here on the two routes differ only in what the gathered plane starts from)
    if (do_slice) {
       if (!have_max) kern::i8_colmax(c->d_T, c->P_g, b, 2, ot, s);
+      const bool g32 = c->gather_f32();
+      if (mode == I8M_SPARSE) { // the slicing pass leaves mean T / sd itself, row-major, for the gather (no per-entry row factor)
+         if (g32)
+            ot[1].copy32 = static_cast<float *>(c->gather_src());
+         else
+            ot[1].copy64 = static_cast<double *>(c->gather_src());
+      }
       kern::i8_slice(c->d_T, c->P_pad, c->P_g, b, c->cur_S(), 2, ot, s);
       if (hyb) {
          // E_d (mean T / sd)_d: the dense SNPs' rows of the operand, gathered and scaled, sliced on their own (own column
@@ -922,13 +936,17 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_
       }
       const double *init = hyb ? c->d_hyb_plane : nullptr;
       if (mode == I8M_SPARSE) { // E (mean T / sd): for every sample the sum of the scaled T rows of its missing SNPs
+         hipStream_t gs = s;
          if (sparse_on_side_stream(c, b)) {
             HIP_CHECK(hipEventRecord(c->ev_aux_go, s)); // T is complete on s here (and the K2 combine has consumed the plane)
             HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_aux_go, 0));
-            kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, c->d_T, c->d_mu_inv_sd, b, c->N, c->N_pad, c->d_eplane, c->aux_stream, init);
-            HIP_CHECK(hipEventRecord(c->ev_aux_done, c->aux_stream));
-         } else
-            kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, c->d_T, c->d_mu_inv_sd, b, c->N, c->N_pad, c->d_eplane, s, init);
+            gs = c->aux_stream;
+         }
+         if (g32)
+            kern::sparse_rows_sum_f32(c->d_smp_ptr, c->d_smp_idx, ot[1].copy32, ot[1].colw, b, c->N, c->N_pad, c->d_eplane, gs, init, true);
+         else
+            kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, ot[1].copy64, nullptr, b, c->N, c->N_pad, c->d_eplane, gs, init, true);
+         if (gs != s) HIP_CHECK(hipEventRecord(c->ev_aux_done, c->aux_stream));
       }
    }
    if (r1 == 0) r1 = c->N_pad;

@@ -96,6 +96,8 @@ struct SliceOp {
    int8_t *Q;
    double *colw;       // [gemm_i8_nsc_pad(S, b)]
    long long *colsum;  // [I8_SHARDS][I8_CS_STRIDE] or null; accumulated with atomics: zero it first
+   double *copy64;     // optional: the scaled operand itself, row-major [rows][b] (what the sparse gathers of the missing-call
+   float *copy32;      // route read: no per-entry row factor; fp32, column-scaled, when the slices carry no more than 30 bits anyway)
 };
 void i8_colmax(const double *V, uint64_t rows, int b, int nops, const SliceOp *ops, hipStream_t stream); // maxbits must be zeroed
 void i8_slice(const double *V, uint64_t rows_pad, uint64_t rows, int b, int S, int nops, const SliceOp *ops, hipStream_t stream);
@@ -118,7 +120,12 @@ void scatter_rows(const double *src, const uint32_t *idx, uint32_t nidx, int b, 
 void count_missing(const uint8_t *packed, size_t pitch, uint64_t ncols, uint64_t nrec, uint32_t *cnt, hipStream_t stream);
 void fill_missing(const uint8_t *packed, size_t pitch, uint64_t ncols, uint64_t nrec, const uint32_t *ptr, uint32_t *idx, hipStream_t stream);
 void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, const double *rowscale, int b, uint64_t nrec,
-                     uint64_t rows_out, double *out, hipStream_t stream, const double *init = nullptr /* [rows_out][b] added to the sums */);
+                     uint64_t rows_out, double *out, hipStream_t stream, const double *init = nullptr /* [rows_out][b] added to the sums */,
+                     bool short_lists = false /* many short lists (per sample): the batched index reads */);
+// the same over the fp32 rows k_slice leaves (SliceOp::copy32: each column scaled into (-2, 2) by its slice exponent; colw = that
+// operand's slice weights, which carry the exponent back)
+void sparse_rows_sum_f32(const uint32_t *ptr, const uint32_t *idx, const float *V, const double *colw, int b, uint64_t nrec, uint64_t rows_out,
+                         double *out, hipStream_t stream, const double *init = nullptr, bool short_lists = false);
 void i8_rowscales(const double *mean, const double *sd, uint64_t P_g, uint64_t P_pad, double *inv_sd, double *mu_inv_sd,
                   hipStream_t stream);
 void transpose_packed(const uint8_t *in, size_t pitch_in, uint64_t N_pad, uint64_t P_pad, uint8_t *out, size_t pitch_out,

@@ -169,6 +169,8 @@ __global__ __launch_bounds__(256) void k_slice(const double *__restrict__ V, uin
             double x = v[j];
             if (ops[o]->rowscale && act && r < rows) x *= ops[o]->rowscale[r];
             m[j] = __double2ll_rn(ldexp(x, sh[o])); // power-of-two scaling is exact; |m| < 2^F
+            if (ops[o]->copy64 && act && r < rows) ops[o]->copy64[r * b + c] = x;
+            if (ops[o]->copy32 && act && r < rows) ops[o]->copy32[r * b + c] = (float)ldexp(x, sh[o] - F + 1); // |.| < 2: any column fits fp32
          }
          for (int s = S - 1; s >= 0; s--) { // bytes from the low end, carries into the next one
             u4 word = {0u, 0u, 0u, 0u};
@@ -1115,10 +1117,11 @@ void fill_missing(const uint8_t *packed, size_t pitch, uint64_t ncols, uint64_t 
 
 // out[r][c] = sum over s in list(r) of V[s][c] * (rowscale ? rowscale[s] : 1)   (fp64, list order = ascending s);
 // rows r >= nrec are zeroed.  One wave per output row; EPW = 64 / b list entries per step, 4 steps in flight.
-template <int B>
+template <int B, class VT>
 __global__ __launch_bounds__(256) void k_sparse_rows_sum(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
-                                                          const double *__restrict__ V, const double *__restrict__ rowscale, uint64_t nrec,
-                                                          uint64_t rows_out, double *__restrict__ out, const double *__restrict__ init)
+                                                          const VT *__restrict__ V, const double *__restrict__ rowscale, uint64_t nrec,
+                                                          uint64_t rows_out, double *__restrict__ out, const double *__restrict__ init,
+                                                          const double *__restrict__ colw)
 {
    constexpr int EPW = 64 / B;
    const int lane = threadIdx.x & 63, c = lane % B, e0 = lane / B;
@@ -1146,7 +1149,10 @@ __global__ __launch_bounds__(256) void k_sparse_rows_sum(const uint32_t *__restr
       double a = (a0 + a1) + (a2 + a3);
 #pragma unroll
       for (int o = 32; o >= B; o >>= 1) a += __shfl_down(a, o);
-      if (lane < B) out[r * B + c] = init ? init[r * B + c] + a : a;
+      if (lane < B) {
+         if (colw) a *= colw[c] * 32.0; // fp32 rows were stored as x 2^(1 - e_c); colw[c] = 2^(e_c - 6) (top slice's weight)
+         out[r * B + c] = init ? init[r * B + c] + a : a;
+      }
    }
 }
 
@@ -1154,10 +1160,11 @@ __global__ __launch_bounds__(256) void k_sparse_rows_sum(const uint32_t *__restr
 // one dependent 4-byte load per gathered row: the loop above is a chain idx -> row of V, both at Infinity-Cache latency,
 // with four rows in flight per wave; here the rows of a batch are independent of any further index load and eight of them
 // are in flight (per lane slot).  The per-row factors of a batch are gathered once, one per lane, the same way.
-template <int B>
+template <int B, class VT>
 __global__ __launch_bounds__(256) void k_sparse_rows_sum_batched(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
-                                                                  const double *__restrict__ V, const double *__restrict__ rowscale,
-                                                                  uint64_t nrec, uint64_t rows_out, double *__restrict__ out, const double *__restrict__ init)
+                                                                  const VT *__restrict__ V, const double *__restrict__ rowscale,
+                                                                  uint64_t nrec, uint64_t rows_out, double *__restrict__ out, const double *__restrict__ init,
+                                                                  const double *__restrict__ colw)
 {
    constexpr int EPW = 64 / B, U = 8;
    const int lane = threadIdx.x & 63, c = lane % B, e0 = lane / B;
@@ -1185,27 +1192,31 @@ __global__ __launch_bounds__(256) void k_sparse_rows_sum_batched(const uint32_t 
       double a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 #pragma unroll
       for (int o = 32; o >= B; o >>= 1) a += __shfl_down(a, o);
-      if (lane < B) out[r * B + c] = init ? init[r * B + c] + a : a;
+      if (lane < B) {
+         if (colw) a *= colw[c] * 32.0; // fp32 rows were stored as x 2^(1 - e_c); colw[c] = 2^(e_c - 6) (top slice's weight)
+         out[r * B + c] = init ? init[r * B + c] + a : a;
+      }
    }
 }
 
-void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, const double *rowscale, int b, uint64_t nrec,
-                     uint64_t rows_out, double *out, hipStream_t stream, const double *init)
+template <class VT>
+static void sparse_rows_sum_t(const uint32_t *ptr, const uint32_t *idx, const VT *V, const double *rowscale, int b, uint64_t nrec,
+                              uint64_t rows_out, double *out, hipStream_t stream, const double *init, bool short_lists, const double *colw)
 {
    if (!rows_out) return;
    const unsigned blocks = (unsigned)std::min<uint64_t>(65536, (rows_out + 3) / 4);
-   // measured (scripts/ab_gather.sh, cfg3): the batched kernel takes 0.3 ms off the K3 gather (short lists per sample, a row
-   // factor per entry), nothing off the K2 one and costs it 6-50 us at the small sizes -- so K3 (rowscale given) takes the
-   // batched kernel, K2 the plain one.  Both sit at ~7 TB/s out of the Infinity Cache; with the gathered matrix resident in
-   // L2 the same kernel reaches 9.4 TB/s (scripts/gather_l2_probe.py), which is all an L2-blocked gather order could win.
+   // measured (scripts/ab_gather.sh, cfg3): the batched kernel takes 0.3 ms off the K3 gather (short lists per sample),
+   // nothing off the K2 one and costs it 6-50 us at the small sizes -- so K3 takes the batched kernel, K2 the plain one.
+   // Both sit at ~7 TB/s out of the Infinity Cache; with the gathered matrix resident in L2 the same kernel reaches 9.4 TB/s
+   // (scripts/gather_l2_probe.py), which is all an L2-blocked gather order could win.
    static const int forced = FPCA_TEST_ENV("FPCA_GATHER") ? atoi(FPCA_TEST_ENV("FPCA_GATHER")) : 0; // 1 / 2 force one kernel (A/B)
-   const int variant = forced ? forced : (rowscale ? 2 : 1);
+   const int variant = forced ? forced : ((rowscale || short_lists) ? 2 : 1);
 #define FPCA_GATHER_CASE(B_)                                                                                                    \
    case B_:                                                                                                                     \
       if (variant == 1)                                                                                                         \
-         hipLaunchKernelGGL(k_sparse_rows_sum<B_>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out, init); \
+         hipLaunchKernelGGL((k_sparse_rows_sum<B_, VT>), dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out, init, colw); \
       else                                                                                                                      \
-         hipLaunchKernelGGL(k_sparse_rows_sum_batched<B_>, dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out, init); \
+         hipLaunchKernelGGL((k_sparse_rows_sum_batched<B_, VT>), dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out, init, colw); \
       break;
    switch (b) {
       FPCA_GATHER_CASE(16)
@@ -1215,6 +1226,16 @@ void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, 
    }
 #undef FPCA_GATHER_CASE
    HIP_CHECK_LAUNCH();
+}
+void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, const double *rowscale, int b, uint64_t nrec,
+                     uint64_t rows_out, double *out, hipStream_t stream, const double *init, bool short_lists)
+{
+   sparse_rows_sum_t<double>(ptr, idx, V, rowscale, b, nrec, rows_out, out, stream, init, short_lists, nullptr);
+}
+void sparse_rows_sum_f32(const uint32_t *ptr, const uint32_t *idx, const float *V, const double *colw, int b, uint64_t nrec, uint64_t rows_out,
+                         double *out, hipStream_t stream, const double *init, bool short_lists)
+{
+   sparse_rows_sum_t<float>(ptr, idx, V, nullptr, b, nrec, rows_out, out, stream, init, short_lists, colw);
 }
 
 // ------------------------------------------------------------------------------------------------
