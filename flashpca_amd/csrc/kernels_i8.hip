@@ -834,6 +834,14 @@ static I8Plan i8_plan(uint64_t rows_pad, uint64_t k_pad, const I8Shape &sh, int 
          }
       }
    }
+   {  // test builds: FPCA_I8_PLAN="nA,s" overrides the decomposition of launches with more than one round of tiles (A/B runs)
+      const char *env_p = FPCA_TEST_ENV("FPCA_I8_PLAN");
+      int e_nA = 0, e_s = 0;
+      if (env_p && std::sscanf(env_p, "%d,%d", &e_nA, &e_s) == 2 && ids >= ncu && e_s >= 1 && e_s * 4 <= chunks) {
+         best_nA = std::min(e_nA / (8 * sh.zb) * (8 * sh.zb), ids);
+         best_s = best_nA == ids ? 1 : e_s;
+      }
+   }
    I8Plan p;
    p.nA = best_nA;
    p.cpsB = (chunks + best_s - 1) / best_s;
