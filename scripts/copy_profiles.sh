@@ -4,6 +4,7 @@ for f in $S/bench_*.json; do [ -s $f ] && cp $f $D/${R}_$(basename $f); done
 for wl in cfg2 cfg3 cfg4shard; do for a in i8 fp64; do
   f=$(ls $S/trace_${wl}_$a/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $D/${R}_bench_${wl}_${a}_kernel_stats.csv
 done; done
+for t in trace_cfg3_i8 trace_cfg3_fp64 trace_cfg4shard_i8; do [ -s $S/${t}_by_grid.csv ] && cp $S/${t}_by_grid.csv $D/${R}_bench_${t#trace_}_kernel_by_grid.csv; done
 cp $S/pmc_summary.json $D/${R}_pmc_summary.json; cp $S/pmc_summary_i8.json $D/${R}_pmc_summary_i8.json
 cp $S/mfma_i8_microbench.txt $D/${R}_mfma_i8_microbench.txt; cp $S/mfma_f64_microbench.txt $D/${R}_mfma_f64_microbench.txt
 [ -s $S/power_sample.txt ] && cp $S/power_sample.txt $D/${R}_power_sample.txt

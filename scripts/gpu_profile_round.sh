@@ -46,6 +46,7 @@ python scripts/r4_mixed_probe.py > gpurun_out/$R/mixed_probe.txt 2>&1
 bash scripts/r4_narrow_probe.sh > /dev/null 2>&1; cp gpurun_out/r4_narrow_probe.txt gpurun_out/$R/narrow_probe.txt
 FPCA_TIMING=1 bash scripts/gpu_cli_e2e.sh 500000 100000 3 > gpurun_out/$R/cli_e2e_cfg3.txt 2>&1
 bash scripts/power_sample.sh i8 > gpurun_out/$R/power_sample.txt 2>&1
+for t in trace_cfg3_i8 trace_cfg3_fp64 trace_cfg4shard_i8; do python scripts/summarise_trace.py gpurun_out/$R/$t > gpurun_out/$R/${t}_by_grid.csv; done
 # slim the raw traces before they travel back (the stats CSVs are what profiles/ keeps)
 find gpurun_out/$R -name "*kernel_trace.csv" -size +2M -delete; find gpurun_out/$R -name "*counter_collection.csv" -size +8M -delete
 cat gpurun_out/$R/pmc_summary_i8.json | head -70; tail -c 1500 gpurun_out/$R/bench_cfg3_n1.json
