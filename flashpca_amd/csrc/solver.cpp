@@ -496,7 +496,10 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          //  must still be well above the threshold -- residuals of a fast solve fall by orders of magnitude per pass, and a
          //  pass launched before the test that ends it is a pass wasted)
          const double expected = (prev_worst > 0 && rho_last > 0 && rho_last < 1) ? prev_worst * std::pow(rho_last, (double)(res.block_applies - prev_step)) : 0.0;
-         if (res.block_applies + 1 < o.max_applies && (no_test || expected > 30.0 * tol_est)) {
+         // "well above": by the decay of four more passes, at least a factor 2 -- a slow solve (decay 0.9-0.97 per pass) keeps
+         // its Rayleigh-Ritz solves hidden until the last few tests, a fast one (0.1 and less) never launches ahead of a test
+         const double margin = rho_last > 0 ? std::max(2.0, 1.0 / (rho_last * rho_last * rho_last * rho_last)) : 30.0;
+         if (res.block_applies + 1 < o.max_applies && (no_test || expected > margin * tol_est)) {
             pend_in = na1 < M ? V[na1] : W;
             pend_out = be.alloc_block();
             pend_cheap = cheap;
