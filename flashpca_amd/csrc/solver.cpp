@@ -623,11 +623,13 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
             S.assign(Tw.begin(), Tw.begin() + (size_t)n * n);
          }
       }
-      host_s += since(t0);
+      const double rr_s = since(t0);
+      host_s += rr_s;
       phase(PH_RR);
       if (o.verbose)
-         std::fprintf(stderr, "[fpca] apply %3d%s basis %4d (+%d waiting)  theta1 %.6g  theta_k %.6g  max rel resid %.3e\n", res.block_applies,
-                      cheap ? " (cheap)" : tainted ? " (exact*)" : "        ", n, Mn - na, theta[0], theta[k - 1], worst);
+         std::fprintf(stderr, "[fpca] apply %3d%s basis %4d (+%d waiting)  theta1 %.6g  theta_k %.6g  max rel resid %.3e  (projected eigenproblem %.2f ms%s)\n",
+                      res.block_applies, cheap ? " (cheap)" : tainted ? " (exact*)" : "        ", n, Mn - na, theta[0], theta[k - 1], worst, rr_s * 1e3,
+                      pend_out >= 0 ? ", next pass in flight" : "");
       if (all_conv && !tainted) {
          res.converged = true;
          break;

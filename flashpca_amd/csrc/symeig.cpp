@@ -9,6 +9,10 @@
 #include <cstdint>
 #include <cstring>
 #include <numeric>
+#include <thread>
+#include <vector>
+
+#include "common.hpp"
 
 namespace fpca {
 
@@ -394,44 +398,65 @@ int cols_core(int n, const double *A, int lda, const std::vector<double> &d, con
       }
       std::memcpy(&y[(size_t)c * n], x.data(), sizeof(double) * n);
    }
+   // Back-transformation and verification are independent per column: at the sizes of a thick restart (n ~ 400, 80 columns:
+   // ~9 ms, which the pass in flight beside it does not cover) they are spread over a few threads.  Every column sees the same
+   // arithmetic in the same order whatever the thread count: the result does not depend on it.
+   const int T = (n >= 192 && ncols >= 32) ? std::max(1, std::min(std::min((int)usable_cpus(), 8), ncols / 8)) : 1;
+   auto on_columns = [&](auto &&fn) { // fn(c0, c1) -> int
+      std::vector<int> rcs((size_t)T, 0);
+      std::vector<std::thread> th;
+      for (int t = 1; t < T; t++) th.emplace_back([&, t] { rcs[(size_t)t] = fn(ncols * t / T, ncols * (t + 1) / T); });
+      rcs[0] = fn(0, ncols / T);
+      for (auto &x : th) x.join();
+      for (int rc : rcs)
+         if (rc) return rc;
+      return 0;
+   };
    // back-transformation: z = H_0 H_1 ... H_{n-3} y
-   std::vector<double> v(n);
-   for (int k = n - 3; k >= 0; k--) {
-      if (beta[k] == 0.0) continue;
-      const int m = n - k - 1;
-      v[0] = 1.0;
-      for (int i = 1; i < m; i++) v[i] = A[(size_t)(k + 1 + i) + (size_t)k * lda];
-      for (int c = 0; c < ncols; c++) {
-         double *col = &y[(size_t)c * n + (k + 1)];
-         double sdot = 0;
-         for (int i = 0; i < m; i++) sdot += v[i] * col[i];
-         sdot *= beta[k];
-         for (int i = 0; i < m; i++) col[i] -= sdot * v[i];
+   (void)on_columns([&](int c0, int c1) {
+      std::vector<double> v(n);
+      for (int k = n - 3; k >= 0; k--) {
+         if (beta[k] == 0.0) continue;
+         const int m = n - k - 1;
+         v[0] = 1.0;
+         for (int i = 1; i < m; i++) v[i] = A[(size_t)(k + 1 + i) + (size_t)k * lda];
+         for (int c = c0; c < c1; c++) {
+            double *col = &y[(size_t)c * n + (k + 1)];
+            double sdot = 0;
+            for (int i = 0; i < m; i++) sdot += v[i] * col[i];
+            sdot *= beta[k];
+            for (int i = 0; i < m; i++) col[i] -= sdot * v[i];
+         }
       }
-   }
+      return 0;
+   });
    // verification against the original matrix
    double anorm = 0;
    for (size_t i = 0; i < A0.size(); i++) anorm = std::max(anorm, std::fabs(A0[i]));
    anorm = std::max(anorm * n, tnorm);
-   std::vector<double> r(n);
-   for (int c = 0; c < ncols; c++) {
-      const double *z = &y[(size_t)c * n];
-      std::fill(r.begin(), r.end(), 0.0);
-      for (int j = 0; j < n; j++) {
-         const double zj = z[j];
-         const double *col = &A0[(size_t)j * n];
-         for (int i = 0; i < n; i++) r[i] += col[i] * zj;
+   const int vrc = on_columns([&](int c0, int c1) {
+      std::vector<double> r(n);
+      for (int c = c0; c < c1; c++) {
+         const double *z = &y[(size_t)c * n];
+         std::fill(r.begin(), r.end(), 0.0);
+         for (int j = 0; j < n; j++) {
+            const double zj = z[j];
+            const double *col = &A0[(size_t)j * n];
+            for (int i = 0; i < n; i++) r[i] += col[i] * zj;
+         }
+         double res = 0;
+         for (int i = 0; i < n; i++) res = std::max(res, std::fabs(r[i] - w[c] * z[i]));
+         if (!(res <= 1e-11 * anorm)) return 6;
+         for (int j = std::max(0, c - 64); j <= c; j++) {
+            const double *zj = &y[(size_t)j * n];
+            double dot = 0;
+            for (int i = 0; i < n; i++) dot += z[i] * zj[i];
+            if (!(std::fabs(dot - (j == c ? 1.0 : 0.0)) <= 1e-10)) return 7;
+         }
       }
-      double res = 0;
-      for (int i = 0; i < n; i++) res = std::max(res, std::fabs(r[i] - w[c] * z[i]));
-      if (!(res <= 1e-11 * anorm)) return 6;
-      for (int j = std::max(0, c - 64); j <= c; j++) {
-         const double *zj = &y[(size_t)j * n];
-         double dot = 0;
-         for (int i = 0; i < n; i++) dot += z[i] * zj[i];
-         if (!(std::fabs(dot - (j == c ? 1.0 : 0.0)) <= 1e-10)) return 7;
-      }
-   }
+      return 0;
+   });
+   if (vrc) return vrc;
    for (int c = 0; c < ncols; c++) std::memcpy(Z + (size_t)c * n, &y[(size_t)c * n], sizeof(double) * n);
    return 0;
 }
