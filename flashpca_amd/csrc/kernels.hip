@@ -981,21 +981,24 @@ void x_t_dense(const double *Xd, const double *T, double *Ypart, uint64_t N_pad,
 // ------------------------------------------------------------------------------------------------
 // K4 gram: part[(split*4+wave)][q][p][c] = sum_{rows of the wave} A_q[s][p] W[s][c]
 //   MFMA roles: A[i = p][k = sample] and B[k = sample][j = c] are both read straight from HBM, 16 lanes
-//   covering 128 contiguous bytes of a row; HBM-bound (each A_q read once, W once per q).
+//   covering 128 contiguous bytes of a row; HBM-bound (each A_q read once, W once per q, the latter out of L2 / the Infinity
+//   Cache).  Measured at N = 500,000 (rocprofv3, slow-spectrum solve): 4.0-4.4 TB/s of basis with each wave streaming its own
+//   contiguous 256 KB range; dealing the chunks round-robin over the waves took 10 % off.
 template <int NT>
 __global__ __launch_bounds__(256) void k_gram(const double *const *__restrict__ blocks, const double *__restrict__ W,
                                                double *__restrict__ part, uint64_t N_pad, int rows_per_split, int nq)
 {
    constexpr int b = 16 * NT;
-   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   constexpr int U = NT == 1 ? 4 : 2; // k-steps (of 4 rows) per chunk: their loads are issued together
+   const int lane = threadIdx.x & 63;
+   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
    const int li = lane & 15, kq = lane >> 4;
    const int q = blockIdx.y;
    const double *__restrict__ A = blocks[q];
-   uint64_t r0 = (uint64_t)blockIdx.x * rows_per_split;
-   uint64_t r1 = r0 + rows_per_split;
-   if (r1 > N_pad) r1 = N_pad;
-   const uint64_t per_wave = (r1 - r0) / 4;
-   const uint64_t ws = r0 + wave * per_wave, we = ws + per_wave;
+   // chunks of 4 U rows are dealt round-robin over all waves of this basis block: at any moment the waves read one contiguous
+   // window of A_q and of W (DRAM pages stay open) instead of gridDim.x * 4 separate 256 KB streams
+   (void)rows_per_split;
+   const uint64_t nchunks = N_pad / (4 * U), total = (uint64_t)gridDim.x * 4;
 
    d4 acc[NT][NT];
 #pragma unroll
@@ -1003,17 +1006,23 @@ __global__ __launch_bounds__(256) void k_gram(const double *const *__restrict__ 
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) acc[pt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
 
-   for (uint64_t s = ws; s < we; s += 4) {
-      const uint64_t row = s + kq;
-      double a[NT], w[NT];
+   for (uint64_t ch = (uint64_t)blockIdx.x * 4 + wave; ch < nchunks; ch += total) {
+      const uint64_t s = ch * (4 * U);
+      double a[U][NT], w[U][NT];
 #pragma unroll
-      for (int pt = 0; pt < NT; pt++) a[pt] = A[row * b + pt * 16 + li];
+      for (int u = 0; u < U; u++) {
+         const uint64_t row = s + 4 * u + kq;
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) w[nt] = W[row * b + nt * 16 + li];
+         for (int pt = 0; pt < NT; pt++) a[u][pt] = A[row * b + pt * 16 + li];
 #pragma unroll
-      for (int pt = 0; pt < NT; pt++)
+         for (int nt = 0; nt < NT; nt++) w[u][nt] = W[row * b + nt * 16 + li];
+      }
 #pragma unroll
-         for (int nt = 0; nt < NT; nt++) acc[pt][nt] = FPCA_MFMA(a[pt], w[nt], acc[pt][nt]);
+      for (int u = 0; u < U; u++)
+#pragma unroll
+         for (int pt = 0; pt < NT; pt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[pt][nt] = FPCA_MFMA(a[u][pt], w[u][nt], acc[pt][nt]);
    }
    double *out = part + ((size_t)(blockIdx.x * 4 + wave) * nq + q) * (size_t)(b * b);
 #pragma unroll
@@ -1038,7 +1047,8 @@ int gram_splits(uint64_t N_pad, int rows) { return (int)((N_pad + rows - 1) / ro
 void gram(const double *const *blocks, int nq, const double *W, double *part, uint64_t N_pad, int b, int rows, hipStream_t stream)
 {
    if (nq <= 0) return;
-   dim3 grid((unsigned)gram_splits(N_pad, rows), (unsigned)nq);
+   if (N_pad % 16) throw Error(-1, "gram: the block height must be a multiple of 16 rows");
+   dim3 grid((unsigned)gram_splits(N_pad, rows), (unsigned)nq); // (`rows` only sets the number of workgroups: 4 partial planes each)
    switch (b) {
    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<1>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, rows, nq); break;
    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<2>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, rows, nq); break;
