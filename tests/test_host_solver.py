@@ -129,6 +129,33 @@ def test_symeig_leading_columns_only(n, ncols, kind):
     assert np.max(np.abs(Z.T @ Z - np.eye(ncols))) < 1e-9
 
 
+def test_symeig_leading_columns_do_not_depend_on_the_thread_count():
+    """At the size of a thick restart (n = 384, 80 Ritz vectors) the back-transformation and the verification of the columns
+    are spread over threads sized from the CPUs this process may use (symeig.cpp cols_core); the columns must come out
+    bit for bit the same with one CPU."""
+    rng = np.random.default_rng(384)
+    n, ncols = 384, 80
+    B = rng.standard_normal((n, 3 * n))
+    A = B @ B.T / n
+    A = (A + A.T) / 2
+    out = []
+    cpus = os.sched_getaffinity(0)
+    try:
+        for allowed in (cpus, {min(cpus)}):
+            os.sched_setaffinity(0, allowed)
+            w = np.zeros(n)
+            Z = np.zeros((n, ncols), order="F")
+            A2 = np.asfortranarray(A.copy())
+            assert hostsim().hostsim_symeig_cols(n, A2.ctypes.data, w.ctypes.data, ncols, Z.ctypes.data) == 0
+            out.append((w.copy(), Z.copy()))
+    finally:
+        os.sched_setaffinity(0, cpus)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    wr = np.linalg.eigvalsh(A)[::-1]
+    assert np.max(np.abs(out[0][0] - wr)) < 1e-12 * wr[0] * n
+    assert np.max(np.abs(A @ out[0][1] - out[0][1] * out[0][0][:ncols])) < 1e-10 * wr[0]
+
+
 @pytest.mark.parametrize("name,k,kw", [("hapmap3_data", 10, {}), ("data_chr1", 10, {}), ("data_chr1", 50, {}),
                                        ("data_chr1", 10, dict(max_blocks=3)), ("data_chr1", 20, dict(blockvec=48)),
                                        ("data_chr1", 1, {}), ("data_chr1", 16, dict(blockvec=16))])
