@@ -937,15 +937,16 @@ void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_
       const double *init = hyb ? c->d_hyb_plane : nullptr;
       if (mode == I8M_SPARSE) { // E (mean T / sd): for every sample the sum of the scaled T rows of its missing SNPs
          hipStream_t gs = s;
+         const double per_sample = (double)(c->hyb_view ? c->hyb_sparse_nnz : c->n_missing) / (double)std::max<uint64_t>(c->N, 1); // listed calls per sample
          if (sparse_on_side_stream(c, b)) {
             HIP_CHECK(hipEventRecord(c->ev_aux_go, s)); // T is complete on s here (and the K2 combine has consumed the plane)
             HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_aux_go, 0));
             gs = c->aux_stream;
          }
          if (g32)
-            kern::sparse_rows_sum_f32(c->d_smp_ptr, c->d_smp_idx, ot[1].copy32, ot[1].colw, b, c->N, c->N_pad, c->d_eplane, gs, init, true);
+            kern::sparse_rows_sum_f32(c->d_smp_ptr, c->d_smp_idx, ot[1].copy32, ot[1].colw, b, c->N, c->N_pad, c->d_eplane, gs, init, true, per_sample);
          else
-            kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, ot[1].copy64, nullptr, b, c->N, c->N_pad, c->d_eplane, gs, init, true);
+            kern::sparse_rows_sum(c->d_smp_ptr, c->d_smp_idx, ot[1].copy64, nullptr, b, c->N, c->N_pad, c->d_eplane, gs, init, true, per_sample);
          if (gs != s) HIP_CHECK(hipEventRecord(c->ev_aux_done, c->aux_stream));
       }
    }

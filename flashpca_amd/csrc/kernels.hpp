@@ -121,11 +121,12 @@ void count_missing(const uint8_t *packed, size_t pitch, uint64_t ncols, uint64_t
 void fill_missing(const uint8_t *packed, size_t pitch, uint64_t ncols, uint64_t nrec, const uint32_t *ptr, uint32_t *idx, hipStream_t stream);
 void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, const double *rowscale, int b, uint64_t nrec,
                      uint64_t rows_out, double *out, hipStream_t stream, const double *init = nullptr /* [rows_out][b] added to the sums */,
-                     bool short_lists = false /* many short lists (per sample): the batched index reads */);
+                     bool short_lists = false /* many short lists (per sample): the batched index reads */,
+                     double avg_len = 0 /* entries per list, if known: a dozen or so takes the several-rows-per-wave kernel */);
 // the same over the fp32 rows k_slice leaves (SliceOp::copy32: each column scaled into (-2, 2) by its slice exponent; colw = that
 // operand's slice weights, which carry the exponent back)
 void sparse_rows_sum_f32(const uint32_t *ptr, const uint32_t *idx, const float *V, const double *colw, int b, uint64_t nrec, uint64_t rows_out,
-                         double *out, hipStream_t stream, const double *init = nullptr, bool short_lists = false);
+                         double *out, hipStream_t stream, const double *init = nullptr, bool short_lists = false, double avg_len = 0);
 void i8_rowscales(const double *mean, const double *sd, uint64_t P_g, uint64_t P_pad, double *inv_sd, double *mu_inv_sd,
                   hipStream_t stream);
 void transpose_packed(const uint8_t *in, size_t pitch_in, uint64_t N_pad, uint64_t P_pad, uint8_t *out, size_t pitch_out,

@@ -1207,9 +1207,57 @@ __global__ __launch_bounds__(256) void k_sparse_rows_sum_batched(const uint32_t 
    }
 }
 
+// Short lists (a dozen entries per row: the samples of a 1/8 SNP shard, small problems): with one wave per row the chain
+// ptr -> idx -> rows is three dependent round trips per row and nothing else in flight in that wave -- latency-bound (4 TB/s
+// out of an L2-resident operand).  Here 64 / B rows share a wave, B lanes (one per column) each, every group walking its own
+// list four entries at a time: four times the rows in flight, no cross-lane reduction.
+template <int B, class VT>
+__global__ __launch_bounds__(256) void k_sparse_rows_sum_short(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
+                                                                const VT *__restrict__ V, uint64_t nrec, uint64_t rows_out,
+                                                                double *__restrict__ out, const double *__restrict__ init,
+                                                                const double *__restrict__ colw)
+{
+   constexpr int G = 64 / B;
+   const int lane = threadIdx.x & 63, c = lane % B, g = lane / B;
+   for (uint64_t r0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G; r0 < rows_out; r0 += (uint64_t)gridDim.x * 4 * G) {
+      const uint64_t r = r0 + g;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      uint32_t p0 = 0, p1 = 0;
+      if (r < nrec) {
+         p0 = ptr[r];
+         p1 = ptr[r + 1];
+      }
+      // the group's index list in batches of B (one coalesced read, an entry per lane, handed round by shuffles): the row reads of
+      // a batch do not wait for any further index read.  (Groups of a wave may run a different number of batches: the shuffles
+      // are executed by all lanes, the reads are predicated.)
+      uint32_t longest = p1 - p0;
+#pragma unroll
+      for (int o = 32; o >= B; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
+      for (uint32_t base = 0; base < longest; base += B) {
+         const uint32_t t = p0 + base + c;
+         const int cnt = (int)min((uint32_t)B, p1 - p0 > base ? p1 - p0 - base : 0u);
+         const uint32_t mine = t < p1 ? idx[t] : 0u;
+#pragma unroll
+         for (int e = 0; e < B; e += 4) {
+            const uint32_t s0 = (uint32_t)__shfl((int)mine, g * B + e), s1 = (uint32_t)__shfl((int)mine, g * B + e + 1),
+                           s2 = (uint32_t)__shfl((int)mine, g * B + e + 2), s3 = (uint32_t)__shfl((int)mine, g * B + e + 3);
+            if (e < cnt) a0 += (double)V[(uint64_t)s0 * B + c];
+            if (e + 1 < cnt) a1 += (double)V[(uint64_t)s1 * B + c];
+            if (e + 2 < cnt) a2 += (double)V[(uint64_t)s2 * B + c];
+            if (e + 3 < cnt) a3 += (double)V[(uint64_t)s3 * B + c];
+         }
+      }
+      if (r < rows_out) {
+         double a = (a0 + a1) + (a2 + a3);
+         if (colw) a *= colw[c] * 32.0;
+         out[r * B + c] = init ? init[r * B + c] + a : a;
+      }
+   }
+}
+
 template <class VT>
 static void sparse_rows_sum_t(const uint32_t *ptr, const uint32_t *idx, const VT *V, const double *rowscale, int b, uint64_t nrec,
-                              uint64_t rows_out, double *out, hipStream_t stream, const double *init, bool short_lists, const double *colw)
+                              uint64_t rows_out, double *out, hipStream_t stream, const double *init, bool short_lists, const double *colw, double avg_len)
 {
    if (!rows_out) return;
    const unsigned blocks = (unsigned)std::min<uint64_t>(65536, (rows_out + 3) / 4);
@@ -1218,10 +1266,14 @@ static void sparse_rows_sum_t(const uint32_t *ptr, const uint32_t *idx, const VT
    // Both sit at ~7 TB/s out of the Infinity Cache; with the gathered matrix resident in L2 the same kernel reaches 9.4 TB/s
    // (scripts/gather_l2_probe.py), which is all an L2-blocked gather order could win.
    static const int forced = FPCA_TEST_ENV("FPCA_GATHER") ? atoi(FPCA_TEST_ENV("FPCA_GATHER")) : 0; // 1 / 2 force one kernel (A/B)
-   const int variant = forced ? forced : ((rowscale || short_lists) ? 2 : 1);
+   // 3: several rows per wave, for lists of a dozen entries (measured on the 1/8 shard of cfg3, 12.5 entries per sample: see DESIGN 3c)
+   const int variant = forced ? forced : (avg_len > 0 && avg_len <= 24.0 && b <= 32 && !rowscale) ? 3 : ((rowscale || short_lists) ? 2 : 1);
 #define FPCA_GATHER_CASE(B_)                                                                                                    \
    case B_:                                                                                                                     \
-      if (variant == 1)                                                                                                         \
+      if (variant == 3 && B_ <= 32 && !rowscale) {                                                                              \
+         const unsigned blocks3 = (unsigned)std::min<uint64_t>(65536, (rows_out + 4 * (64 / B_) - 1) / (4 * (64 / B_)));        \
+         hipLaunchKernelGGL((k_sparse_rows_sum_short<(B_ <= 32 ? B_ : 32), VT>), dim3(blocks3), dim3(256), 0, stream, ptr, idx, V, nrec, rows_out, out, init, colw); \
+      } else if (variant == 1)                                                                                                  \
          hipLaunchKernelGGL((k_sparse_rows_sum<B_, VT>), dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out, init, colw); \
       else                                                                                                                      \
          hipLaunchKernelGGL((k_sparse_rows_sum_batched<B_, VT>), dim3(blocks), dim3(256), 0, stream, ptr, idx, V, rowscale, nrec, rows_out, out, init, colw); \
@@ -1236,14 +1288,14 @@ static void sparse_rows_sum_t(const uint32_t *ptr, const uint32_t *idx, const VT
    HIP_CHECK_LAUNCH();
 }
 void sparse_rows_sum(const uint32_t *ptr, const uint32_t *idx, const double *V, const double *rowscale, int b, uint64_t nrec,
-                     uint64_t rows_out, double *out, hipStream_t stream, const double *init, bool short_lists)
+                     uint64_t rows_out, double *out, hipStream_t stream, const double *init, bool short_lists, double avg_len)
 {
-   sparse_rows_sum_t<double>(ptr, idx, V, rowscale, b, nrec, rows_out, out, stream, init, short_lists, nullptr);
+   sparse_rows_sum_t<double>(ptr, idx, V, rowscale, b, nrec, rows_out, out, stream, init, short_lists, nullptr, avg_len);
 }
 void sparse_rows_sum_f32(const uint32_t *ptr, const uint32_t *idx, const float *V, const double *colw, int b, uint64_t nrec, uint64_t rows_out,
-                         double *out, hipStream_t stream, const double *init, bool short_lists)
+                         double *out, hipStream_t stream, const double *init, bool short_lists, double avg_len)
 {
-   sparse_rows_sum_t<float>(ptr, idx, V, nullptr, b, nrec, rows_out, out, stream, init, short_lists, colw);
+   sparse_rows_sum_t<float>(ptr, idx, V, nullptr, b, nrec, rows_out, out, stream, init, short_lists, colw, avg_len);
 }
 
 // ------------------------------------------------------------------------------------------------
