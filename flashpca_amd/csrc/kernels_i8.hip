@@ -957,6 +957,18 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
          case 112: FPCA_I8_AB(112); break;
          default: FPCA_I8_AB(15); break;
          }
+      } else if (ab && sh.nt == 2 && sh.mt == 2) { // the 2-tile kernel of the 4-slice passes (profiles/r04_i8_ablation_2tile.txt)
+#define FPCA_I8_AB2(A_) launch_i8<I8Cfg<false, 2, 2, 4, 1, 256, 1, I8_NO_MISSING, A_>>(FPCA_I8_ARGS)
+         switch (ab) {
+         case 1: FPCA_I8_AB2(1); break;
+         case 2: FPCA_I8_AB2(2); break;
+         case 8: FPCA_I8_AB2(8); break;
+         case 16: FPCA_I8_AB2(16); break;
+         case 32: FPCA_I8_AB2(32); break;
+         case 48: FPCA_I8_AB2(48); break;
+         case 64: FPCA_I8_AB2(64); break;
+         default: FPCA_I8_AB2(15); break;
+         }
       } else
 #endif
       if (sh.half)
