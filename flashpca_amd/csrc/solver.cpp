@@ -269,6 +269,12 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    double tol_cheap = 0.8 * o.tol; // threshold for the estimates of the cheap passes (the exact residual sits within the noise of it)
    double best_cheap = 0;          // smallest worst-residual the current run of cheap passes has reached, and when
    int best_cheap_step = 0;
+   // The verification is paid for out of the same budget: kb exact passes until the rule can be judged on the Ritz blocks.  They
+   // are RESERVED while cheap passes run -- when only they are left, the cheap passes end whatever their estimates say, so that
+   // a budget that runs out returns Rayleigh-Ritz pairs of the exact operator (and "converged" if the rule holds on them), never
+   // a half-rebuilt T.  ritz_prefix: V[0 .. ritz_prefix) ARE the Ritz blocks of the last compression (until the next test).
+   const int reserve = kb;
+   int ritz_prefix = 0;
 
    // ---- start block ----------------------------------------------------------------------------
    int v0 = be.alloc_block();
@@ -499,7 +505,8 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          // "well above": by the decay of four more passes, at least a factor 2 -- a slow solve (decay 0.9-0.97 per pass) keeps
          // its Rayleigh-Ritz solves hidden until the last few tests, a fast one (0.1 and less) never launches ahead of a test
          const double margin = rho_last > 0 ? std::max(2.0, 1.0 / (rho_last * rho_last * rho_last * rho_last)) : 30.0;
-         if (res.block_applies + 1 < o.max_applies && (no_test || expected > margin * tol_est)) {
+         const bool reserved_next = cheap && res.block_applies + 1 >= o.max_applies - reserve; // (the next step ends the cheap passes)
+         if (res.block_applies + 1 < o.max_applies && !reserved_next && (no_test || expected > margin * tol_est)) {
             pend_in = na1 < M ? V[na1] : W;
             pend_out = be.alloc_block();
             pend_cheap = cheap;
@@ -538,7 +545,8 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       // orders of magnitude per block apply at best): it is skipped for a step (two when six orders away).  Convergence is
       // only ever declared by an actual test, so the worst case is one block apply more than strictly needed.
       if (n < k && skip_rr == 0) skip_rr = 1; // fewer basis columns than wanted pairs: nothing to test yet
-      if (skip_rr > 0 && res.block_applies < o.max_applies && na + 1 <= mcap && Mn + 1 <= Mmax) {
+      const bool last_cheap = cheap && tainted && res.block_applies >= o.max_applies - reserve; // only the reserved passes are left
+      if (skip_rr > 0 && !last_cheap && res.block_applies < o.max_applies && na + 1 <= mcap && Mn + 1 <= Mmax) {
          skip_rr--;
          host_s += since(t0);
          phase(PH_RR);
@@ -546,7 +554,19 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          W = pend_out >= 0 ? pend_out : be.alloc_block();
          continue;
       }
-      if (n < k) throw Error(-5, "solver: maxiter allows fewer basis vectors than the wanted number of eigenpairs");
+      if (n < k) {
+         // the budget ended between a compression and the first test on the rebuilt T: the Ritz blocks of that compression are
+         // what there is (S = identity over them, eigenvalue estimates of the last test) -- returned as not converged
+         if (ritz_prefix * b >= k && (int)V.size() >= ritz_prefix) {
+            n = ritz_prefix * b;
+            S.assign((size_t)n * n, 0.0);
+            for (int i = 0; i < n; i++) S[(size_t)i + (size_t)i * n] = 1.0;
+            host_s += since(t0);
+            break;
+         }
+         throw Error(-1, "solver: max_applies allows fewer basis vectors than the wanted number of eigenpairs");
+      }
+      ritz_prefix = 0;
       // rows of T below the applied part: the waiting blocks' coupling.  Only its trailing columns are populated (a block
       // couples to what was applied after it joined the basis): row_lo = first populated column
       const int nu = (Mn - na) * b;
@@ -602,7 +622,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
             stalled = true;
       }
       // cheap passes have met their threshold (or given up): the leading Ritz blocks go through the exact operator (below)
-      const bool verify = ((all_conv && tainted) || stalled) && !out_of_budget;
+      const bool verify = ((all_conv && tainted) || stalled || last_cheap) && !out_of_budget && o.max_applies - res.block_applies >= reserve;
       // number of leading Ritz blocks a compression keeps
       // Round 4: more of them when the basis has room -- kb + 3 blocks, at most a quarter of the cap.  Measured at 500,000 x
       // 100,000 with the 24-block cap (passes / wall, kept blocks 3 -> 5 for k = 20, 2 -> 4 for k = 10, 5 -> 6 for k = 50):
@@ -656,7 +676,8 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          prev_step = res.block_applies;
          // exact -> cheap passes: once the decay says that what is left pays for the kb exact passes of the verification
          // (a cheap pass saves about a quarter of an exact one).  From Ritz data only: every rank switches alike.
-         if (can_cheap && !cheap && verifications < 3 && ((n_est > 4.5 * kb + 4) || (verifications > 0))) {
+         if (can_cheap && !cheap && verifications < 3 && ((n_est > 4.5 * kb + 4) || (verifications > 0)) &&
+             o.max_applies - res.block_applies > reserve + 1) { // (room for at least one cheap pass before the reserved ones)
             cheap = true;
             be.set_cheap(true);
             if (o.verbose) std::fprintf(stderr, "[fpca] apply %3d: switching to cheap passes (about %.0f passes to go)\n", res.block_applies, n_est);
@@ -692,6 +713,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          tol_cheap *= 0.5; // (should the exact residuals fail the rule: the next round of cheap passes aims lower)
          // (until the next Rayleigh-Ritz the Ritz vectors ARE the blocks: what is returned if the budget ends right here)
          n = nkv * b;
+         ritz_prefix = nkv;
          S.assign((size_t)n * n, 0.0);
          for (int i = 0; i < n; i++) S[(size_t)i + (size_t)i * n] = 1.0;
          skip_rr = 0;
@@ -700,7 +722,7 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          keep.n = 0;
          if (o.verbose)
             std::fprintf(stderr, "[fpca] apply %3d: %s; %d Ritz block(s) go through the exact operator\n", res.block_applies,
-                         stalled ? "the cheap passes have stopped converging (noise floor)" : "estimates of the cheap passes meet the rule", nkv);
+                         stalled ? "the cheap passes have stopped converging (noise floor)" : all_conv ? "estimates of the cheap passes meet the rule" : "only the passes reserved for the verification are left", nkv);
          continue; // (W is free: it is overwritten by the next apply)
       }
 

@@ -258,6 +258,38 @@ def test_mixed_precision_passes_are_verified_by_exact_ones(golden_dir, k, bits, 
         assert r["applies"] <= r0["applies"] + 2 * -(-k // r["b"]) + 2  # cheap passes converge like exact ones (+ the verification)
 
 
+@pytest.mark.parametrize("k", [30, 50])
+def test_budget_ending_anywhere_in_the_verification_window_returns_ritz_pairs(golden_dir, k):
+    """max_applies swept across the window in which the cheap passes end and the Ritz blocks go through the exact operator
+    (a budget that ended between the compression and the first test on the rebuilt T threw, and FPCA_ENOTCONVERGED came
+    back with U / d never written).  The ceil(k/b) exact passes of the verification are reserved out of the budget: every cap
+    returns filled, descending eigenvalue estimates and orthonormal vectors; a cap that is one verification short of the
+    unconstrained solve still ends converged -- on exact residuals -- and no cap ever takes more passes than it allows."""
+    N = O.count_fam_rows(os.path.join(golden_dir, "data_chr1.fam"))
+    d = O.OracleData(os.path.join(golden_dir, "data_chr1.bed"), N, "binom2")
+    X = d.dense()
+    w = np.linalg.eigvalsh(X @ X.T)[::-1][:k] / d.P
+    rc0, r0 = run_pca(d, k, cheap_bits=30)
+    assert rc0 == 0 and r0["converged"] == 1 and r0["cheap_applies"] > 0
+    full = r0["applies"]
+    kb = -(-k // r0["b"])
+    seen_converged = False
+    for cap in range(full - 3 * kb - 4, full + 2):
+        rc, r = run_pca(d, k, cheap_bits=30, maxiter=-cap)
+        assert rc in (0, -5), (cap, rc)
+        assert r["applies"] <= cap and (rc == 0) == (r["converged"] == 1), (cap, r["applies"])
+        assert r["d"][0] > 0 and np.all(np.diff(r["d"]) <= 1e-12 * r["d"][0]), cap  # filled, descending
+        assert np.max(np.abs(r["d"] - w) / w) < (1e-9 if rc == 0 else 3e-2), cap  # (unconverged: estimates of a solve cut short)
+        assert np.max(np.abs(r["U"].T @ r["U"] - np.eye(k))) < 1e-8, cap
+        if r["cheap_applies"] > 0:  # the last ceil(k/b) passes were exact ones: what comes back are Rayleigh-Ritz pairs of the exact operator
+            assert r["applies"] - r["cheap_applies"] >= kb, cap
+        if rc == 0:
+            res = np.linalg.norm(X @ (X.T @ r["U"]) / d.P - r["U"] * r["d"], axis=0)
+            assert np.max(res / r["d"]) < 1.05e-6, cap
+            seen_converged = True
+    assert seen_converged
+
+
 def test_easy_spectrum_never_leaves_exact_arithmetic(golden_dir):
     """A solve that converges within a handful of passes is what it always was: no cheap pass, no verification."""
     N = O.count_fam_rows(os.path.join(golden_dir, "hapmap3_data.fam"))
