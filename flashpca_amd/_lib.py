@@ -45,6 +45,7 @@ class PcaOpts(C.Structure):
         ("max_applies", C.c_int),
         ("mixed", C.c_int),
         ("cheap_slices", C.c_int),
+        ("partial_rows", C.c_int),
     ]
 
 
@@ -71,7 +72,12 @@ class PcaInfo(C.Structure):
         ("cheap_applies", C.c_int),
         ("cheap_slices", C.c_int),
         ("seconds_exact", C.c_double),
+        ("solver_path", C.c_int),
     ]
+
+
+SOLVER_PATH = {0: "single", 1: "rowshard", 2: "replicated", 3: "replicated (self-test of the row-sharded exchange failed)",
+               4: "replicated (a collective of the row-sharded solve failed)"}
 
 
 class BenchResult(C.Structure):
@@ -125,6 +131,8 @@ SIGNATURES = {
     "fpca_set_rank": (_I, [_P, _I, _I]),
     "fpca_collective_stats": (_I, [_P, C.POINTER(_U64), C.POINTER(_U64)]),
     "fpca_pca_default_opts": (None, [C.POINTER(PcaOpts)]),
+    "fpca_pca_init_opts": (None, [C.POINTER(PcaOpts), C.c_size_t, C.c_size_t]),
+    "fpca_pca_row_ranges": (_I, [_P, C.POINTER(PcaOpts), C.POINTER(_U64), _I]),
     "fpca_pca": (_I, [_P, C.POINTER(PcaOpts), _P, _P, _P, _P, _P, _P, C.POINTER(PcaInfo)]),
     "fpca_check": (_I, [_P, _P, C.c_int64, _P, _I, _I, _P, C.POINTER(_D), C.POINTER(_D)]),
     "fpca_bench_apply": (_I, [_P, _I, _I, _I, C.POINTER(BenchResult)]),
@@ -137,9 +145,11 @@ SIGNATURES = {
     "fpca_debug_mfma_peak": (_I, [_I, _I, _I, C.POINTER(_D)]),
     "fpca_debug_census": (_I, [_I, _U64, _P]),
     "fpca_debug_k4": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P]),
+    "fpca_debug_k4_variant": (_I, [_I]),
+    "fpca_debug_k4_bench": (_I, [_P, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)]),
 }
 
-ABI_VERSION = 2  # FPCA_ABI_VERSION of the include/fpca.h the structures above mirror
+ABI_VERSION = 3  # FPCA_ABI_VERSION of the include/fpca.h the structures above mirror
 
 _lib = None
 _loaded = {}

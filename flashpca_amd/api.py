@@ -186,25 +186,38 @@ class Context:
 
     # ---- driver ---------------------------------------------------------------------------------------
     def pca(self, ndim=10, tol=1e-6, maxiter=500, div="p", do_loadings=False, blockvec=0, max_blocks=0, seed=1, verbose=0,
-            allow_unconverged=False, max_applies=0, replicated_solver=False, mixed=0, cheap_slices=0):
+            allow_unconverged=False, max_applies=0, replicated_solver=False, mixed=0, cheap_slices=0, partial_rows=False):
+        """fpca_pca.  allow_unconverged: FPCA_ENOTCONVERGED comes back as a result (info["converged"] == 0) whose U / d / Px / pve hold
+        the current Rayleigh-Ritz pairs (pca_driver.hpp) instead of raising.  partial_rows (several ranks): U / Px carry only this
+        rank's rows (result["row_ranges"]), NaN elsewhere."""
         o = PcaOpts()
-        lib().fpca_pca_default_opts(C.byref(o))
+        lib().fpca_pca_init_opts(C.byref(o), C.sizeof(PcaOpts), C.sizeof(PcaInfo))
         o.ndim, o.tol, o.maxiter, o.divisor = ndim, tol, maxiter, DIVISOR[div]
         o.do_loadings, o.blockvec, o.max_blocks, o.seed, o.verbose = int(do_loadings), blockvec, max_blocks, seed, verbose
         o.max_applies = max_applies
         o.replicated_solver = int(replicated_solver)
         o.mixed, o.cheap_slices = int(mixed), int(cheap_slices)  # mixed: 0 automatic (on), 1 on, -1 off (every pass exact)
-        U = np.empty((self.N, ndim), order="F")
-        d = np.empty(ndim)
-        Px = np.empty((self.N, ndim), order="F")
-        pve = np.empty(ndim)
+        o.partial_rows = int(partial_rows)
+        # (NaN-filled: whatever the library does not write -- another rank's rows under partial_rows, everything after a hard
+        #  error -- can never pass for a result)
+        U = np.full((self.N, ndim), np.nan, order="F")
+        d = np.full(ndim, np.nan)
+        Px = np.full((self.N, ndim), np.nan, order="F")
+        pve = np.full(ndim, np.nan)
         V = np.empty((self.P, ndim), order="F") if do_loadings else None
         ms = np.empty((self.P, 2), order="F")
         info = PcaInfo()
         rc = lib().fpca_pca(self.h, C.byref(o), _p(U), _p(d), _p(Px), _p(pve), _p(V), _p(ms), C.byref(info))
         if rc != 0 and not (allow_unconverged and rc == -5):
             check(rc)
-        return dict(U=U, d=d, Px=Px, pve=pve, V=V, meansd=ms, info={f[0]: getattr(info, f[0]) for f in PcaInfo._fields_})
+        out = dict(U=U, d=d, Px=Px, pve=pve, V=V, meansd=ms, info={f[0]: getattr(info, f[0]) for f in PcaInfo._fields_})
+        if partial_rows:
+            rg = (C.c_uint64 * 16)()
+            n = lib().fpca_pca_row_ranges(self.h, C.byref(o), rg, 8)
+            if n < 0:
+                check(n)
+            out["row_ranges"] = [(int(rg[2 * i]), int(rg[2 * i + 1])) for i in range(n)]
+        return out
 
     def check(self, evec, evals, div="p"):
         evec = np.asfortranarray(evec, dtype=np.float64)

@@ -83,6 +83,13 @@ class BlockBackend {
             for (uint64_t i = 0; i < N; i++) host2[i + (std::size_t)c * ld2] = dst[i + (std::size_t)c * ldd] * scale[c];
    }
 
+   // Several ranks: only the rows of the result THIS rank is responsible for (its slice of a row-sharded basis, or an even share of
+   // whole blocks) into the caller's N x ncols matrices -- no collective, 1 / G of the traffic per rank.  Default: everything.
+   virtual void download_rows_mine(int h, int ncols, double *host, int64_t ld, double *host2, int64_t ld2, const double *scale)
+   {
+      download2(h, ncols, host, ld, host2, ld2, scale);
+   }
+
    // sum over ranks of the shard traces sum X^2 (svdwide.cpp:44-45, 60-61)
    virtual double trace() = 0;
 

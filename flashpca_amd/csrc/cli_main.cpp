@@ -108,7 +108,8 @@ const OptSpec OPTS[] = {
    {"save-vinit", 0, false, "saves the initial v eigenvector for SCCA (no effect)"},
    {"version", 0, false, "version"},
    {"device", 0, true, "HIP device index [0] (with --gpus G: the first of G consecutive devices)", true},
-   {"gpus", 0, true, "number of GPUs for PCA [1]: the SNPs are split into that many contiguous shards, one process per GPU, partial products summed by an RCCL all-reduce", true},
+   {"gpus", 0, true, "number of GPUs for PCA [1]: the SNPs are split into that many contiguous shards, one process per GPU, partial products summed over RCCL", true},
+   {"solver", 0, true, "with --gpus: how the eigensolver's sample-sized work is laid out [rowshard | replicated]: rowshard (default) = every GPU keeps and orthogonalises 1/G of the rows of the Krylov basis (all-gather -> products -> reduce-scatter per pass); replicated = every GPU keeps the whole basis, ONE all-reduce of the N x b product per pass and nothing else on the wire.  rowshard checks its exchange once and falls back to replicated by itself if the check fails", true},
    {"blockvec", 0, true, "block width of the eigensolver: 16, 32, 48 or 64 [16; 32 / 64 for ndim > 64 / > 128]", true},
    {"maxblocks", 0, true, "basis cap (in blocks) before a thick restart [automatic]", true},
    {"passes", 0, true, "arithmetic of the eigensolver's passes in the exact-integer modes [mixed | exact]: mixed (default) = a solve that needs many passes makes most of them on 4 byte slices of the fp64 operand and puts the Ritz vectors through the exact operator before it declares convergence; exact = every pass on all slices", true},
@@ -243,6 +244,7 @@ struct Multi {
    int ngpus = 1, rank = 0;
    MultiShared *sh = nullptr;
    double *V = nullptr, *meansd = nullptr; // P x k and P x 2, column-major, in the shared region
+   double *U = nullptr, *Px = nullptr;     // N x k each, column-major, in the shared region: every rank writes its own rows
    double *slots = nullptr;                // FPCA_CLI_TEST_TRANSPORT=shm only: G x slot_cap doubles
    size_t slot_cap = 0;
    bool test_transport = false;
@@ -626,6 +628,15 @@ int main(int argc, char *argv[])
          }
       }
 
+      int replicated_solver = 0;
+      if (has("solver")) {
+         const std::string m = vm["solver"];
+         if (m == "replicated") replicated_solver = 1;
+         else if (m != "rowshard") {
+            std::cerr << "Error: unknown --solver layout (rowshard | replicated): " << m << std::endl;
+            return EXIT_FAILURE;
+         }
+      }
       int mixed = 0;
       if (has("passes")) {
          const std::string m = vm["passes"];
@@ -745,7 +756,7 @@ int main(int argc, char *argv[])
                          "hook for one-GPU boxes, not a way to run" << std::endl;
          mg.slot_cap = mg.test_transport ? (size_t)(N + 1024 + 512 * (size_t)ngpus) * 64 : 0; // the row-sharded solver's padded blocks
          const size_t head = (sizeof(MultiShared) + 63) / 64 * 64;
-         const size_t bytes = head + ((size_t)P_file * (n_dim + 2) + (size_t)ngpus * mg.slot_cap) * sizeof(double);
+         const size_t bytes = head + ((size_t)P_file * (n_dim + 2) + 2 * (size_t)N * n_dim + (size_t)ngpus * mg.slot_cap) * sizeof(double);
          void *mem = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
          if (mem == MAP_FAILED) throw std::runtime_error(std::string("mmap of the shared region failed: ") + strerror(errno));
          mg.sh = new (mem) MultiShared();
@@ -757,7 +768,9 @@ int main(int argc, char *argv[])
          mg.sh->msg[0] = 0;
          mg.V = reinterpret_cast<double *>(static_cast<char *>(mem) + head);
          mg.meansd = mg.V + (size_t)P_file * n_dim;
-         mg.slots = mg.meansd + (size_t)P_file * 2;
+         mg.U = mg.meansd + (size_t)P_file * 2;
+         mg.Px = mg.U + (size_t)N * n_dim;
+         mg.slots = mg.Px + (size_t)N * n_dim;
          std::cout.flush();
          std::fflush(nullptr);
          g_shared = mg.sh;
@@ -897,7 +910,7 @@ int main(int argc, char *argv[])
       if (mode == MODE_PCA) {
          std::cout << timestamp() << "PCA begin" << std::endl;
          fpca_pca_opts o;
-         fpca_pca_default_opts(&o);
+         FPCA_PCA_OPTS_INIT(&o);
          o.ndim = n_dim;
          o.blockvec = blockvec;
          o.maxiter = maxiter;
@@ -906,6 +919,7 @@ int main(int argc, char *argv[])
          o.do_loadings = do_loadings ? 1 : 0;
          o.max_blocks = maxblocks;
          o.mixed = mixed;
+         o.replicated_solver = replicated_solver;
          o.verbose = verbose ? 1 : 0;
          o.seed = (uint64_t)seed;
          d.resize(n_dim);
@@ -919,18 +933,15 @@ int main(int argc, char *argv[])
             meansd.resize((size_t)nsnps * 2);
             rc = fpca_pca(ctx, &o, U.data(), d.data(), Px.data(), pve.data(), do_loadings ? V.data() : nullptr, meansd.data(), &info);
          } else {
-            // eigenvectors / PCs are identical on every rank: only rank 0 downloads them; loadings and mean/sd are this
-            // shard's rows and go into the shared region at their place
+            // Eigenvectors / PCs: every rank downloads ITS OWN ROWS (its slice of the row-sharded basis, or an even share of the
+            // replicated one) straight into the shared region -- no gather of the Ritz blocks, no funnel through rank 0's PCIe
+            // link; loadings and mean/sd are this shard's rows and go into the shared region at their place
             const uint64_t P_loc = fpca_nsnps(ctx);
             std::vector<double> Vloc, msloc((size_t)P_loc * 2);
             if (do_loadings) Vloc.resize((size_t)P_loc * n_dim);
-            if (mg.rank == 0) {
-               U.resize((size_t)N * n_dim);
-               Px.resize((size_t)N * n_dim);
-            } else
-               o.verbose = 0;
-            rc = fpca_pca(ctx, &o, mg.rank == 0 ? U.data() : nullptr, d.data(), mg.rank == 0 ? Px.data() : nullptr, pve.data(),
-                          do_loadings ? Vloc.data() : nullptr, msloc.data(), &info);
+            if (mg.rank > 0) o.verbose = 0;
+            o.partial_rows = 1;
+            rc = fpca_pca(ctx, &o, mg.U, d.data(), mg.Px, pve.data(), do_loadings ? Vloc.data() : nullptr, msloc.data(), &info);
             if (rc != FPCA_OK && rc != FPCA_ENOTCONVERGED) multi_fail(mg, fpca_last_error());
             for (int c = 0; c < n_dim && do_loadings; c++)
                std::memcpy(mg.V + (size_t)c * nsnps + snp_begin, Vloc.data() + (size_t)c * P_loc, P_loc * sizeof(double));
@@ -953,11 +964,18 @@ int main(int argc, char *argv[])
             throw std::runtime_error("Spectra eigen-decomposition was not successful, status: not converging");
          fpca_ok(rc);
          verbose && std::cout << timestamp() << "GRM trace: " << info.trace << std::endl;
-         if (verbose && info.cheap_applies > 0)
-            std::cout << timestamp() << info.cheap_applies << " of them on " << info.cheap_slices << " byte slices of the operand, verified by exact passes" << std::endl;
          verbose && std::cout << timestamp() << info.block_applies << " block applies of width " << info.blockvec << " (" << info.vector_ops
                               << " vector operations), " << info.restarts << " restarts, device " << info.seconds_apply + info.seconds_ortho
                               << " s, host " << info.seconds_host << " s" << std::endl;
+         if (verbose && info.cheap_applies > 0)
+            std::cout << timestamp() << info.cheap_applies << " of the block applies on " << info.cheap_slices
+                      << " byte slices of the operand, verified by exact passes" << std::endl;
+         if (verbose && ngpus > 1) {
+            static const char *const names[] = {"single", "row-sharded", "replicated", "replicated (the self-test of the row-sharded exchange failed)",
+                                                "replicated (a collective of the row-sharded solve failed; started over)"};
+            std::cout << timestamp() << "eigensolver layout over " << ngpus << " GPUs: " << names[info.solver_path >= 0 && info.solver_path <= 4 ? info.solver_path : 0]
+                      << std::endl;
+         }
          std::cout << timestamp() << "PCA done" << std::endl;
       } else if (mode == MODE_CHECK) {
          // RandomPCA::check(Data&, block_size, evec_file, eval_file) (randompca.cpp:627-661)
@@ -1070,10 +1088,10 @@ int main(int argc, char *argv[])
                colnames_u[i + 1] = "U" + std::to_string(i + 1);
                colnames_pc[i + 1] = "PC" + std::to_string(i + 1);
             }
-            fpca::save_text(U.data(), N, n_dim, colnames_u, rownames, eigvecfile, precision, share);
+            fpca::save_text(ngpus > 1 ? mg.U : U.data(), N, n_dim, colnames_u, rownames, eigvecfile, precision, share); // (--gpus: the shared region)
 
             std::cout << timestamp() << "Writing " << n_dim << " PCs to file " << pcfile << std::endl;
-            fpca::save_text(Px.data(), N, n_dim, colnames_pc, rownames, pcfile, precision, share);
+            fpca::save_text(ngpus > 1 ? mg.Px : Px.data(), N, n_dim, colnames_pc, rownames, pcfile, precision, share);
 
             std::cout << timestamp() << "Writing " << n_dim << " proportion variance explained to file " << eigpvefile << std::endl;
             fpca::save_text(pve.data(), n_dim, 1, none, none, eigpvefile, precision);

@@ -369,7 +369,14 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
          }
 }
 
-// slots = workgroups the chip holds at once (256 CUs x resident workgroups per CU for this kernel's registers / LDS)
+// Split-K plan of an MFMA-bound GEMM.  The co-resident workgroups of a CU share its four matrix pipes, so what a launch takes is
+// the work the BUSIEST CU serialises through them -- ceil(workgroups / 256) x (chunks per workgroup + fill / drain) --, not the
+// number of "rounds" of resident workgroups: 391 SNP tiles unsplit put two workgroups on 135 CUs and one on 121 (0.76 of the
+// chip; this was the 16-column fp64 K2 of rounds 1-4), cut 13 ways they are 5,083 workgroups = 20 per CU with the last CU
+// 1 % short.  More splits cost one partial plane each (a write + a read of the output in the combine pass) and ~1.5 chunks of
+// fill / drain per workgroup; a CU left with a single workgroup cannot hide its staging behind a neighbour (x 1.4).
+// `slots` = workgroups the chip holds at once: plans that fit are placed round-robin (the count per CU is exact); larger grids
+// are fed as slots free up and balance themselves.
 static int pick_splits(uint64_t tiles, uint64_t chunks, int min_chunks, int max_splits, uint64_t slots)
 {
    uint64_t best_t = ~0ull;
@@ -378,10 +385,12 @@ static int pick_splits(uint64_t tiles, uint64_t chunks, int min_chunks, int max_
       uint64_t cps = (chunks + s - 1) / s;
       if (s > 1 && cps < (uint64_t)min_chunks) break;
       uint64_t seff = (chunks + cps - 1) / cps;
-      uint64_t rounds = (tiles * seff + slots - 1) / slots;
-      // time in 1/64 chunk units: every workgroup pays ~2 chunks of fill/drain on top of its cps chunks, and
-      // every extra partial costs a write + a read of the output in the combine pass
-      uint64_t t = rounds * (cps * 64 + 96) + (seff > 1 ? seff * 24 : 0);
+      const uint64_t wgs = tiles * seff, per_cu = (wgs + 255) / 256;
+      // time in 1/64 chunk units
+      uint64_t t = per_cu * (cps * 64 + 96);
+      if (wgs > slots) t += (cps * 64 + 96) / 2; // (dynamic placement: the last workgroups start when a slot frees, half a one late on average)
+      if (per_cu < 2) t = t * 7 / 5;
+      t += seff > 1 ? seff * 24 * ((tiles + 255) / 256) : 0; // the combine pass streams `seff` planes of the output
       if (t < best_t) {
          best_t = t;
          best = (int)seff;
@@ -1033,12 +1042,83 @@ __global__ __launch_bounds__(256) void k_gram(const double *const *__restrict__ 
          for (int r = 0; r < 4; r++) out[(size_t)(pt * 16 + kq + 4 * r) * b + nt * 16 + li] = acc[pt][nt][r];
 }
 
-// Rows per workgroup: enough workgroups to fill the chip several times over (nq blocks x splits >= ~1024) without making
-// the stack of partial planes (4 per workgroup) taller than it has to be.
-int gram_rows(uint64_t N_pad, int nq)
+// The same with ONE W tile serving QG basis blocks (blockIdx.y = group of QG blocks): what the chip moves for a Gram launch is
+// the basis once PLUS W once per workgroup row -- W does not fit in the 4 MB L2s, so every re-read comes over the fabric out of
+// the Infinity Cache, and with one basis block per workgroup row (k_gram) that is as many bytes again as the basis itself.
+// With QG = 8 the fabric carries 9/8 of the basis instead of 2x.
+template <int NT, int QG>
+__global__ __launch_bounds__(256) void k_gram_tiled(const double *const *__restrict__ blocks, const double *__restrict__ W,
+                                                     double *__restrict__ part, uint64_t N_pad, int nq)
 {
+   constexpr int b = 16 * NT;
+   constexpr int U = 2; // k-steps (of 4 rows) per chunk: (QG + 1) NT U loads in flight per wave
+   const int lane = threadIdx.x & 63;
+   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+   const int li = lane & 15, kq = lane >> 4;
+   const int q0 = blockIdx.y * QG;
+   const int nqg = min(QG, nq - q0);
+   const double *__restrict__ A[QG];
+#pragma unroll
+   for (int i = 0; i < QG; i++) A[i] = blocks[q0 + (i < nqg ? i : 0)]; // (slots beyond the last block re-read block q0: never stored)
+   const uint64_t nchunks = N_pad / (4 * U), total = (uint64_t)gridDim.x * 4;
+
+   d4 acc[QG][NT][NT];
+#pragma unroll
+   for (int i = 0; i < QG; i++)
+#pragma unroll
+      for (int pt = 0; pt < NT; pt++)
+#pragma unroll
+         for (int nt = 0; nt < NT; nt++) acc[i][pt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+
+   for (uint64_t ch = (uint64_t)blockIdx.x * 4 + wave; ch < nchunks; ch += total) {
+      const uint64_t s = ch * (4 * U);
+      double a[QG][U][NT], w[U][NT];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         const uint64_t off = (s + 4 * u + kq) * b + li;
+#pragma unroll
+         for (int nt = 0; nt < NT; nt++) w[u][nt] = W[off + nt * 16];
+#pragma unroll
+         for (int i = 0; i < QG; i++)
+#pragma unroll
+            for (int pt = 0; pt < NT; pt++) a[i][u][pt] = A[i][off + pt * 16];
+      }
+#pragma unroll
+      for (int i = 0; i < QG; i++)
+#pragma unroll
+         for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int pt = 0; pt < NT; pt++)
+#pragma unroll
+               for (int nt = 0; nt < NT; nt++) acc[i][pt][nt] = FPCA_MFMA(a[i][u][pt], w[u][nt], acc[i][pt][nt]);
+   }
+#pragma unroll
+   for (int i = 0; i < QG; i++) {
+      if (i >= nqg) break;
+      double *out = part + ((size_t)(blockIdx.x * 4 + wave) * nq + q0 + i) * (size_t)(b * b);
+#pragma unroll
+      for (int pt = 0; pt < NT; pt++)
+#pragma unroll
+         for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[(size_t)(pt * 16 + kq + 4 * r) * b + nt * 16 + li] = acc[i][pt][nt][r];
+   }
+}
+
+// basis blocks that share one W tile, by block width (accumulators: QG NT^2 x 8 registers)
+static inline int gram_group(int b) { return b == 16 ? 8 : b == 32 ? 2 : 1; }
+static int g_k4_variant = 1; // fpca_debug_k4_variant: 0 = round 4's kernels (one basis block per workgroup row / C from L1), 1 = tiled
+void k4_variant(int v) { g_k4_variant = v; }
+
+// Rows per workgroup: enough workgroups to fill the chip (groups x splits >= ~512: two per CU, each wave with (QG + 1) U NT loads
+// in flight; ~1024 with one block per workgroup row) without making the stack of partial planes (4 per workgroup) taller than it
+// has to be.
+int gram_rows(uint64_t N_pad, int nq, int b)
+{
+   const int QG = g_k4_variant ? gram_group(b) : 1;
+   const uint64_t groups = (uint64_t)((nq > 0 ? nq : 1) + QG - 1) / QG, want = QG > 1 ? 512 : 1024;
    uint64_t rows = 8192;
-   while (rows > 256 && (N_pad + rows - 1) / rows * (uint64_t)(nq > 0 ? nq : 1) < 1024) rows /= 2;
+   while (rows > 256 && (N_pad + rows - 1) / rows * groups < want) rows /= 2;
    return (int)rows;
 }
 
@@ -1048,6 +1128,16 @@ void gram(const double *const *blocks, int nq, const double *W, double *part, ui
 {
    if (nq <= 0) return;
    if (N_pad % 16) throw Error(-1, "gram: the block height must be a multiple of 16 rows");
+   const int QG = g_k4_variant ? gram_group(b) : 1;
+   if (QG > 1) {
+      dim3 grid((unsigned)gram_splits(N_pad, rows), (unsigned)((nq + QG - 1) / QG));
+      if (b == 16)
+         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram_tiled<1, 8>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, nq);
+      else
+         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram_tiled<2, 2>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, nq);
+      HIP_CHECK_LAUNCH();
+      return;
+   }
    dim3 grid((unsigned)gram_splits(N_pad, rows), (unsigned)nq); // (`rows` only sets the number of workgroups: 4 partial planes each)
    switch (b) {
    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<1>), grid, dim3(256), 0, stream, blocks, W, part, N_pad, rows, nq); break;
@@ -1108,9 +1198,90 @@ __global__ __launch_bounds__(256) void k_block_gemm(const double *const *__restr
       for (int r = 0; r < 4; r++) Out[(s0 + kq + 4 * r) * b + nt * 16 + li] = acc[nt][r];
 }
 
+// The same with the coefficients staged through LDS and TPW row tiles per wave.  In k_block_gemm every MFMA's B operand is an 8-byte
+// global load that hits L1 -- twice as many vector-memory instructions for C as for the basis rows the kernel is there to stream.
+// Here a workgroup copies QC coefficient blocks into LDS once (kq-group rows padded so that the four lane groups of a ds_read_b64
+// fall into different bank halves), every wave runs them against TPW tiles of 16 rows whose loads are issued together, and the
+// operand reads are LDS reads.  Reads of a wave's rows all precede its stores: Out may alias Init or any A_q.
+template <int NT, int QC, int TPW>
+__global__ __launch_bounds__(256) void k_block_gemm_lds(const double *const *__restrict__ blocks, int nq, const double *__restrict__ C,
+                                                         const double *Init, double *Out, uint64_t N_pad)
+{
+   constexpr int b = 16 * NT, KS = b / 4, GRP = KS * b + 16 /* doubles per kq group of one block, padded */, BLK = 4 * GRP;
+   __shared__ double Cs[QC * BLK];
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int li = lane & 15, kq = lane >> 4;
+   uint64_t s0[TPW];
+   bool ok[TPW]; // (wave-uniform) a tile past the end computes on tile 0's rows and stores nothing
+   d4 acc[TPW][NT];
+#pragma unroll
+   for (int t = 0; t < TPW; t++) {
+      s0[t] = (((uint64_t)blockIdx.x * 4 + wave) * TPW + t) * 16;
+      ok[t] = s0[t] < N_pad;
+      if (!ok[t]) s0[t] = 0;
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+         if (Init && ok[t]) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[t][nt][r] = Init[(s0[t] + kq + 4 * r) * b + nt * 16 + li];
+         } else
+            acc[t][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+      }
+   }
+   for (int q0 = 0; q0 < nq; q0 += QC) {
+      const int nqc = min(QC, nq - q0);
+      __syncthreads(); // (the previous stage's operand reads are done)
+      for (int idx = threadIdx.x; idx < nqc * (b * b / 2); idx += 256) { // pairs of doubles along c
+         const int qi = idx / (b * b / 2), rem = idx - qi * (b * b / 2), p = rem / (b / 2), c2 = rem - p * (b / 2);
+         const d2 v = reinterpret_cast<const d2 *>(C + (size_t)(q0 + qi) * b * b)[rem];
+         *reinterpret_cast<d2 *>(&Cs[qi * BLK + (p / KS) * GRP + (p % KS) * b + 2 * c2]) = v;
+      }
+      __syncthreads();
+      for (int qi = 0; qi < nqc; qi++) {
+         const double *A = blocks[q0 + qi];
+         d2 av[TPW][KS / 2];
+#pragma unroll
+         for (int t = 0; t < TPW; t++) {
+            const d2 *src = reinterpret_cast<const d2 *>(A + (s0[t] + li) * b + kq * KS);
+#pragma unroll
+            for (int r = 0; r < KS / 2; r++) av[t][r] = src[r];
+         }
+         const double *cq = &Cs[qi * BLK + kq * GRP + li];
+#pragma unroll
+         for (int tt = 0; tt < KS; tt++) {
+            double cv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) cv[nt] = cq[tt * b + nt * 16];
+#pragma unroll
+            for (int t = 0; t < TPW; t++)
+#pragma unroll
+               for (int nt = 0; nt < NT; nt++) acc[t][nt] = FPCA_MFMA((tt & 1) ? av[t][tt / 2].y : av[t][tt / 2].x, cv[nt], acc[t][nt]);
+         }
+      }
+   }
+#pragma unroll
+   for (int t = 0; t < TPW; t++) {
+      if (!ok[t]) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+         for (int r = 0; r < 4; r++) Out[(s0[t] + kq + 4 * r) * b + nt * 16 + li] = acc[t][nt][r];
+   }
+}
+
 void block_gemm(const double *const *blocks, int nq, const double *C, const double *Init, double *Out, uint64_t N_pad,
                 int b, hipStream_t stream)
 {
+   if (g_k4_variant && (b == 16 || b == 32) && N_pad >= 64) {
+      constexpr int TPW = 4;
+      dim3 grid((unsigned)((N_pad / 16 + 4 * TPW - 1) / (4 * TPW)));
+      if (b == 16)
+         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm_lds<1, 12, TPW>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad);
+      else
+         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm_lds<2, 3, TPW>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad);
+      HIP_CHECK_LAUNCH();
+      return;
+   }
    dim3 grid((unsigned)(N_pad / 64));
    switch (b) {
    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm<1>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad); break;

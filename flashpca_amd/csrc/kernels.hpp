@@ -49,9 +49,10 @@ void x_t_dense(const double *Xd, const double *T, double *Ypart, uint64_t N_pad,
 
 // K4 helpers on row-major [N_pad][b] blocks ------------------------------------------------------------
 // part[4*split + wave][q][b][b] (row-major p,c) = A_q^T W over the rows of one wave of split `split` (gram_splits(N_pad,
-// rows) workgroups of `rows` = gram_rows(N_pad, nq) rows each); `blocks` = device array of nq pointers
+// rows) workgroups of `rows` = gram_rows(N_pad, nq, b) rows each); `blocks` = device array of nq pointers
 void gram(const double *const *blocks, int nq, const double *W, double *part, uint64_t N_pad, int b, int rows, hipStream_t stream);
-int gram_rows(uint64_t N_pad, int nq);
+int gram_rows(uint64_t N_pad, int nq, int b);
+void k4_variant(int v); // lab switch (fpca_debug_k4_variant): 0 = round 4's K4 kernels, 1 = the tiled ones (default)
 int gram_splits(uint64_t N_pad, int rows);
 // Out = (Init ? Init : 0) + sum_q A_q C_q,   C: [nq][b][b] row-major (C_q[p][c]); Out may alias Init or any A_q
 void block_gemm(const double *const *blocks, int nq, const double *C, const double *Init, double *Out, uint64_t N_pad,

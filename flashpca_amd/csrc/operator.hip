@@ -1,0 +1,146 @@
+// operator.hip -- the block operator Y = X_g X_g' B on device-resident blocks (SVDWideOnline::perform_op / perform_op_mat,
+// svdwide.cpp:21-118, b columns at a time) and its halves (crossprod / prod, svdwide.cpp:122-226): dispatch between the
+// exact-integer stages (missing_routes.hip) and the fp64 / fp32 / dense MFMA kernels, split-K combines, and the two multi-GPU
+// shapes -- whole blocks + all-reduce, row-sharded blocks + all-gather / reduce-scatter.
+#include <algorithm>
+
+#include "ctx.hpp"
+
+using namespace fpca;
+
+namespace fpca {
+
+// the operator on device-resident blocks: dY = X_g X_g' dB (+ all-reduce).  ev (optional): 4 events recorded
+// at [start, after K2(+reduce), after K3(+reduce), after all-reduce].
+void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t s, hipEvent_t *ev, bool reduce)
+{
+   ensure_stats(c);
+   if (c->i8_S && ensure_i8(c, b)) {
+      c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
+      if (ev) HIP_CHECK(hipEventRecord(ev[0], s));
+      i8_zero_meta(c, s);
+      xt_i8(c, dB, b, s, true, ev ? ev + 4 : nullptr);
+      if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
+      const int nch = reduce ? ar_chunks(c) : 1;
+      if (nch > 1) {
+         if (ev) HIP_CHECK(hipEventRecord(ev[6], s)); // (chunked: the "GEMM kernel" interval spans all chunks, slicing included)
+         for (int i = 0; i < nch; i++) {
+            const uint64_t r0 = ar_chunk_begin(c, nch, i), r1 = ar_chunk_begin(c, nch, i + 1);
+            x_i8(c, b, dY, s, true, i == 0, r0, r1);
+            if (r1 <= r0) continue;
+            HIP_CHECK(hipEventRecord(c->ev_chunk[i], s));
+            HIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_chunk[i], 0));
+            RCCL_CHECK(rccl().AllReduce(dY + r0 * b, dY + r0 * b, (r1 - r0) * b, ncclDouble, ncclSum, c->comm, c->comm_stream));
+         }
+         if (ev) HIP_CHECK(hipEventRecord(ev[7], s));
+         if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
+         HIP_CHECK(hipEventRecord(c->ev_comm_done, c->comm_stream));
+         HIP_CHECK(hipStreamWaitEvent(s, c->ev_comm_done, 0));
+         if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
+         return;
+      }
+      x_i8(c, b, dY, s, true, true, 0, 0, ev ? ev + 6 : nullptr);
+      if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
+      if (reduce) allreduce_rows(c, dY, b, s);
+      if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
+      return;
+   }
+   const int s2 = c->dense ? kern::xt_b_dense_splits(c->N_pad, c->P_pad) : kern::xt_b_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
+   const int s3 = c->dense ? kern::x_t_dense_splits(c->N_pad, c->P_pad) : kern::x_t_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
+   c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
+   size_t need = 0;
+   if (s2 > 1) need = std::max(need, (size_t)s2 * c->P_pad * b);
+   if (s3 > 1) need = std::max(need, (size_t)s3 * c->N_pad * b);
+   if (need) c->ensure(c->d_part, c->part_cap, need);
+   if (ev) HIP_CHECK(hipEventRecord(ev[0], s));
+   if (ev) HIP_CHECK(hipEventRecord(ev[4], s));
+   if (c->dense)
+      kern::xt_b_dense(c->d_Xd, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, s);
+   else
+      kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, c->accum == FPCA_ACCUM_FP32, s);
+   if (ev) HIP_CHECK(hipEventRecord(ev[5], s));
+   if (s2 > 1) kern::reduce_sum(c->d_part, c->d_T, (uint64_t)c->P_pad * b, s2, s);
+   if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
+   if (ev) HIP_CHECK(hipEventRecord(ev[6], s));
+   if (c->dense)
+      kern::x_t_dense(c->d_Xd, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, s);
+   else
+      kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, c->accum == FPCA_ACCUM_FP32, s);
+   if (ev) HIP_CHECK(hipEventRecord(ev[7], s));
+   if (s3 > 1) kern::reduce_sum(c->d_part, dY, (uint64_t)c->N_pad * b, s3, s);
+   if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
+   if (reduce) allreduce_rows(c, dY, b, s);
+   if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
+}
+
+// The operator on a ROW-SHARDED block (the eigensolver's view, backend.hpp RowShard): all-gather the rows of the input block
+// (K2 sums over all samples), K2, K3 on the whole block, reduce-scatter the partial products -- the same bytes on the wire
+// as the all-reduce of apply_xxt_dev, but every rank ends up with only ITS rows of the sum, which is all the
+// orthogonalisation that follows needs.  With the built-in communicator and more than one chunk, K3 runs chunk by chunk
+// and the reduce-scatter of chunk i rides on the communication stream under the computation of chunk i + 1.
+void apply_sharded(fpca_ctx *c, const RowShard &sh, const double *in_slice, int b, double *out_slice, hipStream_t s)
+{
+   c->all_gather(sh, in_slice, c->d_full_in, b, s);
+   if (sh.nch > 1 && c->native_collectives() && c->comm_stream) {
+      ensure_stats(c);
+      if (c->i8_S && ensure_i8(c, b)) {
+         c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
+         i8_zero_meta(c, s);
+         xt_i8(c, c->d_full_in, b, s, true);
+         for (int i = 0; i < sh.nch; i++) {
+            const uint64_t r0 = std::min<uint64_t>((uint64_t)i * sh.L, c->N_pad), r1 = std::min<uint64_t>((uint64_t)(i + 1) * sh.L, c->N_pad);
+            if (r1 <= r0 && i > 0) { // a chunk wholly behind the last row (the same on every rank): no K3, no collective, zeros out
+               HIP_CHECK(hipMemsetAsync(out_slice + (size_t)i * sh.plen * b, 0, (size_t)sh.plen * b * sizeof(double), s));
+               continue;
+            }
+            x_i8(c, b, c->d_full_out, s, true, i == 0, r0, r1); // (rows >= N_pad of d_full_out stay zero: nothing writes them)
+            HIP_CHECK(hipEventRecord(c->ev_chunk[i], s));
+            HIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_chunk[i], 0));
+            c->reduce_scatter(sh, c->d_full_out, out_slice, b, c->comm_stream, i);
+         }
+         HIP_CHECK(hipEventRecord(c->ev_comm_done, c->comm_stream));
+         HIP_CHECK(hipStreamWaitEvent(s, c->ev_comm_done, 0));
+         return;
+      }
+   }
+   apply_xxt_dev(c, c->d_full_in, b, c->d_full_out, s, nullptr, false);
+   c->reduce_scatter(sh, c->d_full_out, out_slice, b, s);
+}
+
+void xt_dev(fpca_ctx *c, const double *dB, int b, hipStream_t s)
+{
+   ensure_stats(c);
+   if (c->i8_S && ensure_i8(c, b)) {
+      c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
+      i8_zero_meta(c, s);
+      xt_i8(c, dB, b, s, false);
+      return;
+   }
+   const int s2 = c->dense ? kern::xt_b_dense_splits(c->N_pad, c->P_pad) : kern::xt_b_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
+   c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
+   if (s2 > 1) c->ensure(c->d_part, c->part_cap, (size_t)s2 * c->P_pad * b);
+   if (c->dense)
+      kern::xt_b_dense(c->d_Xd, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, s);
+   else
+      kern::xt_b(c->d_packed, c->pitch, c->d_lut, dB, s2 > 1 ? c->d_part : c->d_T, c->N_pad, c->P_pad, b, s2, c->accum == FPCA_ACCUM_FP32, s);
+   if (s2 > 1) kern::reduce_sum(c->d_part, c->d_T, (uint64_t)c->P_pad * b, s2, s);
+}
+
+void x_dev(fpca_ctx *c, int b, double *dY, hipStream_t s)
+{
+   ensure_stats(c);
+   if (c->i8_S && ensure_i8(c, b)) {
+      i8_zero_meta(c, s);
+      x_i8(c, b, dY, s, false);
+      return;
+   }
+   const int s3 = c->dense ? kern::x_t_dense_splits(c->N_pad, c->P_pad) : kern::x_t_splits(c->N_pad, c->P_pad, b, c->accum == FPCA_ACCUM_FP32);
+   if (s3 > 1) c->ensure(c->d_part, c->part_cap, (size_t)s3 * c->N_pad * b);
+   if (c->dense)
+      kern::x_t_dense(c->d_Xd, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, s);
+   else
+      kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, c->accum == FPCA_ACCUM_FP32, s);
+   if (s3 > 1) kern::reduce_sum(c->d_part, dY, (uint64_t)c->N_pad * b, s3, s);
+}
+
+} // namespace fpca

@@ -100,9 +100,13 @@ int run_pca(BlockBackend &be, const fpca_pca_opts &o, uint64_t P_div, const PcaO
       // (copy into U, scaled copy into Px) running while the next chunk is on the wire (HipBackend::download2)
       std::vector<double> sq(k);
       for (int j = 0; j < k; j++) sq[j] = std::sqrt(d[j]);
-      for (int j0 = 0, q = 0; j0 < k; j0 += be.width(), q++)
-         be.download2(r.ritz_blocks[q], std::min(be.width(), k - j0), out.U ? out.U + (size_t)j0 * N : nullptr, (int64_t)N,
-                      out.Px ? out.Px + (size_t)j0 * N : nullptr, (int64_t)N, sq.data() + j0);
+      for (int j0 = 0, q = 0; j0 < k; j0 += be.width(), q++) {
+         double *u = out.U ? out.U + (size_t)j0 * N : nullptr, *px = out.Px ? out.Px + (size_t)j0 * N : nullptr;
+         if (out.partial_rows) // every rank its own rows: no gather of the Ritz blocks, no funnel through one PCIe link
+            be.download_rows_mine(r.ritz_blocks[q], std::min(be.width(), k - j0), u, (int64_t)N, px, (int64_t)N, sq.data() + j0);
+         else
+            be.download2(r.ritz_blocks[q], std::min(be.width(), k - j0), u, (int64_t)N, px, (int64_t)N, sq.data() + j0);
+      }
       sec_download = std::chrono::duration<double>(std::chrono::steady_clock::now() - td).count();
       lap("download U, Px = U sqrt(d)");
    }

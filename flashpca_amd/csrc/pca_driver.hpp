@@ -13,6 +13,7 @@ int choose_blockvec(int ndim, int requested);
 
 struct PcaOutputs {
    double *U = nullptr, *d = nullptr, *Px = nullptr, *pve = nullptr;
+   bool partial_rows = false; // several ranks: each writes only its own rows of U / Px (fpca_pca_opts.partial_rows)
 };
 
 // Runs the solver on `be` (whose width must equal choose_blockvec(...)).  N_div/P_div are the N and the TOTAL

@@ -32,12 +32,14 @@
 extern "C" {
 #endif
 
-#define FPCA_VERSION "0.2.0"
+#define FPCA_VERSION "0.3.0"
 /* Binary interface revision: bumped whenever a struct below changes size or a field changes meaning.  A binding checks
  * fpca_abi_version() == FPCA_ABI_VERSION once after loading the library (flashpca_amd/_lib.py does).
  *   2 (library 0.2.0): fpca_pca_opts / fpca_pca_info carry their own size and the mixed-precision fields; `maxiter` counts the
- *     reference's restarts (it was a cap on block applies in 0.1.0 -- use max_applies for that). */
-#define FPCA_ABI_VERSION 2
+ *     reference's restarts (it was a cap on block applies in 0.1.0 -- use max_applies for that).
+ *   3 (library 0.3.0): fpca_pca_opts.partial_rows, fpca_pca_info.solver_path; the struct sizes are the CALLER's
+ *     (FPCA_PCA_OPTS_INIT / fpca_pca_init_opts); fpca_pca_row_ranges. */
+#define FPCA_ABI_VERSION 3
 
 /* standardisation methods: same numeric values as the reference (util.h:34-38); the packed-genotype constructors
  * accept BINOM / BINOM2 like the CLI (flashpca.cpp:336-349), fpca_create_dense accepts all five */
@@ -211,8 +213,8 @@ int fpca_set_total_snps(fpca_ctx *ctx, uint64_t P_total);
  * With fewer than three block widths of samples (N < 3 b; the reference admits ndim <= (min(N,P)-1)/2, flashpca.cpp:623-633)
  * X X' is formed from ceil(N/b) applies on the identity and decomposed directly. */
 typedef struct fpca_pca_opts {
-   uint32_t struct_size; /* sizeof(fpca_pca_opts) / sizeof(fpca_pca_info) of the header the CALLER was compiled against; set by */
-   uint32_t info_size;   /* fpca_pca_default_opts, checked by fpca_pca (FPCA_EINVAL on a mismatch instead of reading garbage) */
+   uint32_t struct_size; /* sizeof(fpca_pca_opts) / sizeof(fpca_pca_info) of the header the CALLER was compiled against: written by */
+   uint32_t info_size;   /* FPCA_PCA_OPTS_INIT from the caller's own sizeof, checked by fpca_pca (FPCA_EINVAL on a mismatch) */
    int ndim;        /* --ndim (flashpca.cpp:325 default 10) */
    int blockvec;    /* block width b (16, 32, 48 or 64); 0 = automatic: 16 for ndim <= 64, 32 for ndim <= 128, else 64 -- the
                      * narrowest block gives the shortest time to solution (pca_driver.cpp).  ndim may exceed b -- up to the
@@ -242,7 +244,19 @@ typedef struct fpca_pca_opts {
                      * ||A u - theta u|| < tol max(eps^(2/3), |theta|) (randompca.cpp:173-178) is judged on exact residuals.  If
                      * it does not hold there, the iteration continues from those vectors with exact passes only. */
    int cheap_slices; /* 0 = automatic (4); 3..S-1 */
+   int partial_rows; /* multi-GPU only.  1 = this rank writes ONLY ITS OWN ROWS of U and Px (still N x ndim, leading dimension N):
+                     * its row slice of the row-sharded solver, or an even share of the rows under the replicated one -- no gather
+                     * of the eigenvector blocks, 1 / nranks of the PCIe traffic per rank.  For callers whose ranks share the
+                     * output memory (flashpca --gpus: one mmap'ed region) or gather the slices themselves
+                     * (fpca_pca_row_ranges).  0 (default) = every rank that passes U / Px gets all N rows. */
 } fpca_pca_opts;
+
+/* fpca_pca_info.solver_path: which layout of the eigensolver's N-sized work the solve ran on */
+#define FPCA_SOLVER_SINGLE 0              /* one rank */
+#define FPCA_SOLVER_ROWSHARD 1            /* row-sharded: all-gather -> K2, K3 -> reduce-scatter per apply (default for nranks > 1) */
+#define FPCA_SOLVER_REPLICATED 2          /* replicated, as asked (replicated_solver = 1, or an all-reduce hook without fpca_set_rank) */
+#define FPCA_SOLVER_REPLICATED_SELFTEST 3 /* replicated after the self-test of the row-sharded exchange failed on some rank */
+#define FPCA_SOLVER_REPLICATED_FAILURE 4  /* replicated, started over after a collective of the row-sharded solve reported a failure */
 
 typedef struct fpca_pca_info {
    int converged;         /* all ndim pairs met the rule (mixed precision: on residuals of the exact operator) */
@@ -261,9 +275,20 @@ typedef struct fpca_pca_info {
    int cheap_applies;       /* of block_applies: passes on cheap_slices byte slices (0 when mixed precision is off) */
    int cheap_slices;        /* slices of those passes (0: none ran) */
    double seconds_exact;    /* of seconds_apply: the exact passes (verification and whatever followed it) */
+   int solver_path;         /* FPCA_SOLVER_*: identical on every rank (a demotion is agreed through one all-reduce of a flag) */
 } fpca_pca_info;
 
+/* Defaults of the reference CLI (flashpca.cpp:276-484) + the CALLER's struct sizes, so that fpca_pca can refuse a caller built
+ * against another revision of this header: never more than opts_size bytes are written.  C callers use the macro. */
+void fpca_pca_init_opts(fpca_pca_opts *opts, size_t opts_size, size_t info_size);
+#define FPCA_PCA_OPTS_INIT(o) fpca_pca_init_opts((o), sizeof(*(o)), sizeof(fpca_pca_info))
+/* The same with the LIBRARY's own sizes: only for bindings that mirror the structs of this very header field by field
+ * and check fpca_abi_version() first (flashpca_amd/_lib.py). */
 void fpca_pca_default_opts(fpca_pca_opts *opts);
+/* partial_rows = 1: the row ranges [begin, end) of U / Px this rank writes -- ranges[2 i], ranges[2 i + 1], at most max_ranges of
+ * them are stored, the count is returned (<= 4; negative FPCA_E* on error).  After an fpca_pca call the answer reflects the
+ * layout that call ended on (a demotion to the replicated solver changes the ranges). */
+int fpca_pca_row_ranges(fpca_ctx *ctx, const fpca_pca_opts *opts, uint64_t *ranges, int max_ranges);
 /* Outputs (host, column-major, caller-allocated; any may be NULL):
  *   U  N x ndim eigenvectors (unit 2-norm, sign arbitrary like Spectra's) ..... RandomPCA::U
  *   d  ndim eigenvalues of X X'/div, descending .............................. RandomPCA::d

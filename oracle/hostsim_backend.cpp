@@ -21,7 +21,7 @@
 #include "fpca_oracle.h"
 
 namespace fpca {
-// libfpca.so defines this in device_ctx.hip; the test library needs its own copy
+// libfpca.so defines this in context.hip; the test library needs its own copy
 void set_last_error(const std::string &) {}
 } // namespace fpca
 

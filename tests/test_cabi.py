@@ -68,7 +68,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for n in names:
         assert hasattr(L, n), "libfpca.so does not export %s" % n
         assert n in _lib.SIGNATURES, "flashpca_amd/_lib.py has no signature for %s" % n
-    assert flashpca_amd.lib().fpca_version().decode() == "0.2.0"
+    assert flashpca_amd.lib().fpca_version().decode() == "0.3.0"
 
 
 def test_product_never_touches_the_oracle():

@@ -236,6 +236,62 @@ def test_cli_gpus_launcher_rccl_shaped_exchange(tmp_path, built_lib):
 
 
 @pytest.mark.gpu
+def test_cli_gpus_solver_switch_and_fail_safe_demotion(tmp_path, built_lib):
+    """`--solver rowshard|replicated` and the fail-safe of the row-sharded default (1a), with 2 and 3
+    processes on one device over the host-memory transports: (i) --solver replicated -- north_star's literal scheme, ONE
+    all-reduce of the N x b product per pass -- gives the single-process files; (ii) a reduce-scatter that reports a failure
+    half-way through the row-sharded solve (every rank: the call sequence is the same everywhere), a self-test that fails on
+    ONE rank only, and one that fails everywhere all end on the replicated solver with the same eigenvalues (1e-12) and say so
+    under --verbose; every rank has written its own rows of the eigenvectors / PCs into the shared region (1c: no funnel
+    through rank 0), so the files are complete.  Unknown --solver values are refused like unknown --accum values."""
+    import flashpca_amd as fp
+
+    N, P, k = 5000, 3000, 8
+    pre = str(tmp_path / "syn")
+    with fp.Context.synthetic(N, P, n_pop=6, accum="fp64") as c:
+        packed = c.download_packed()
+    with open(pre + ".bed", "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x01]))
+        packed.tofile(f)
+    open(pre + ".fam", "w").write("".join("F%d I%d 0 0 0 -9\n" % (i, i) for i in range(N)))
+    open(pre + ".bim", "w").write("".join("1 rs%d 0 %d A C\n" % (j, j + 1) for j in range(P)))
+    base = ["--bfile", pre, "--ndim", str(k), "--outload", "load.txt", "--outmeansd", "ms.txt", "--precision", "14", "--verbose"]
+    d1 = tmp_path / "one"
+    d1.mkdir()
+    r = subprocess.run([fp.CLI_PATH] + base, cwd=d1, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    e1 = np.loadtxt(d1 / "eigenvalues.txt")
+    U1, V1, m1 = _tab(d1 / "eigenvectors.txt"), _tab(d1 / "load.txt"), _tab(d1 / "ms.txt")
+    cases = [
+        ("replicated", 2, "shm", ["--solver", "replicated"], {}, "eigensolver layout over 2 GPUs: replicated\n"),
+        ("replicated3", 3, "shm2", ["--solver", "replicated"], {}, "eigensolver layout over 3 GPUs: replicated\n"),
+        ("rowshard", 3, "shm2", ["--solver", "rowshard"], {}, "eigensolver layout over 3 GPUs: row-sharded\n"),
+        ("rsfail", 2, "shm2", [], {"FPCA_DEBUG_RS_FAIL": "7", "FPCA_AR_CHUNKS": "2"}, "a collective of the row-sharded solve failed"),
+        ("rsfail3", 3, "shm2", [], {"FPCA_DEBUG_RS_FAIL": "5"}, "a collective of the row-sharded solve failed"),
+        ("selftest1", 3, "shm2", [], {"FPCA_DEBUG_SELFTEST_FAIL": "1"}, "the self-test of the row-sharded exchange failed"),
+        ("selftestall", 2, "shm", [], {"FPCA_DEBUG_SELFTEST_FAIL": "all"}, "the self-test of the row-sharded exchange failed"),
+    ]
+    for name, g, transport, extra, env_extra, says in cases:
+        d = tmp_path / name
+        d.mkdir()
+        env = dict(os.environ, FPCA_CLI_TEST_TRANSPORT=transport, **env_extra)
+        r = subprocess.run([fp.HOOKS_CLI_PATH] + base + ["--gpus", str(g)] + extra, cwd=d, capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, (name, r.stdout[-1500:] + r.stderr[-1500:])
+        assert says in r.stdout, (name, r.stdout[-1500:])
+        if env_extra.get("FPCA_DEBUG_RS_FAIL") or env_extra.get("FPCA_DEBUG_SELFTEST_FAIL"):
+            assert r.stderr.count("continues with the replicated solver") + r.stderr.count("starts over with the replicated solver") == g, (name, r.stderr[-1500:])
+        e, U, V, m = np.loadtxt(d / "eigenvalues.txt"), _tab(d / "eigenvectors.txt"), _tab(d / "load.txt"), _tab(d / "ms.txt")
+        sg = np.sign(np.sum(U1 * U, axis=0))
+        # the replicated solver follows the one-GPU iteration (whole blocks, same start block): eigenvalues to rounding
+        assert np.max(np.abs(e - e1) / e1) < (1e-10 if name == "rowshard" else 1e-12), (name, np.max(np.abs(e - e1) / e1))
+        assert np.max(np.abs(U * sg - U1)) < 1e-8 and np.max(np.abs(V * sg - V1)) < 1e-8, name
+        assert np.max(np.abs(_tab(d / "pcs.txt") * sg - _tab(d1 / "pcs.txt"))) < 1e-7, name
+        assert np.array_equal(m, m1)
+    r = subprocess.run([fp.CLI_PATH] + base + ["--solver", "sharded"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "unknown --solver layout" in r.stderr
+
+
+@pytest.mark.gpu
 def test_cli_gpus_launcher_failures_do_not_hang(tmp_path, built_lib, golden_dir):
     """A rank that dies (SIGKILL: what an OOM kill looks like), or rank 0 failing after the fork, must end the whole --gpus
     run promptly with a message and a non-zero status; what can be refused from the file sizes is refused before the fork."""

@@ -658,3 +658,45 @@ def test_row_sharded_solver_path_on_one_rank(fp, monkeypatch, nch, k):
         err, mse, rmse = c.check(r["U"], r["d"])
         assert np.all(np.sqrt(err) <= 1.01e-6 * r["d"])
         assert np.max(np.abs(r["Px"] - r["U"] * np.sqrt(r["d"]))) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fault", ["selftest", "reduce_scatter"])
+def test_row_sharded_exchange_failure_demotes_to_the_replicated_solver(fp, monkeypatch, fault):
+    """The never-run default of a multi-GPU solve must not be a single point of failure: when the self-test
+    of the row-sharded exchange fails, or a reduce-scatter of the solve reports an error half-way, the ranks agree -- one plain
+    all-reduce of a flag through the same communicator -- and the solve ends on the replicated solver (one all-reduce of the
+    N x b product per apply, svdwide.cpp:48-62 summed over ranks) with the same eigenvalues; fpca_pca_info.solver_path says
+    which path ran, and the context does not try the failed layout again.  One rank over RCCL (this box has one GPU): the
+    sharded code path is forced, the failure injected (test build only)."""
+    N, P, k = 40000, 1500, 10
+    with fp.Context.synthetic(N, P, n_pop=6, accum="i8") as ref:
+        r0 = ref.pca(ndim=k, do_loadings=True)
+        assert r0["info"]["solver_path"] == 0
+    monkeypatch.setenv("FPCA_AR_CHUNKS", "2")
+    monkeypatch.setenv("FPCA_FORCE_ROWSHARD", "1")
+    if fault == "selftest":
+        monkeypatch.setenv("FPCA_DEBUG_SELFTEST_FAIL", "all")
+    else:
+        monkeypatch.setenv("FPCA_DEBUG_RS_FAIL", "9")  # (two chunks per apply: the fifth apply fails)
+    with fp.test_hooks(), fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:
+        c.comm_init_rank(1, 0, fp.Context.comm_unique_id())
+        r = c.pca(ndim=k, do_loadings=True)
+        assert r["info"]["solver_path"] == (3 if fault == "selftest" else 4) and r["info"]["converged"] == 1
+        assert r["info"]["block_applies"] == r0["info"]["block_applies"]  # whole blocks on one rank: the plain iteration
+        assert np.max(np.abs(r["d"] - r0["d"]) / r0["d"]) < 1e-12
+        sg = np.sign(np.sum(r["U"] * r0["U"], axis=0))
+        assert np.max(np.abs(r["U"][:, :5] * sg[:5] - r0["U"][:, :5])) < 1e-9 and np.max(np.abs(r["V"][:, :5] * sg[:5] - r0["V"][:, :5])) < 1e-9
+        monkeypatch.delenv("FPCA_DEBUG_SELFTEST_FAIL", raising=False)
+        monkeypatch.delenv("FPCA_DEBUG_RS_FAIL", raising=False)
+        r2 = c.pca(ndim=k)  # the failed layout is remembered: straight to the replicated solver, no second self-test
+        assert r2["info"]["solver_path"] == (3 if fault == "selftest" else 4) and np.max(np.abs(r2["d"] - r0["d"]) / r0["d"]) < 1e-12
+    with fp.test_hooks(), fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:  # nothing injected: the sharded path itself
+        c.comm_init_rank(1, 0, fp.Context.comm_unique_id())
+        r = c.pca(ndim=k, partial_rows=True)
+        assert r["info"]["solver_path"] == 1
+        # one rank owns every row: the chunk-interleaved slice layout must put each row where it belongs
+        assert r["row_ranges"] and sum(b - a for a, b in r["row_ranges"]) == N and not np.isnan(r["U"]).any() and not np.isnan(r["Px"]).any()
+        sg = np.sign(np.sum(r["U"] * r0["U"], axis=0))
+        assert np.max(np.abs(r["d"] - r0["d"]) / r0["d"]) < 1e-10 and np.max(np.abs(r["U"][:, :5] * sg[:5] - r0["U"][:, :5])) < 1e-9
+        assert np.max(np.abs(r["Px"] - r["U"] * np.sqrt(r["d"]))) < 1e-12
