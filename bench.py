@@ -73,14 +73,15 @@ SPINUP = {"cfg2": 150, "tiny": 300, "cfg3": 4, "cfg5": 1, "cfg4shard": 20, "cfg5
 
 
 def _child(args, prof_args, steps, tmp):
-    """one child run of this bench (block applies only) under rocprofv3; returns the rows of the csv it wrote"""
+    """one child run of this bench (block applies only; args.accum may be overridden by the caller: the cheap passes run as
+    --accum i8x4) under rocprofv3; returns the rows of the csv it wrote"""
     import csv
     import glob
     import subprocess
 
     cmd = ["rocprofv3"] + prof_args + ["--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
            os.path.abspath(__file__), "--workload", args.workload, "--accum", args.accum, "--blockvec", str(args.blockvec),
-           "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-pca", "--no-alt", "--no-e2e", "--traffic", "none"]
+           "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-pca", "--no-alt", "--no-e2e", "--no-cheap", "--traffic", "none"]
     subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True,  # (a healthy child takes ~10 s)
                    env={k: v for k, v in dict(os.environ, TMPDIR="/tmp").items() if k != "LD_PRELOAD"})
     pat = "*kernel_trace.csv" if "--pmc" not in prof_args else "*counter_collection.csv"
@@ -102,7 +103,7 @@ def _dominant_rows(rows, args, dom, id_key="Dispatch_Id"):
     return [r for r in rows if key in r["Kernel_Name"]]
 
 
-def measure_counters(args, dom):
+def measure_counters(args, dom, hbm=True):
     """What hardware counters and the kernel trace say about the dominant GEMM kernel, from four child runs of this bench (block
     applies only) right after the timed region -- separate passes, as the guide prescribes:
       --pmc FETCH_SIZE, --pmc WRITE_SIZE       HBM bytes per launch (FETCH_SIZE counts 64 of every 128 B on gfx950: x2; KiB)
@@ -111,9 +112,21 @@ def measure_counters(args, dom):
     """
     import tempfile
 
-    res = dict(traffic=0.0)
+    res = dict(traffic=0.0 if hbm else None)
+    try:
+        tr = trace_gemms(args)
+        if dom == "auto":  # the slower of the two in event-free launches
+            dom = max(("xt_b", "x_t"), key=lambda d_: tr[d_][0] or 0.0)
+        res["ms_trace"], res["trace_launches"] = tr[dom]
+        res["ms_trace_both"] = {d_: tr[d_][0] for d_ in tr}
+    except Exception as e:
+        res["ms_trace"] = None
+        res["trace_error"] = str(e)[:200]
+        if dom == "auto":
+            dom = "x_t"
+    res["dom"] = dom
     alone_ns = []  # the dominant kernel's own duration in the counter runs: nothing runs beside it there
-    for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+    for counter, scale in ((("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)) if hbm else ()):
         with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
             rows = _dominant_rows(_child(args, ["--pmc", counter], 2, tmp), args, dom)
         vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter]
@@ -141,16 +154,20 @@ def measure_counters(args, dom):
         res["why"] = why
     except Exception as e:
         res["why"] = dict(error=str(e)[:200])
-    try:
-        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-            rows = _dominant_rows(_child(args, ["--kernel-trace"], 12, tmp), args, dom, id_key="Dispatch_Id")
-        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows][-10:]  # the timed region of the child: its last launches
-        res["ms_trace"] = sum(d) / len(d) * 1e-6 if d else None
-        res["trace_launches"] = len(d)
-    except Exception as e:
-        res["ms_trace"] = None
-        res["trace_error"] = str(e)[:200]
     return res
+
+
+def trace_gemms(args):
+    """event-free durations (ms) of the two GEMM kernels of a block apply: rocprofv3 --kernel-trace of a child run, last 10 launches each"""
+    import tempfile
+
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        rows = _child(args, ["--kernel-trace"], 12, tmp)
+    out = {}
+    for dom in ("xt_b", "x_t"):
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in _dominant_rows(rows, args, dom, id_key="Dispatch_Id")][-10:]
+        out[dom] = (sum(d) / len(d) * 1e-6 if d else None, len(d))
+    return out
 
 
 def e2e_cli(fp, size, k, device):
@@ -213,6 +230,70 @@ def e2e_cli(fp, size, k, device):
         shutil.rmtree(td, ignore_errors=True)
 
 
+def power_sample(enqueue, seconds=2.5):
+    """Package power and shader clock (rocm-smi --showpower --showclocks, as fast as it answers) WHILE `enqueue()` keeps the device
+    busy for about `seconds`: the question is whether the int8 GEMMs sit at the package power cap (MI355X: 1,400 W) with the
+    clock pulled down -- "throttled, not waiting" -- or run below it.  Samples under 60 % of the largest reading (ramp, drain) are
+    dropped.  Returns None where rocm-smi is missing or says nothing parsable."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+
+    if not shutil.which("rocm-smi"):
+        return None
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                o = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+            except Exception:
+                return
+            w = re.search(r"GPU\[0\].*?Package Power \(W\):\s*([0-9.]+)", o)
+            c = re.search(r"GPU\[0\].*?sclk clock level:.*?\((\d+)Mhz\)", o)
+            if w:
+                samples.append((float(w.group(1)), float(c.group(1)) if c else None))
+
+    th = threading.Thread(target=poll, daemon=True)
+    t_end = time.perf_counter() + seconds
+    th.start()
+    n = 0
+    while time.perf_counter() < t_end:
+        n += enqueue()
+    stop.set()
+    th.join(timeout=15)
+    cap = None
+    try:
+        m = re.search(r"GPU\[0\].*?Max Graphics Package Power \(W\):\s*([0-9.]+)", subprocess.run(["rocm-smi", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout)
+        cap = float(m.group(1)) if m else None
+    except Exception:
+        pass
+    if not samples:
+        return None
+    top = max(w for w, _ in samples)
+    busy = sorted((w, c) for w, c in samples if w >= 0.6 * top)
+    med = busy[len(busy) // 2]
+    clk = sorted(c for _, c in busy if c)
+    return dict(watts_median=med[0], watts_max=top, sclk_mhz_median=clk[len(clk) // 2] if clk else None, cap_watts=cap,
+                frac_of_cap=(med[0] / cap) if cap else None, samples=len(busy), samples_dropped=len(samples) - len(busy), applies_during_sampling=n,
+                source="rocm-smi --showpower --showclocks polled while the applies ran")
+
+
+def e2e_size_auto(N, P):
+    """The end-to-end CLI run takes the headline fileset (cfg3: a 12.5 GB .bed) when /tmp has room for it twice over and the machine
+    has the memory to keep it in the page cache, else the 50,000 x 20,000 one."""
+    import shutil
+
+    need = (N + 3) // 4 * P
+    try:
+        free = shutil.disk_usage("/tmp").free
+        mem = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_AVPHYS_PAGES")
+    except Exception:
+        return "cfg2"
+    return "cfg3" if (free > 2.2 * need and mem > 3 * need) else "cfg2"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,8 +313,10 @@ def main():
     ap.add_argument("--no-validate", action="store_true", help="several ranks: skip the self-validation against a one-context copy of the whole matrix on rank 0")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra exact-int8-mode measurement of the same workload")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run of the flashpca CLI on a fileset in /tmp")
-    ap.add_argument("--e2e-size", default="cfg2", choices=["cfg2", "cfg3"],
-                    help="fileset of the end-to-end CLI run [cfg2: 50000 x 20000, 250 MB; cfg3 writes and reads 12.5 GB]")
+    ap.add_argument("--e2e-size", default="auto", choices=["auto", "cfg2", "cfg3"],
+                    help="fileset of the end-to-end CLI run [auto: cfg3 -- the headline 500000 x 100000, a 12.5 GB .bed written to /tmp -- when "
+                         "/tmp and the page cache have room for it, else cfg2: 50000 x 20000, 250 MB]")
+    ap.add_argument("--no-cheap", action="store_true", help="skip the cheap_pass block (the eigensolver's 4-slice passes: kernel trace, counters, power sample)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the bounded baseline sample")
     ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "replay", "none"],
                     help="roofline.traffic: measure = two extra rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of a 2-step run of the "
@@ -517,6 +600,65 @@ def main():
                                          "decay predicts a long solve, then 4-slice passes verified by exact ones (see cheap_applies there)"),
                roofline=roofline)
 
+    # ---- what the realistic solves actually run: the eigensolver's CHEAP passes (block apply on 4 byte slices of the operand: the
+    # 2-column-tile instantiation of the int8 GEMM; 128 of the 141 passes of pca_realistic, 137 of 150 of pca_hard_spectrum) -- its own
+    # roofline, priced both ways (at 64 slice-columns the ridge puts the kernel on the HBM side: 1.57 ms at 8 TB/s against 1.27 ms of
+    # matrix work at the int8 issue peak), its counters, and the package power while it loops, beside the same sample of the exact
+    # apply: "throttled at the power cap, not waiting on memory" is a claim a power reading can refute -------------------------
+    if world == 1 and args.accum == "i8" and not args.no_cheap and not under_profiler:
+        S4 = 4
+        ops4 = 2.0 * N * P_rank * b * S4
+        cp = dict(what="block apply on %d byte slices of the f64 operand (30 bits below each column's maximum): the eigensolver's cheap passes, "
+                       "verified by exact ones before convergence is declared" % S4,
+                  kernel="k_gemm_i8<I8Cfg<false, 2, 2, ...>>: 64 slice-columns = 2 column tiles of 32", slices=S4, blockvec=b,
+                  ops_per_launch=ops4, algorithmic_bytes=roofline["algorithmic_bytes"], peak_mfma_tops=I8_MFMA_PEAK_TOPS, peak_hbm_gbs=HBM_PEAK_GBS)
+        try:
+            with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=min(2 * k, 64), device=local_rank, accum="i8x%d" % S4) as c4:
+                c4.set_total_snps(P_total)
+                c4.stats()
+                for _ in range(max(3, args.warmup)):
+                    c4.apply_xxt_dev(B.data_ptr(), b, Y.data_ptr())
+                c4.synchronize()
+                steps4 = max(8, args.steps // 2)
+                t1 = time.perf_counter()
+                for _ in range(steps4):
+                    c4.apply_xxt_dev(B.data_ptr(), b, Y.data_ptr())
+                c4.synchronize()
+                cp.update(steps=steps4, ms_per_step=(time.perf_counter() - t1) / steps4 * 1e3)
+                cp["speedup_vs_exact_step"] = (elapsed / args.steps * 1e3) / cp["ms_per_step"]
+
+                def enq4():
+                    for _ in range(8):
+                        c4.apply_xxt_dev(B.data_ptr(), b, Y.data_ptr())
+                    c4.synchronize()
+                    return 8
+
+                cp["power"] = power_sample(enq4)
+
+            def enq7():
+                for _ in range(8):
+                    ctx.apply_xxt_dev(B.data_ptr(), b, Y.data_ptr())
+                ctx.synchronize()
+                return 8
+
+            roofline["power"] = power_sample(enq7)
+            a4 = argparse.Namespace(**vars(args))
+            a4.accum = "i8x%d" % S4
+            cnt4 = measure_counters(a4, "auto", hbm=False)
+            if cnt4.get("ms_trace"):
+                ms4 = cnt4["ms_trace"]
+                cp.update(dominant=cnt4["dom"], ms_dominant_kernel=ms4, ms_gemm_kernels=cnt4.get("ms_trace_both"),
+                          achieved_tops=ops4 / (ms4 * 1e-3) / 1e12, frac_mfma=ops4 / (ms4 * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
+                          achieved_gbs=cp["algorithmic_bytes"] / (ms4 * 1e-3) / 1e9, frac_hbm=cp["algorithmic_bytes"] / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          duration_source="rocprofv3 --kernel-trace of a child run of this bench with --accum i8x%d (event-free block applies, last %d "
+                                          "launches of the slower GEMM)" % (S4, cnt4["trace_launches"]))
+            else:
+                cp["trace_error"] = cnt4.get("trace_error")
+            cp["why"] = cnt4.get("why")
+        except Exception as e:  # never lose the line over a side block
+            cp["error"] = str(e)[:300]
+        out["cheap_pass"] = cp
+
     # ---- several ranks: the line validates itself ---------------------------------------------------------------------------
     # Rank 0 additionally holds the WHOLE matrix in one context without a communicator (12.5 GB at the headline size) and applies
     # it to the same block: multi_rank_parity = max |Y_N - Y_1| / max |Y_1| (Y_N: what the N ranks' shards + the all-reduce of
@@ -667,10 +809,14 @@ def main():
                           wall_minus_apply_s=wall - info["seconds_apply"],
                           eigenvalue_1=float(r["d"][0]), eigenvalue_k=float(r["d"][-1]),
                           max_rel_residual=info["max_residual"])
-        out["pca"].update(cheap_applies=info["cheap_applies"], cheap_slices=info["cheap_slices"], seconds_apply_exact=info["seconds_exact"])
+        out["pca"].update(cheap_applies=info["cheap_applies"], cheap_slices=info["cheap_slices"], seconds_apply_exact=info["seconds_exact"],
+                          solver_path=fp._lib.SOLVER_PATH.get(info["solver_path"], str(info["solver_path"])))
         if world > 1:
-            out["pca"]["solver"] = ("replicated (one all-reduce per apply; the row-sharded solver FAILED, see pca_rowsharded_error)" if solver_kw else
-                                    "row-sharded (all-gather -> K2, K3 -> reduce-scatter per apply; every rank orthogonalises N / %d rows)" % world)
+            # (since round 5 the library demotes itself -- rank-agreed -- when the exchange self-test or a collective of the row-sharded
+            #  solve fails: info.solver_path says which layout the solve ended on; the try / except above is the second line of defence)
+            out["pca"]["solver"] = ("replicated (one all-reduce per apply; the row-sharded solver FAILED with an error, see pca_rowsharded_error)" if solver_kw else
+                                    "row-sharded (all-gather -> K2, K3 -> reduce-scatter per apply; every rank orthogonalises N / %d rows)" % world
+                                    if info["solver_path"] == 1 else "replicated by the library's own demotion: " + fp._lib.SOLVER_PATH.get(info["solver_path"], "?"))
             out["pca"]["collectives"] = dict(zip(("calls", "bytes"), ctx.collective_stats()))
             if not args.no_validate:
                 # the same solve with round 2's replicated solver (one all-reduce per apply, every rank keeps the whole basis), and
@@ -807,7 +953,9 @@ def main():
     # cache (just written), once after asking the kernel to drop it (fsync + posix_fadvise DONTNEED) ---------------------
     if world == 1 and not args.no_e2e and not under_profiler:  # (a profiler would follow the CLI child process too)
         try:
-            out["e2e_cli"] = e2e_cli(fp, args.e2e_size, k, local_rank)
+            size = args.e2e_size if args.e2e_size != "auto" else (e2e_size_auto(N, P_total) if args.workload == "cfg3" else "cfg2")
+            out["e2e_cli"] = e2e_cli(fp, size, k, local_rank)
+            out["e2e_cli"]["fileset"] = size + (": the headline fileset" if size == "cfg3" else "")
         except Exception as e:  # never lose the line over the side measurement
             out["e2e_cli"] = dict(error=str(e)[:300])
 

@@ -144,8 +144,8 @@ SIGNATURES = {
     "fpca_debug_mfma_i8_probe": (_I, [_P, _P, _P]),
     "fpca_debug_mfma_peak": (_I, [_I, _I, _I, C.POINTER(_D)]),
     "fpca_debug_census": (_I, [_I, _U64, _P]),
-    "fpca_debug_k4": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P]),
-    "fpca_debug_k4_variant": (_I, [_I]),
+    "fpca_debug_k4": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "fpca_debug_variant": (_I, [_I, _I]),
     "fpca_debug_k4_bench": (_I, [_P, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)]),
 }
 

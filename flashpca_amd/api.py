@@ -198,11 +198,13 @@ class Context:
         o.replicated_solver = int(replicated_solver)
         o.mixed, o.cheap_slices = int(mixed), int(cheap_slices)  # mixed: 0 automatic (on), 1 on, -1 off (every pass exact)
         o.partial_rows = int(partial_rows)
-        # (NaN-filled: whatever the library does not write -- another rank's rows under partial_rows, everything after a hard
-        #  error -- can never pass for a result)
-        U = np.full((self.N, ndim), np.nan, order="F")
+        # (the small outputs are NaN-filled: what the library does not write can never pass for a result; the N x ndim ones only
+        #  under partial_rows, where another rank's rows stay unwritten -- filling 160 MB costs a timed solve 8 ms of page faults,
+        #  and a call that fails raises, FPCA_ENOTCONVERGED fills everything)
+        mk = (lambda shape: np.full(shape, np.nan, order="F")) if partial_rows else (lambda shape: np.empty(shape, order="F"))
+        U = mk((self.N, ndim))
         d = np.full(ndim, np.nan)
-        Px = np.full((self.N, ndim), np.nan, order="F")
+        Px = mk((self.N, ndim))
         pve = np.full(ndim, np.nan)
         V = np.empty((self.P, ndim), order="F") if do_loadings else None
         ms = np.empty((self.P, 2), order="F")

@@ -66,6 +66,14 @@ class BlockBackend {
    // out = (init >= 0 ? block init : 0) + sum_q A_q C_q, C[q][p][c]; out may alias init or any a[q]
    virtual void gemm(const int *a, int nq, const double *C, int init, int out) = 0;
 
+   // gemm + the Gram matrix of what it wrote: G[p][c] = sum_s Out[s][p] Out[s][c] (host result => synchronises).  A backend that
+   // can produce G from the tile it has in registers saves a pass over the block; the default is the two calls.
+   virtual void gemm_gram(const int *a, int nq, const double *C, int init, int out, double *G)
+   {
+      gemm(a, nq, C, init, out);
+      gram(&out, 1, out, G);
+   }
+
    // first ncols columns of a block <-> host column-major N x ncols
    virtual void download(int h, int ncols, double *host, int64_t ld) = 0;
    virtual void upload(int h, int ncols, const double *host, int64_t ld) = 0;

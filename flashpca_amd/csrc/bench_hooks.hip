@@ -184,11 +184,11 @@ int fpca_debug_mfma_i8_probe(const int8_t *A, const int8_t *Bt, int32_t *D)
 }
 
 int fpca_debug_k4(fpca_ctx *ctx, int b, int nq, const double *V, const double *W, double *C_gram, const double *C_in, int use_init,
-                  double *Out)
+                  double *Out, double *G_out)
 {
    return guarded([&] {
       if (!ctx || !V || !W || nq < 1 || nq > 1000 || (b != 16 && b != 32 && b != 48 && b != 64)) throw Error(FPCA_EINVAL, "bad argument to fpca_debug_k4");
-      if (Out && !C_in) throw Error(FPCA_EINVAL, "fpca_debug_k4: Out needs C_in");
+      if ((Out || G_out) && !C_in) throw Error(FPCA_EINVAL, "fpca_debug_k4: Out needs C_in");
       HIP_CHECK(hipSetDevice(ctx->device));
       HipBackend be(ctx, b);
       const int64_t N = (int64_t)ctx->N;
@@ -200,10 +200,13 @@ int fpca_debug_k4(fpca_ctx *ctx, int b, int nq, const double *V, const double *W
       const int hw = be.alloc_block();
       be.upload(hw, b, W, N);
       if (C_gram) be.gram(hv.data(), nq, hw, C_gram);
-      if (Out) {
+      if (Out || G_out) {
          const int ho = be.alloc_block();
-         be.gemm(hv.data(), nq, C_in, use_init ? hw : -1, ho);
-         be.download(ho, b, Out, N);
+         if (G_out) // the update and the Gram matrix of its output from one launch (HipBackend::gemm_gram)
+            be.gemm_gram(hv.data(), nq, C_in, use_init ? hw : -1, ho, G_out);
+         else
+            be.gemm(hv.data(), nq, C_in, use_init ? hw : -1, ho);
+         if (Out) be.download(ho, b, Out, N);
          be.free_block(ho);
       }
       be.free_block(hw);
@@ -211,9 +214,12 @@ int fpca_debug_k4(fpca_ctx *ctx, int b, int nq, const double *V, const double *W
    });
 }
 
-int fpca_debug_k4_variant(int variant)
+int fpca_debug_variant(int which, int variant)
 {
-   kern::k4_variant(variant);
+   if (which == 0)
+      kern::k4_variant(variant);
+   else
+      return FPCA_EINVAL;
    return FPCA_OK;
 }
 

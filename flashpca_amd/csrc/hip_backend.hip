@@ -178,9 +178,8 @@ void HipBackend::gram(const int *a, int nq, int w, double *C)
    sec_other_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-void HipBackend::gemm(const int *a, int nq, const double *C, int init, int out)
+void HipBackend::gemm_launch(const int *a, int nq, const double *C, int init, int out, double *gram_part)
 {
-   auto t0 = std::chrono::steady_clock::now();
    const size_t cnt = (size_t)nq * b_ * b_;
    grow(d_C_, C_cap_, std::max(cnt, (size_t)1024 * b_ * 4));
    double *hc = pin_coeff(cnt);
@@ -190,7 +189,35 @@ void HipBackend::gemm(const int *a, int nq, const double *C, int init, int out)
    HIP_CHECK(hipEventRecord(ev_pin_, c_->stream));
    pin_busy_ = true;
    // not drained: d_C_ / d_ptrs_ are only rewritten by later copies on this same stream, i.e. after the kernel
-   kern::block_gemm(d_ptrs_, nq, d_C_, init >= 0 ? blocks_[init] : nullptr, blocks_[out], rows_, b_, c_->stream);
+   kern::block_gemm(d_ptrs_, nq, d_C_, init >= 0 ? blocks_[init] : nullptr, blocks_[out], rows_, b_, c_->stream, gram_part);
+}
+
+void HipBackend::gemm(const int *a, int nq, const double *C, int init, int out)
+{
+   auto t0 = std::chrono::steady_clock::now();
+   gemm_launch(a, nq, C, init, out, nullptr);
+   sec_other_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// the update and the Gram matrix of the block it writes in ONE pass over that block (k_block_gemm_lds<..., GRAM>)
+void HipBackend::gemm_gram(const int *a, int nq, const double *C, int init, int out, double *G)
+{
+   const int planes = kern::block_gemm_gram_planes(rows_, b_);
+   if (!planes) {
+      BlockBackend::gemm_gram(a, nq, C, init, out, G);
+      return;
+   }
+   auto t0 = std::chrono::steady_clock::now();
+   const size_t bb = (size_t)b_ * b_;
+   grow(d_gpart_, gpart_cap_, bb * planes + bb);
+   gemm_launch(a, nq, C, init, out, d_gpart_ + bb);
+   kern::reduce_sum(d_gpart_ + bb, d_gpart_, bb, planes, c_->stream);
+   if (sharded() && sh_.G > 1) c_->allreduce(d_gpart_, bb, c_->stream);
+   pin_wait(); // (the coefficients just pushed have been picked up before the pinned buffer is reused for the result)
+   double *hc = pin_coeff(bb);
+   HIP_CHECK(hipMemcpyAsync(hc, d_gpart_, bb * sizeof(double), hipMemcpyDeviceToHost, c_->stream));
+   HIP_CHECK(hipStreamSynchronize(c_->stream));
+   std::memcpy(G, hc, bb * sizeof(double));
    sec_other_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 

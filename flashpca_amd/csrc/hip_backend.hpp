@@ -39,6 +39,7 @@ class HipBackend : public BlockBackend {
    bool set_cheap(bool cheap) override;
    void gram(const int *a, int nq, int w, double *C) override;
    void gemm(const int *a, int nq, const double *C, int init, int out) override;
+   void gemm_gram(const int *a, int nq, const double *C, int init, int out, double *G) override;
    void download(int h, int ncols, double *host, int64_t ld) override { download2(h, ncols, host, ld, nullptr, 0, nullptr); }
    void download2(int h, int ncols, double *host, int64_t ld, double *host2, int64_t ld2, const double *scale) override;
    void download_rows_mine(int h, int ncols, double *host, int64_t ld, double *host2, int64_t ld2, const double *scale) override;
@@ -65,6 +66,7 @@ class HipBackend : public BlockBackend {
    void pin_wait();
    double *pin_coeff(size_t cnt);
    void push_ptrs(const int *a, int nq);
+   void gemm_launch(const int *a, int nq, const double *C, int init, int out, double *gram_part);
    void grow(double *&p, size_t &cap, size_t need);
 
    fpca_ctx *c_;

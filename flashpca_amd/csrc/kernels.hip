@@ -255,10 +255,13 @@ __device__ __forceinline__ void lds_put2(float *base, int idx, d2 v)
 //   code.  The loads of chunk c+1 are issued before the MFMAs of chunk c.  Split-K over samples (blockIdx.y) with a
 //   deterministic combine when there are too few SNP tiles to fill the chip.
 template <int NT> struct XtCfg {
-   static constexpr int KC = (NT <= 2) ? 128 : 64; // samples per LDS chunk: keeps the prefetch registers <= 32
+   // samples per LDS chunk: keeps the prefetch registers <= 32.  (Round 5 measured 256 for 16 columns -- half the barriers, staging
+   // passes and fp64 folds per MFMA -- at 500,000 x 100,000: fp64 24.1 -> 24.8 ms, fp32 14.3 -> 14.4; the 40 extra registers cost a
+   // resident wave per SIMD, which is worth more.  Not kept; K3 with 128-SNP chunks likewise: 24.4 -> 25.7 ms.)
+   static constexpr int KC = (NT <= 2) ? 128 : 64;
 };
 
-template <typename RT, int NT, int MT /* m-tiles (16 SNPs each) per wave; workgroup tile = 64*MT SNPs */>
+template <typename RT, int NT, int MT /* m-tiles (16 SNPs each) per wave; workgroup tile = 64*MT SNPs */, int KC /* samples per LDS chunk */>
 __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ packed, size_t pitch,
                                                   const double *__restrict__ lut, const double *__restrict__ B,
                                                   double *__restrict__ Tpart, uint64_t P_pad, int chunks_total,
@@ -268,7 +271,6 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
    constexpr bool MIXED = sizeof(RT) == 4;
    constexpr int b = 16 * NT;
    constexpr int TILE = 64 * MT;
-   constexpr int KC = XtCfg<NT>::KC;
    constexpr int NW = KC / 64;                    // packed dwords per lane per m-tile per chunk (16 samples each)
    constexpr int NLOAD = KC * b * 8 / (256 * 16); // 16-byte pieces of the (fp64) B tile per thread
    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -281,10 +283,17 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
    const int c_begin = blockIdx.y * chunks_per_split;
    int c_end = c_begin + chunks_per_split;
    if (c_end > chunks_total) c_end = chunks_total;
+   // The workgroup's table in LDS is laid out [16-SNP group][code][SNP in group]: the 16 lanes of an MFMA row group -- 16 different
+   // SNPs, whatever their codes -- then read 16 consecutive words = every bank once.  (Rounds 1-4 kept the HBM layout [SNP][code]:
+   // lanes li and li + 4 shared their banks whenever their codes agreed, 31-38 % of the LDS cycles of this kernel were conflicts.)
    if (tid < TILE) { // one SNP's 4-entry table per thread; visible after the first barrier of the chunk loop
       const d2 *lsrc = reinterpret_cast<const d2 *>(lut + ((uint64_t)blockIdx.x * TILE + tid) * 4);
-      lds_put2(sLut, tid * 2, lsrc[0]);
-      lds_put2(sLut, tid * 2 + 1, lsrc[1]);
+      const d2 e01 = lsrc[0], e23 = lsrc[1];
+      RT *dst = sLut + (tid >> 4) * 64 + (tid & 15);
+      dst[0] = (RT)e01.x;
+      dst[16] = (RT)e01.y;
+      dst[32] = (RT)e23.x;
+      dst[48] = (RT)e23.y;
    }
    const uint8_t *rowp[MT];
 #pragma unroll
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
    if (c_begin < c_end) FPCA_XTB_ISSUE(c_begin);
 
    const RT *sB_lane = sB + (size_t)((KC / 4) * kq) * b + li;
-   const RT *sLut_lane = sLut + (size_t)(wave * (16 * MT) + li) * 4;
+   const RT *sLut_lane = sLut + (size_t)(wave * MT) * 64 + li; // m-tile m, code c: sLut_lane[m * 64 + c * 16]
 
    for (int c = c_begin; c < c_end; c++) {
       __syncthreads(); // every wave has finished reading the previous B tile
@@ -329,21 +338,25 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
          for (int h = 0; h < NW; h++) pk[m][h] = pk_next[m][h];
       __syncthreads();
       if (c + 1 < c_end) FPCA_XTB_ISSUE(c + 1);
+      // k-step t + 1's operands (B fragment, MT table gathers) are read while step t's MFMAs run (see K3)
+      RT av[2][MT], bv[2][NT];
+#define FPCA_XTB_FETCH(tt_, slot_)                                                                                              \
+   {                                                                                                                            \
+      _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bv[slot_][nt] = sB_lane[(size_t)(tt_) * b + nt * 16];                   \
+      _Pragma("unroll") for (int m = 0; m < MT; m++) av[slot_][m] = sLut_lane[m * 64 + (((pk[m][(tt_) / 16] >> (2 * ((tt_) % 16))) & 3u) << 4)]; \
+   }
+      FPCA_XTB_FETCH(0, 0);
 #pragma unroll
-      for (int half = 0; half < NW; half++) {
+      for (int tt = 0; tt < 16 * NW; tt++) {
+         if (tt + 1 < 16 * NW) FPCA_XTB_FETCH(tt + 1, (tt + 1) & 1);
+         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-         for (int t = 0; t < 16; t++) {
-            RT bv[NT];
+         for (int m = 0; m < MT; m++)
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) bv[nt] = sB_lane[(size_t)(16 * half + t) * b + nt * 16];
-#pragma unroll
-            for (int m = 0; m < MT; m++) {
-               const RT a = sLut_lane[m * 64 + ((pk[m][half] >> (2 * t)) & 3u)];
-#pragma unroll
-               for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(a, bv[nt], acc[m][nt]);
-            }
-         }
+            for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(av[tt & 1][m], bv[tt & 1][nt], acc[m][nt]);
+         __builtin_amdgcn_sched_barrier(0);
       }
+#undef FPCA_XTB_FETCH
       if (MIXED) { // fold this chunk's fp32 partial sums into the fp64 accumulators
 #pragma unroll
          for (int m = 0; m < MT; m++)
@@ -401,8 +414,8 @@ static int pick_splits(uint64_t tiles, uint64_t chunks, int min_chunks, int max_
 
 int xt_b_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32)
 {
-   const int kc = b <= 32 ? 128 : 64;
-   const int tile = (fp32 && b >= 48) ? 128 : 256;
+   const int kc = b <= 32 ? 128 : 64; // XtCfg<NT>::KC
+   const int tile = ((fp32 && b >= 48) || (!fp32 && b == 16)) ? 128 : 256; // 64 XtMt<RT, NT>::MT
    static const int forced = FPCA_ENV_INT("FPCA_XT_SPLITS", 0);
    if (forced > 0) return (int)std::min<uint64_t>(forced, N_pad / kc);
    // fp64 with b <= 32 needs 145 VGPRs and 40 KB of LDS: three workgroups per CU are resident
@@ -411,7 +424,11 @@ int xt_b_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32)
 }
 
 template <typename RT, int NT> struct XtMt {
-   static constexpr int MT = (sizeof(RT) == 4 && NT >= 3) ? 2 : 4; // mixed mode carries fp32 + fp64 accumulators
+   // m-tiles of 16 SNPs per wave.  The mixed mode carries fp32 + fp64 accumulators (2 at b >= 48).  16 columns in fp64: 2 -- measured
+   // at 500,000 x 100,000 (profiles/r05_fp_kernels.txt): 8 m-tiles 25.4 ms, 4 (rounds 1-4) 24.2, 2 23.9; the narrow tile has 70
+   // registers, so more waves take turns on the matrix pipe, which at one MFMA per table gather is what this shape is short of.
+   // (fp32: 4 stays -- 14.4 ms against 14.7 with 2)
+   static constexpr int MT = (sizeof(RT) == 4 && NT >= 3) ? 2 : (sizeof(RT) == 8 && NT == 1) ? 2 : 4;
 };
 
 template <typename RT, int NT>
@@ -425,11 +442,11 @@ static void launch_xt_b(const uint8_t *packed, size_t pitch, const double *lut, 
    const size_t smem = ((size_t)KC * 16 * NT + 64 * MT * 4) * sizeof(RT);
    static bool attr_set = false;
    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xt_b<RT, NT, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xt_b<RT, NT, MT, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr_set = true;
    }
    dim3 grid((unsigned)(P_pad / (64 * MT)), (unsigned)nsplit);
-   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xt_b<RT, NT, MT>), grid, dim3(256), smem, stream, packed, pitch, lut, B, Tpart, P_pad,
+   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xt_b<RT, NT, MT, KC>), grid, dim3(256), smem, stream, packed, pitch, lut, B, Tpart, P_pad,
                       chunks_total, cps);
    HIP_CHECK_LAUNCH();
 }
@@ -535,24 +552,39 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
       }
       __syncthreads();
       if (c + 1 < c_end) FPCA_XT_ISSUE(c + 1);
+      // this lane's packed codes of the whole chunk go to registers in one batch of LDS reads: inside the loop the table gather of a
+      // k-step then hangs on ONE LDS round trip (code -> value), not two (record -> code -> value), like K2's register-resident words
+      uint32_t hh[KCX / 4];
 #pragma unroll
       for (int t = 0; t < KCX / 4; t++) {
-         uint32_t h;
          if (MT == 8)
-            h = *reinterpret_cast<const unsigned short *>(sP_lane + (size_t)(4 * t) * ROWB);
+            hh[t] = *reinterpret_cast<const unsigned short *>(sP_lane + (size_t)(4 * t) * ROWB);
          else
-            h = *(sP_lane + (size_t)(4 * t) * ROWB);
-         RT tv[NT];
-#pragma unroll
-         for (int nt = 0; nt < NT; nt++) tv[nt] = sT_lane[(size_t)(4 * t) * b + nt * 16];
-         const RT *lrow = sL_lane + (size_t)(4 * t) * 4;
-#pragma unroll
-         for (int m = 0; m < MT; m++) {
-            const RT a = lrow[(h >> (2 * m)) & 3u];
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(a, tv[nt], acc[m][nt]);
-         }
+            hh[t] = *(sP_lane + (size_t)(4 * t) * ROWB);
       }
+      // k-step t + 1's operands -- the T fragment and the MT table gathers -- are read while step t's MFMAs run: left to itself
+      // the compiler funnels every gather through one register pair (ds_read, s_waitcnt 0, v_mfma, MT times over), and a 64-cycle
+      // MFMA behind a ~100-cycle LDS round trip kept the pipe 74 % busy with four waves per SIMD taking turns (rounds 1-4)
+      RT av[2][MT], tv[2][NT];
+#define FPCA_XT_FETCH(t_, slot_)                                                                                    \
+   {                                                                                                                \
+      const uint32_t h_ = hh[t_];                                                                                   \
+      const RT *lrow_ = sL_lane + (size_t)(4 * (t_)) * 4;                                                           \
+      _Pragma("unroll") for (int nt = 0; nt < NT; nt++) tv[slot_][nt] = sT_lane[(size_t)(4 * (t_)) * b + nt * 16];  \
+      _Pragma("unroll") for (int m = 0; m < MT; m++) av[slot_][m] = lrow_[(h_ >> (2 * m)) & 3u];                    \
+   }
+      FPCA_XT_FETCH(0, 0);
+#pragma unroll
+      for (int t = 0; t < KCX / 4; t++) {
+         if (t + 1 < KCX / 4) FPCA_XT_FETCH(t + 1, (t + 1) & 1);
+         __builtin_amdgcn_sched_barrier(0); // (the fetch group stays ahead of the MFMA group it does not feed)
+#pragma unroll
+         for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(av[t & 1][m], tv[t & 1][nt], acc[m][nt]);
+         __builtin_amdgcn_sched_barrier(0);
+      }
+#undef FPCA_XT_FETCH
       if (MIXED) {
 #pragma unroll
          for (int m = 0; m < MT; m++)
@@ -1203,9 +1235,13 @@ __global__ __launch_bounds__(256) void k_block_gemm(const double *const *__restr
 // Here a workgroup copies QC coefficient blocks into LDS once (kq-group rows padded so that the four lane groups of a ds_read_b64
 // fall into different bank halves), every wave runs them against TPW tiles of 16 rows whose loads are issued together, and the
 // operand reads are LDS reads.  Reads of a wave's rows all precede its stores: Out may alias Init or any A_q.
-template <int NT, int QC, int TPW>
+// GRAM: the launch also leaves Out'Out -- one partial plane [b][b] per workgroup in gpart, to be summed by reduce_sum: the output
+// tile sits in the accumulators in exactly the layout both MFMA operands of W'W want (lane (li, kq), register r = row kq + 4r,
+// column li), so the Gram matrix of the block just written costs NT^2 x 4 MFMAs per tile and no memory traffic (the solver's
+// re-normalisation pass needs nothing else: it saves a launch that re-reads the block and one round trip to the host).
+template <int NT, int QC, int TPW, bool GRAM>
 __global__ __launch_bounds__(256) void k_block_gemm_lds(const double *const *__restrict__ blocks, int nq, const double *__restrict__ C,
-                                                         const double *Init, double *Out, uint64_t N_pad)
+                                                         const double *Init, double *Out, uint64_t N_pad, double *__restrict__ gpart)
 {
    constexpr int b = 16 * NT, KS = b / 4, GRP = KS * b + 16 /* doubles per kq group of one block, padded */, BLK = 4 * GRP;
    __shared__ double Cs[QC * BLK];
@@ -1267,18 +1303,73 @@ __global__ __launch_bounds__(256) void k_block_gemm_lds(const double *const *__r
 #pragma unroll
          for (int r = 0; r < 4; r++) Out[(s0[t] + kq + 4 * r) * b + nt * 16 + li] = acc[t][nt][r];
    }
+   if (GRAM) {
+      d4 g[NT][NT];
+#pragma unroll
+      for (int pt = 0; pt < NT; pt++)
+#pragma unroll
+         for (int nt = 0; nt < NT; nt++) g[pt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < TPW; t++) {
+         if (!ok[t]) continue;
+#pragma unroll
+         for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int pt = 0; pt < NT; pt++)
+#pragma unroll
+               for (int nt = 0; nt < NT; nt++) g[pt][nt] = FPCA_MFMA(acc[t][pt][r], acc[t][nt][r], g[pt][nt]);
+      }
+      // the four waves' planes are summed through LDS (fixed order), one plane per workgroup leaves
+      __syncthreads(); // (the coefficient stage is done with)
+      static_assert(3 * b * b <= QC * BLK, "the coefficient stage must hold three planes");
+      if (wave > 0) {
+#pragma unroll
+         for (int pt = 0; pt < NT; pt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+               for (int r = 0; r < 4; r++) Cs[(wave - 1) * b * b + (pt * 16 + kq + 4 * r) * b + nt * 16 + li] = g[pt][nt][r];
+      }
+      __syncthreads();
+      if (wave == 0) {
+         double *out = gpart + (size_t)blockIdx.x * (b * b);
+#pragma unroll
+         for (int pt = 0; pt < NT; pt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+               for (int r = 0; r < 4; r++) {
+                  const int idx = (pt * 16 + kq + 4 * r) * b + nt * 16 + li;
+                  out[idx] = ((g[pt][nt][r] + Cs[idx]) + Cs[b * b + idx]) + Cs[2 * b * b + idx];
+               }
+      }
+   }
+}
+
+constexpr int BG_TPW = 4; // row tiles per wave of k_block_gemm_lds
+int block_gemm_gram_planes(uint64_t N_pad, int b)
+{
+   return (g_k4_variant && (b == 16 || b == 32) && N_pad >= 64) ? (int)((N_pad / 16 + 4 * BG_TPW - 1) / (4 * BG_TPW)) : 0;
 }
 
 void block_gemm(const double *const *blocks, int nq, const double *C, const double *Init, double *Out, uint64_t N_pad,
-                int b, hipStream_t stream)
+                int b, hipStream_t stream, double *gram_part)
 {
+   if (gram_part && !block_gemm_gram_planes(N_pad, b)) throw Error(-1, "block_gemm: no fused Gram for this shape");
    if (g_k4_variant && (b == 16 || b == 32) && N_pad >= 64) {
-      constexpr int TPW = 4;
+      constexpr int TPW = BG_TPW;
       dim3 grid((unsigned)((N_pad / 16 + 4 * TPW - 1) / (4 * TPW)));
-      if (b == 16)
-         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm_lds<1, 12, TPW>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad);
-      else
-         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm_lds<2, 3, TPW>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad);
+      if (b == 16) {
+         if (gram_part)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm_lds<1, 12, TPW, true>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad, gram_part);
+         else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm_lds<1, 12, TPW, false>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad, nullptr);
+      } else {
+         if (gram_part)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm_lds<2, 3, TPW, true>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad, gram_part);
+         else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_gemm_lds<2, 3, TPW, false>), grid, dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad, nullptr);
+      }
       HIP_CHECK_LAUNCH();
       return;
    }

@@ -55,8 +55,11 @@ int gram_rows(uint64_t N_pad, int nq, int b);
 void k4_variant(int v); // lab switch (fpca_debug_k4_variant): 0 = round 4's K4 kernels, 1 = the tiled ones (default)
 int gram_splits(uint64_t N_pad, int rows);
 // Out = (Init ? Init : 0) + sum_q A_q C_q,   C: [nq][b][b] row-major (C_q[p][c]); Out may alias Init or any A_q
+// gram_part non-null (only where block_gemm_gram_planes(N_pad, b) > 0): the launch also leaves that many partial planes [b][b] of
+// Out' Out there (sum them with reduce_sum)
 void block_gemm(const double *const *blocks, int nq, const double *C, const double *Init, double *Out, uint64_t N_pad,
-                int b, hipStream_t stream);
+                int b, hipStream_t stream, double *gram_part = nullptr);
+int block_gemm_gram_planes(uint64_t N_pad, int b);
 // uniform(-0.5, 0.5) entries for rows < N, zero for rows in [N, N_pad)
 void fill_random(double *blk, uint64_t N, uint64_t rows, int b, uint64_t seed, hipStream_t stream, uint64_t row0 = 0);
 // *out_bits = max(*out_bits, bits of max |a - scale b|) over n doubles (NaN counts as +inf); out_bits zeroed by the caller

@@ -104,16 +104,34 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
             hyb = false;
          }
       }
-      if (hyb) {
-         HIP_CHECK(hipMemcpyAsync(c->d_hyb_idx, c->h_hyb_idx.data(), c->hyb_n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-         kern::gather_packed_rows(c->d_packed, c->pitch, c->d_hyb_idx, c->hyb_n, c->hyb_pad, c->d_packedE, s);
-         kern::patch_missing_rows(c->d_packed, c->pitch, c->d_hyb_idx, c->hyb_n, s);
-      }
-      kern::transpose_packed(c->d_packed, c->pitch, c->N_pad, c->P_pad, c->d_packedT, c->pitchT, s);
-      if (hyb) {
-         kern::scatter_packed_rows(c->d_packedE, c->pitch, c->d_hyb_idx, c->hyb_n, c->d_packed, s);
-         kern::transpose_packed(c->d_packedE, c->pitch, c->N_pad, c->hyb_pad, c->d_packedET, c->pitchET, s);
-         c->hyb_view = true;
+      bool patched = false;
+      try {
+         if (hyb) {
+            HIP_CHECK(hipMemcpyAsync(c->d_hyb_idx, c->h_hyb_idx.data(), c->hyb_n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            kern::gather_packed_rows(c->d_packed, c->pitch, c->d_hyb_idx, c->hyb_n, c->hyb_pad, c->d_packedE, s);
+            kern::patch_missing_rows(c->d_packed, c->pitch, c->d_hyb_idx, c->hyb_n, s);
+            patched = true;
+         }
+         kern::transpose_packed(c->d_packed, c->pitch, c->N_pad, c->P_pad, c->d_packedT, c->pitchT, s);
+         if (hyb) {
+            kern::scatter_packed_rows(c->d_packedE, c->pitch, c->d_hyb_idx, c->hyb_n, c->d_packed, s);
+            patched = false;
+            kern::transpose_packed(c->d_packedE, c->pitch, c->N_pad, c->hyb_pad, c->d_packedET, c->pitchET, s);
+            HIP_CHECK(hipStreamSynchronize(s)); // (a failed launch of the set-up surfaces HERE, not in some later apply)
+            c->hyb_view = true;
+         }
+      } catch (...) {
+         // the resident SNP-major matrix must never stay altered: every later K1 pass, fp64 apply and download reads it
+         if (patched) {
+            (void)hipGetLastError();
+            try {
+               kern::scatter_packed_rows(c->d_packedE, c->pitch, c->d_hyb_idx, c->hyb_n, c->d_packed, s);
+               (void)hipStreamSynchronize(s);
+            } catch (...) {
+            }
+         }
+         c->hyb_failed = true;
+         throw;
       }
       c->i8_transposed = true;
    }

@@ -392,9 +392,6 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
       const double zero_scale = scale * 16 * DBL_EPSILON * std::sqrt((double)N);
       int ndead = svqb_factor(b, Gw, zero_scale, M1, R1, dead);
       host_s += since(t0);
-      update_with(M1);
-      phase(PH_SVQB);
-
       // The third projection exists because the normalisation of pass 2 amplifies whatever component along V the first two
       // left behind (~eps of the column's norm BEFORE normalisation) by  max column norm / smallest pivot of the triangular
       // factor.  When that factor is small -- a well-conditioned block of comparable columns: every step of a slowly
@@ -417,11 +414,32 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          }
          light3 = upper && pmin > 0 && cmax / pmin < 1e4;
       }
+      // pass 2's update -- and, when pass 3 will only re-normalise, the Gram matrix of the block it writes from the same launch
+      // (BlockBackend::gemm_gram: no second pass over W, no second round trip)
+      {
+         const std::vector<double> &Mx = M1;
+         for (size_t qp = 0; qp < (size_t)M * b; qp++) {
+            const double *row = &C[qp * b];
+            double *out = &negC[qp * b];
+            for (int c = 0; c < b; c++) out[c] = 0.0;
+            for (int j = 0; j < b; j++) {
+               const double x = -row[j];
+               if (x == 0.0) continue;
+               const double *mj = &Mx[(size_t)j * b];
+               for (int c = 0; c < b; c++) out[c] += x * mj[c];
+            }
+         }
+         std::copy(Mx.begin(), Mx.end(), negC.begin() + (long)cnt);
+         if (light3) {
+            Gw.assign((size_t)b * b, 0.0);
+            be.gemm_gram(VW.data(), M + 1, negC.data(), -1, W, Gw.data());
+         } else
+            be.gemm(VW.data(), M + 1, negC.data(), -1, W);
+      }
+      phase(PH_SVQB);
       int nd2;
       if (light3) {
-         std::vector<double> &G3 = Gw;
-         G3.assign((size_t)b * b, 0.0);
-         be.gram(&W, 1, W, G3.data());
+         std::vector<double> &G3 = Gw; // (left there by the fused update + Gram launch of pass 2, below)
          t0 = clk::now();
          nd2 = svqb_factor(b, G3, 0.0, M2, R2, dead2);
          host_s += since(t0);

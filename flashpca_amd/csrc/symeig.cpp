@@ -402,19 +402,43 @@ int cols_core(int n, const double *A, int lda, const std::vector<double> &d, con
    // ~9 ms, which the pass in flight beside it does not cover) they are spread over a few threads.  Every column sees the same
    // arithmetic in the same order whatever the thread count: the result does not depend on it.
    const int T = (n >= 192 && ncols >= 32) ? std::max(1, std::min(std::min((int)usable_cpus(), 8), ncols / 8)) : 1;
-   auto on_columns = [&](auto &&fn) { // fn(c0, c1) -> int
+   // (per-thread scratch is allocated here, before anything is spawned; a thread body that throws reports 8, and whatever
+   //  has been started is joined before this function is left -- by return or by an exception from thread creation: a
+   //  non-zero return sends the caller to symeig_desc, nothing ends in std::terminate)
+   std::vector<std::vector<double>> scratch((size_t)T, std::vector<double>((size_t)n));
+   auto on_columns = [&](auto &&fn) { // fn(c0, c1, scratch) -> int
       std::vector<int> rcs((size_t)T, 0);
       std::vector<std::thread> th;
-      for (int t = 1; t < T; t++) th.emplace_back([&, t] { rcs[(size_t)t] = fn(ncols * t / T, ncols * (t + 1) / T); });
-      rcs[0] = fn(0, ncols / T);
+      struct Joiner {
+         std::vector<std::thread> &t;
+         ~Joiner()
+         {
+            for (auto &x : t)
+               if (x.joinable()) x.join();
+         }
+      } joiner{th};
+      auto body = [&](int t) {
+         try {
+            rcs[(size_t)t] = fn(ncols * t / T, ncols * (t + 1) / T, scratch[(size_t)t]);
+         } catch (...) {
+            rcs[(size_t)t] = 8;
+         }
+      };
+      try {
+         th.reserve((size_t)T);
+         for (int t = 1; t < T; t++) th.emplace_back(body, t);
+      } catch (...) { // thread creation failed: the columns of the threads that never started are done here
+         const int started = (int)th.size() + 1;
+         for (int t = started; t < T; t++) body(t);
+      }
+      body(0);
       for (auto &x : th) x.join();
       for (int rc : rcs)
          if (rc) return rc;
       return 0;
    };
    // back-transformation: z = H_0 H_1 ... H_{n-3} y
-   (void)on_columns([&](int c0, int c1) {
-      std::vector<double> v(n);
+   const int brc = on_columns([&](int c0, int c1, std::vector<double> &v) {
       for (int k = n - 3; k >= 0; k--) {
          if (beta[k] == 0.0) continue;
          const int m = n - k - 1;
@@ -430,12 +454,12 @@ int cols_core(int n, const double *A, int lda, const std::vector<double> &d, con
       }
       return 0;
    });
+   if (brc) return brc;
    // verification against the original matrix
    double anorm = 0;
    for (size_t i = 0; i < A0.size(); i++) anorm = std::max(anorm, std::fabs(A0[i]));
    anorm = std::max(anorm * n, tnorm);
-   const int vrc = on_columns([&](int c0, int c1) {
-      std::vector<double> r(n);
+   const int vrc = on_columns([&](int c0, int c1, std::vector<double> &r) {
       for (int c = c0; c < c1; c++) {
          const double *z = &y[(size_t)c * n];
          std::fill(r.begin(), r.end(), 0.0);

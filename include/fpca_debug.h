@@ -56,14 +56,16 @@ int fpca_debug_mfma_peak(int waves_per_simd, int iters, int pattern, double *tfl
  * through the very backend object the solver drives (HipBackend::gram incl. its split-K plane reduction, HipBackend::gemm).
  * V: N x (nq b) fp64 column-major with leading dimension N, basis block q = columns [q b, (q+1) b); W: N x b.
  *   C_gram (may be NULL): [q][p][c] = sum_s V_q[s][p] W[s][c]                       nq b b doubles
- *   Out (may be NULL), N x b: (use_init ? W : 0) + sum_q V_q C_in[q]                C_in: [q][p][c], nq b b doubles */
+ *   Out (may be NULL), N x b: (use_init ? W : 0) + sum_q V_q C_in[q]                C_in: [q][p][c], nq b b doubles
+ *   G_out (may be NULL): [p][c] = sum_s Out[s][p] Out[s][c], from the SAME launch that writes Out (HipBackend::gemm_gram)  b b doubles */
 int fpca_debug_k4(fpca_ctx *ctx, int b, int nq, const double *V, const double *W, double *C_gram, const double *C_in, int use_init,
-                  double *Out);
-/* lab: which K4 kernels the eigensolver's orthogonalisation runs (process-wide): 1 (default) = the tiled ones -- Gram with one W tile
- * per 8 basis blocks, block GEMM with its coefficients in LDS and four row tiles per wave --, 0 = round 4's; and their launch times
- * on nq device-resident random basis blocks of this context's height: ms per Gram (kernel + plane reduction) and per block GEMM
- * (Out = Init + sum_q V_q C_q) */
-int fpca_debug_k4_variant(int variant);
+                  double *Out, double *G_out);
+/* lab (process-wide A/B switches, 1 = default = the round-5 kernels, 0 = the kernels of rounds 1-4):
+ *   which 0: the K4 kernels of the eigensolver's orthogonalisation -- Gram with one W tile per 8 basis blocks, block GEMM with its
+ *            coefficients in LDS and four row tiles per wave.
+ * fpca_debug_k4_bench: launch times of the K4 kernels on nq device-resident random basis blocks of this context's height: ms per
+ * Gram (kernel + plane reduction) and per block GEMM (Out = Init + sum_q V_q C_q) */
+int fpca_debug_variant(int which, int variant);
 int fpca_debug_k4_bench(fpca_ctx *ctx, int b, int nq, int reps, double *ms_gram, double *ms_gemm);
 /* diagnostic: placement census of an nwg-workgroup grid (256 threads, lds_bytes dynamic LDS each): out[2i] = HW_ID,
  * out[2i+1] = XCC_ID of workgroup i */

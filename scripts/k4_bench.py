@@ -15,11 +15,11 @@ with fp.Context.synthetic(N, 512, n_pop=4, accum="fp64") as c:
         for nq in (1, 2, 8, 14, 24, 27):
             line = "b=%2d nq=%2d " % (b, nq)
             for variant in (0, 1):
-                L.fpca_debug_k4_variant(variant)
+                L.fpca_debug_variant(0, variant)
                 g, m = C.c_double(0), C.c_double(0)
                 rc = L.fpca_debug_k4_bench(c.h, b, nq, reps, C.byref(g), C.byref(m))
                 assert rc == 0, fp.lib().fpca_last_error()
                 gb = nq * rows * b * 8 / 1e9
                 line += "| v%d gram %.3f ms (%.2f TB/s)  gemm %.3f ms (%.2f TB/s) " % (variant, g.value, gb / g.value, m.value, gb / m.value)
             print(line, flush=True)
-    L.fpca_debug_k4_variant(1)
+    L.fpca_debug_variant(0, 1)

@@ -596,13 +596,17 @@ def test_k4_gram_and_block_gemm_at_full_height(fp, b, nq):
     Cin = rng.standard_normal((nq, b, b))
     Cg = np.empty((nq, b, b))
     Out = np.empty((N, b), order="F")
+    G = np.empty((b, b))
     with fp.Context.synthetic(N, 256, n_pop=4, accum="fp64") as ctx:
-        for use_init in (1, 0):
+        for use_init, fused in ((1, 0), (0, 0), (1, 1)):  # fused: the update and the Gram matrix of its output from one launch
             fp._lib.check(fp.lib().fpca_debug_k4(ctx.h, b, nq, V.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p),
                                                  Cg.ctypes.data_as(C.c_void_p), Cin.ctypes.data_as(C.c_void_p), use_init,
-                                                 Out.ctypes.data_as(C.c_void_p)))
+                                                 Out.ctypes.data_as(C.c_void_p), G.ctypes.data_as(C.c_void_p) if fused else None))
             ref = V @ Cin.reshape(nq * b, b) + (W if use_init else 0.0)
             assert np.max(np.abs(Out - ref)) <= 1e-12 * np.max(np.abs(ref)), (use_init,)
+            if fused:
+                Gr = ref.T @ ref
+                assert np.max(np.abs(G - Gr)) <= 1e-12 * np.max(np.abs(Gr)), np.max(np.abs(G - Gr))
     Gref = (V.T @ W).reshape(nq, b, b)
     # sums of 500,000 products of O(1) numbers: |error| ~ eps sqrt(N) per entry at worst for a blocked summation
     assert np.max(np.abs(Cg - Gref)) <= 2e-13 * np.sqrt(N), np.max(np.abs(Cg - Gref))
