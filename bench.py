@@ -740,6 +740,22 @@ def main():
             sm["slowdown_vs_value"] = sm["ms_per_step"] / (elapsed / args.steps * 1e3)
             out["apply_at_missing_2pct"] = sm
 
+    # (c) ... and with the SAME 2 % of the calls missing, but per-SNP rates log-normally distributed (sd of ln(rate) 1.5: most SNPs below
+    #     1 %, a long tail of poor assays) -- where real arrays sit, between "uniform" and the concentrated profile of pca_realistic.  The
+    #     route is chosen from a cost model over K1's per-SNP counts (missing_routes.hip hybrid_classify): SNPs whose calls cost more to
+    #     gather than their indicator row costs on the matrix cores go dense, the shard goes hybrid if that beats the two-matrix kernels
+    if world == 1 and not args.no_alt and args.accum.startswith("i8"):
+        for tag, mean in (("apply_at_missing_2pct_lognormal", 0.02), ("apply_at_missing_1pct_lognormal", 0.01)):
+            with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=min(2 * k, 64), missing_rate=mean, missing_model=2, lognormal_sigma=1.5,
+                                      device=local_rank, accum=args.accum) as cm:
+                cm.set_total_snps(P_total)
+                ms_l, _ = cm.stats()
+                sm = side_apply(cm, b, max(4, args.steps // 8))
+                sm["missing_call_rate_mean"] = mean
+                sm["lognormal_sigma"] = 1.5
+                sm["slowdown_vs_value"] = sm["ms_per_step"] / (elapsed / args.steps * 1e3)
+                out[tag] = sm
+
     # ---- one full PCA solve to convergence (reported, not the timed region) -------------------------------
     watchdog = None
     if not args.no_pca and world > 1:

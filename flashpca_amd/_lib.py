@@ -51,7 +51,7 @@ class PcaOpts(C.Structure):
 
 class SynthModel(C.Structure):
     _fields_ = [("n_pop", C.c_int), ("fst", C.c_double), ("missing_rate", C.c_double), ("maf_model", C.c_int), ("missing_model", C.c_int),
-                ("conc_frac", C.c_double)]
+                ("conc_frac", C.c_double), ("lognormal_sigma", C.c_double)]
 
 
 class PcaInfo(C.Structure):

@@ -84,12 +84,12 @@ class Context:
 
     @classmethod
     def synthetic(cls, N, P, snp_begin=0, seed=20260928, n_pop=40, fst=0.05, missing_rate=0.001, stand="binom2", device=0,
-                  accum="fp64", realistic=False, maf_model=None, missing_model=None, conc_frac=0.05):
+                  accum="fp64", realistic=False, maf_model=None, missing_model=None, conc_frac=0.05, lognormal_sigma=0.0):
         """realistic=True: the round-4 profile (synth.hpp) -- rare-variant allele-frequency spectrum, missing calls concentrated in
         5 % of the SNPs (maf_model / missing_model = 1; either can be chosen alone)."""
         h = C.c_void_p()
         m = _lib.SynthModel(n_pop, fst, missing_rate, int(realistic if maf_model is None else maf_model),
-                            int(realistic if missing_model is None else missing_model), conc_frac)
+                            int(realistic if missing_model is None else missing_model), conc_frac, lognormal_sigma)
         check(lib().fpca_create_synthetic_model(C.byref(h), N, snp_begin, P, seed, C.byref(m), STANDARDISE[stand], device, ACCUM[accum]))
         return cls(h)
 

@@ -226,13 +226,20 @@ int fpca_create_synthetic_model(fpca_ctx **out, uint64_t N, uint64_t snp_begin, 
       const double fst = model->fst, missing_rate = model->missing_rate;
       if (n_pop < 1 || n_pop > synth::MAX_POP) throw Error(FPCA_EINVAL, "n_pop must be in 1..64");
       if (!(fst >= 0 && fst < 1) || !(missing_rate >= 0 && missing_rate < 1)) throw Error(FPCA_EINVAL, "fst / missing_rate out of range");
-      if ((model->maf_model | 1) != 1 || (model->missing_model | 1) != 1 || !(model->conc_frac >= 0 && model->conc_frac <= 1))
-         throw Error(FPCA_EINVAL, "maf_model / missing_model must be 0 or 1, conc_frac in [0, 1]");
+      if ((model->maf_model | 1) != 1 || model->missing_model < 0 || model->missing_model > 2 || !(model->conc_frac >= 0 && model->conc_frac <= 1))
+         throw Error(FPCA_EINVAL, "maf_model must be 0 or 1, missing_model 0, 1 or 2, conc_frac in [0, 1]");
+      if (model->missing_model == 2 && !(model->lognormal_sigma >= 0 && model->lognormal_sigma <= 4))
+         throw Error(FPCA_EINVAL, "lognormal_sigma must be in [0, 4]");
       ctx_alloc_common(c, N, P_g, stand_method, device, accum);
       const uint32_t fst_fp = (uint32_t)std::llround(fst * 65536.0);
       const uint32_t miss_thr = (uint32_t)std::llround(missing_rate * 65536.0);
+      // log-normal rates: the median that gives the asked-for mean, in 0.32 fixed point; sigma as a power of two (host libm only sets
+      // these two integers: the matrix itself is integer arithmetic, identical on every host and device)
+      const double sig = model->missing_model == 2 ? model->lognormal_sigma : 0.0;
+      const uint64_t med_q32 = (uint64_t)std::llround(std::min(missing_rate * std::exp(-0.5 * sig * sig), 0.9) * 4294967296.0);
+      const uint32_t sig2_fp = (uint32_t)std::llround(sig / std::log(2.0) * 65536.0);
       kern::synth_generate(c->d_packed, c->pitch, N, snp_begin, P_g, seed, n_pop, fst_fp, miss_thr, c->stream, model->maf_model, model->missing_model,
-                           (uint32_t)std::llround(model->conc_frac * 65536.0));
+                           (uint32_t)std::llround(model->conc_frac * 65536.0), med_q32, sig2_fp);
       HIP_CHECK(hipStreamSynchronize(c->stream));
    });
    if (rc != FPCA_OK) {

@@ -1516,13 +1516,14 @@ void colmajor_to_t(const double *in, uint64_t ld, uint64_t P_g, uint64_t P_pad, 
 // thread per iteration; integer-only model of synth.hpp, so the host can reproduce any record bit for bit.
 __global__ __launch_bounds__(256) void k_synth_generate(uint8_t *packed, size_t pitch, uint64_t N, uint64_t snp_begin,
                                                          uint64_t seed, int n_pop, uint32_t fst_fp, uint32_t miss_thr, int maf_model,
-                                                         int missing_model, uint32_t conc_fp)
+                                                         int missing_model, uint32_t conc_fp, uint64_t med_q32, uint32_t sig2_fp)
 {
    __shared__ uint32_t thr[synth::MAX_POP];
    __shared__ uint64_t bnd[synth::MAX_POP + 1];
    const uint64_t snp = snp_begin + blockIdx.x;
    const uint32_t pj = maf_model == 1 ? synth::snp_freq_rare(seed, snp) : synth::snp_freq(seed, snp);
    if (missing_model == 1) miss_thr = synth::snp_miss_thr_concentrated(seed, snp, conc_fp);
+   if (missing_model == 2) miss_thr = synth::snp_miss_thr_lognormal(seed, snp, med_q32, sig2_fp);
    if ((int)threadIdx.x < n_pop) thr[threadIdx.x] = synth::pop_freq(seed, snp, pj, fst_fp, (int)threadIdx.x);
    if ((int)threadIdx.x <= n_pop) bnd[threadIdx.x] = synth::pop_boundary(N, n_pop, (int)threadIdx.x);
    __syncthreads();
@@ -1557,11 +1558,12 @@ __global__ __launch_bounds__(256) void k_synth_generate(uint8_t *packed, size_t 
 }
 
 void synth_generate(uint8_t *packed, size_t pitch, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed,
-                    int n_pop, uint32_t fst_fp, uint32_t miss_thr, hipStream_t stream, int maf_model, int missing_model, uint32_t conc_fp)
+                    int n_pop, uint32_t fst_fp, uint32_t miss_thr, hipStream_t stream, int maf_model, int missing_model, uint32_t conc_fp,
+                    uint64_t med_q32, uint32_t sig2_fp)
 {
    if (P_g == 0) return;
    hipLaunchKernelGGL(k_synth_generate, dim3((unsigned)P_g), dim3(256), 0, stream, packed, pitch, N, snp_begin, seed,
-                      n_pop, fst_fp, miss_thr, maf_model, missing_model, conc_fp);
+                      n_pop, fst_fp, miss_thr, maf_model, missing_model, conc_fp, med_q32, sig2_fp);
    HIP_CHECK_LAUNCH();
 }
 

@@ -77,10 +77,11 @@ void colmajor_to_t(const double *in, uint64_t ld, uint64_t P_g, uint64_t P_pad, 
 // synthetic genotype generator (synth.hpp model), one workgroup per SNP record
 //   maf_model 0: ancestral frequency uniform in [0.05, 0.95); 1: rare-variant spectrum 0.001 + 0.499 u^3
 //   missing_model 0: every call missing with probability miss_thr / 65536; 1: concentrated in a fraction conc_fp / 65536 of
-//   the SNPs (10-30 % of their calls), the others at most 0.1 %  (synth.hpp)
+//   the SNPs (10-30 % of their calls), the others at most 0.1 %; 2: per-SNP rates log-normal, median med_q32 (0.32 fixed point),
+//   log2-sd sig2_fp (16.16)  (synth.hpp)
 void synth_generate(uint8_t *packed, size_t pitch, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed,
                     int n_pop, uint32_t fst_fp, uint32_t miss_thr, hipStream_t stream, int maf_model = 0, int missing_model = 0,
-                    uint32_t conc_fp = 0);
+                    uint32_t conc_fp = 0, uint64_t med_q32 = 0, uint32_t sig2_fp = 0);
 
 // diagnostic: D(16x16) = A(16x4) B(4x16) through v_mfma_f64_16x16x4_f64 with this file's operand mapping
 void mfma_layout_probe(const double *A, const double *B, double *D, hipStream_t stream);

@@ -20,7 +20,7 @@ constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_D = 1920, I8W_ZERO = 256
               I8W_CSM = I8W_CSB + kern::I8_CS_STRIDE * kern::I8_SHARDS, I8W_TOTAL = I8W_CSM + kern::I8_CS_STRIDE * kern::I8_SHARDS;
 
 
-constexpr double SPARSE_BREAK_EVEN = 0.005; // missing-call rate at which the gathers cost what the E half of the GEMMs costs
+constexpr double SPARSE_BREAK_EVEN = 0.005; // missing-call rate at which the gathers cost what the E half of the GEMMs costs (= M2_CELL S / G_CALL at S = 7)
 static void hybrid_classify(fpca_ctx *c);
 static void ensure_i8_alloc(fpca_ctx *c, int b);
 
@@ -203,14 +203,30 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
 // 4 = hybrid: G.M on the matrix cores; the missing-indicator products as sparse gathers for most SNPs and as a small
 // integer GEMM over a compacted sub-matrix for the few SNPs that hold most of the missing calls (real arrays: failed assays)
 
-// Per-SNP choice of the route (from K1's per-SNP counts): a SNP above the break-even rate goes dense.  The shard qualifies
-// for the hybrid route when that leaves the rest at or below the break-even and the dense set is a minority of the SNPs.
+// What a shard's missing calls cost per block column, beyond the one-matrix GEMMs every route runs -- three linear models fitted to
+// the stage times at 500,000 x 100,000 (profiles/r03_sparse_breakeven.txt, r04_gather_ab.txt, r05_missing_routes.txt):
+//   gathers (sparse / hybrid lists)          G_CALL per listed missing call (both stages: a 128-byte row each)
+//   compacted indicator GEMMs (hybrid)       D_CELL x N x S per dense SNP (two one-matrix launches over the SNP's records)
+//   two-matrix kernels (dense route)         M2_CELL x N x S per SNP of the shard (the second matrix shares loads and decode)
+// Per SNP the hybrid route is free to choose: a SNP whose calls cost more to gather than its indicator row costs on the matrix
+// cores goes dense -- above D_CELL S / G_CALL = 0.69 % of the samples at S = 7.  The shard takes the hybrid route when the sum of
+// those per-SNP minima beats both alternatives; uniform rates have no minority to single out and land where they landed before
+// (gathers up to M2_CELL S / G_CALL = 0.51 %, the two-matrix kernels above).  Round 4 decided by two fixed rules instead (dense SNPs
+// at most a quarter, the rest at most 0.5 %): right for the concentrated profile, blind to everything between it and uniform.
+constexpr double G_CALL = 2.0e-12, D_CELL = 1.96e-15, M2_CELL = 1.45e-15;
+static double cost_sparse(const fpca_ctx *c, uint64_t calls) { return G_CALL * (double)calls; }
+static double cost_two_matrix(const fpca_ctx *c) { return M2_CELL * (double)c->N * c->i8_S_req * (double)c->P_g; }
+static double cost_hybrid(const fpca_ctx *c, uint64_t listed, uint64_t ndense)
+{
+   return G_CALL * (double)listed + D_CELL * (double)c->N * c->i8_S_req * (double)ndense;
+}
+
 void hybrid_classify(fpca_ctx *c)
 {
    if (c->hyb_class >= 0) return;
    c->hyb_class = 0;
-   if (!c->missing_known || c->h_nmiss.size() != c->P_g || c->P_g == 0) return;
-   const double thr = SPARSE_BREAK_EVEN * (double)c->N;
+   if (!c->missing_known || c->h_nmiss.size() != c->P_g || c->P_g == 0 || c->i8_S_req <= 0) return;
+   const double thr = D_CELL * c->i8_S_req / G_CALL * (double)c->N; // calls of one SNP above which its indicator row is cheaper dense
    uint64_t dense_nnz = 0;
    std::vector<uint32_t> idx;
    for (uint64_t j = 0; j < c->P_g; j++)
@@ -219,8 +235,11 @@ void hybrid_classify(fpca_ctx *c)
          dense_nnz += c->h_nmiss[j];
       }
    const uint64_t rest = c->n_missing - dense_nnz;
-   if (idx.empty() || idx.size() * 4 > c->P_g) return;
-   if ((double)rest > SPARSE_BREAK_EVEN * (double)c->N * (double)(c->P_g - idx.size()) || rest >= (1ull << 31)) return;
+   if (idx.empty() || rest >= (1ull << 31)) return;
+   const double ch = cost_hybrid(c, rest, idx.size());
+   // (against the gathers alone a clear margin is asked for: the route has a one-off set-up -- two row shuffles of the dense SNPs and
+   //  a second, small transposition -- and keeps a compacted copy of their records)
+   if (!(ch < cost_two_matrix(c)) || !(ch < 0.85 * cost_sparse(c, c->n_missing))) return;
    c->hyb_n = (uint32_t)idx.size();
    c->hyb_pad = (uint32_t)round_up(c->hyb_n, SNP_ALIGN);
    c->hyb_sparse_nnz = rest;
@@ -241,7 +260,7 @@ int i8_mode(fpca_ctx *c, int b) // (classifies the SNPs the first time a rate ab
    if (!c->missing_known) return I8M_FULL;
    if (c->n_missing == 0) return I8M_NONE;
    const double rate = (double)c->n_missing / ((double)c->N * (double)std::max<uint64_t>(c->P_g, 1));
-   if (lists_ok && rate > SPARSE_BREAK_EVEN && !c->hyb_failed) {
+   if (lists_ok && !c->hyb_failed) {
       hybrid_classify(c);
       if (c->hyb_class == 1) return I8M_HYBRID;
    }

@@ -92,6 +92,31 @@ FPCA_HD uint32_t snp_miss_thr_concentrated(uint64_t seed, uint64_t snp, uint32_t
    return (lvl * 66u) >> 16;                                  // 0 .. 0.1 %
 }
 
+// missing_model 2 (round 5): per-SNP missing-call rates from a LOG-NORMAL distribution -- where most real arrays sit, between "every
+// SNP the same rate" (model 0) and "5 % of the SNPs hold nearly all of it" (model 1): rate_j = median * 2^(sig2 z_j), z_j the
+// Irwin-Hall normal of pop_freq, capped at 0.9.  med_q32 = median rate in 0.32 fixed point, sig2_fp = sigma / ln 2 in 16.16;
+// 2^f for the fractional part by a cubic whose coefficients sum to one (2^0 = 1 and 2^1 = 2 exactly, 2e-4 relative in between).
+FPCA_HD uint32_t snp_miss_thr_lognormal(uint64_t seed, uint64_t snp, uint64_t med_q32, uint32_t sig2_fp)
+{
+   int64_t zsum = 0;
+   for (int r = 0; r < 3; r++) {
+      const uint64_t h = rnd64(seed, 5, snp, (uint64_t)r);
+      zsum += (int64_t)(h & 0xFFFF) + (int64_t)((h >> 16) & 0xFFFF) + (int64_t)((h >> 32) & 0xFFFF) + (int64_t)(h >> 48);
+   }
+   const int64_t z = zsum - 6 * 65535;               // mean 0, std 1.0 in 16.16
+   const int64_t x = ((int64_t)sig2_fp * z) >> 16;   // exponent of 2 in 16.16 (arithmetic shift: floor)
+   const int64_t e = x >> 16;
+   const uint64_t f = (uint64_t)(x & 0xFFFF);
+   const uint64_t m = 65536u + ((f * (45426u + ((f * (15743u + ((f * 4367u) >> 16))) >> 16))) >> 16); // 2^f in 16.16
+   uint64_t rate = (med_q32 * m) >> 16;              // 0.32
+   if (e >= 0)
+      rate = e >= 20 ? ~0ull : rate << e;
+   else
+      rate = e <= -40 ? 0 : rate >> (-e);
+   const uint64_t thr = rate >> 16;                  // 16-bit uniform < thr
+   return (uint32_t)(thr > 58982u ? 58982u : thr);   // at most 90 %
+}
+
 // frequency of SNP j in population c (16.16 fixed point threshold for 16-bit uniforms)
 FPCA_HD uint32_t pop_freq(uint64_t seed, uint64_t snp, uint32_t pj, uint32_t fst_fp /*16.16*/, int c)
 {

@@ -109,13 +109,16 @@ int fpca_create_synthetic(fpca_ctx **out, uint64_t N, uint64_t snp_begin, uint64
 /* The same generator with the knobs that make the matrix look like array / sequencing data instead of the survey's uniform model
  * (flashpca_amd/csrc/synth.hpp): maf_model 1 = rare-variant spectrum (minor-allele frequency 0.001 + 0.499 u^3: per-SNP sd over a
  * 16x range, SNPs monomorphic in small samples); missing_model 1 = missing calls concentrated in `conc_frac` of the SNPs (10-30 %
- * of their calls; every other SNP <= 0.1 %; missing_rate is ignored).  maf_model = missing_model = 0 is fpca_create_synthetic. */
+ * of their calls; every other SNP <= 0.1 %; missing_rate is ignored); missing_model 2 = per-SNP rates log-normally distributed
+ * with MEAN missing_rate and log-sd lognormal_sigma (capped at 90 %): most SNPs below the mean, a long tail of poor assays.
+ * maf_model = missing_model = 0 is fpca_create_synthetic. */
 typedef struct fpca_synth_model {
    int n_pop;            /* sub-populations (1..64): n_pop - 1 structured eigenvalues */
    double fst;
-   double missing_rate;  /* missing_model 0 */
+   double missing_rate;  /* missing_model 0: every call; 2: the mean over SNPs */
    int maf_model, missing_model;
    double conc_frac;     /* missing_model 1: fraction of SNPs with 10-30 % missing calls (e.g. 0.05) */
+   double lognormal_sigma; /* missing_model 2: sd of ln(rate) over SNPs (e.g. 1.5) */
 } fpca_synth_model;
 int fpca_create_synthetic_model(fpca_ctx **out, uint64_t N, uint64_t snp_begin, uint64_t P_g, uint64_t seed, const fpca_synth_model *model,
                                 int stand_method, int device, int accum);

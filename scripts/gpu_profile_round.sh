@@ -1,7 +1,7 @@
 # Regenerates the committed profile evidence of a round:  bash scripts/gpu_profile_round.sh r02
 # (run through gpurun; writes under gpurun_out/<round>/, scripts/copy_profiles.sh copies the summaries into profiles/)
-R=${1:-r04}
-mkdir -p gpurun_out/$R; export TMPDIR=/tmp
+R=${1:-r05}
+mkdir -p gpurun_out/$R; export TMPDIR=/tmp; export PYTHONPATH=$PWD
 PMC_SQ="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 Q="--no-cpu-baseline --no-pca-hard --no-e2e"
 # the default line = the driver's command (500k x 100k headline, exact-integer mode; carries the fp64 kernels' numbers as
@@ -40,10 +40,10 @@ python scripts/mfma_peak.py > gpurun_out/$R/mfma_f64_microbench.txt 2>&1
 python bench.py --workload cfg5 $Q --no-e2e > gpurun_out/$R/bench_cfg5_n1.json 2>/dev/null
 python bench.py --blockvec 32 $Q --no-e2e --no-alt > gpurun_out/$R/bench_cfg3_n1_b32.json 2>/dev/null
 python scripts/ortho_slice_cost.py > gpurun_out/$R/ortho_slice_cost.txt 2>&1
-python scripts/mfma_mix_probe.py > gpurun_out/$R/mfma_mix_probe.txt 2>&1
-python scripts/hard_spectrum_once.py > gpurun_out/$R/hard_spectrum.txt 2>&1
-python scripts/r4_mixed_probe.py > gpurun_out/$R/mixed_probe.txt 2>&1
-bash scripts/r4_narrow_probe.sh > /dev/null 2>&1; cp gpurun_out/r4_narrow_probe.txt gpurun_out/$R/narrow_probe.txt
+python scripts/solve_profiles.py 1 2 > gpurun_out/$R/solve_profiles.txt 2>&1
+python scripts/k4_bench.py > gpurun_out/$R/k4_bench.txt 2>&1
+python scripts/fp_apply_bench.py > gpurun_out/$R/fp_apply_bench.txt 2>&1
+python scripts/missing_routes_probe.py > gpurun_out/$R/missing_routes.txt 2>&1
 FPCA_TIMING=1 bash scripts/gpu_cli_e2e.sh 500000 100000 3 > gpurun_out/$R/cli_e2e_cfg3.txt 2>&1
 bash scripts/power_sample.sh i8 > gpurun_out/$R/power_sample.txt 2>&1
 for t in trace_cfg3_i8 trace_cfg3_fp64 trace_cfg4shard_i8; do python scripts/summarise_trace.py gpurun_out/$R/$t > gpurun_out/$R/${t}_by_grid.csv; done
