@@ -22,33 +22,57 @@ namespace {
 // With rows != nullptr Q is not formed: rows (nrows x n, ld nrows) receives rows row0..row0+nrows-1 of Q instead.
 // With beta_out != nullptr Q is not formed: the reflectors stay below the sub-diagonal of A and their coefficients are
 // returned, for the caller to apply (symeig_desc_cols); rows are still produced when asked for.
-// fixed-order vectorised dot product (4 lanes x 4 accumulators): the result does not depend on who computes it
 typedef double v4d __attribute__((vector_size(32)));
-inline double dot_fixed(const double *a, const double *b, int m)
+// One column of the symmetric matrix-vector product and of the rank-2 update on LOWER-triangle storage, fixed evaluation order
+// (4 lanes x 2 accumulators) so that every rank of a multi-GPU run gets the same bits:
+//   sym_col_mv:  returns col[1:].v[1:]  and adds col[1:] * vj to p[1:]      (column j of A22 from its diagonal down, length len)
+//   sym_col_r2:  col[i] -= v[i] qj + q[i] vj                                 (the same column after the step's q is known)
+inline double sym_col_mv(const double *col, const double *v, double *p, double vj, int len)
 {
-   v4d s0 = {0.0, 0.0, 0.0, 0.0}, s1 = s0, s2 = s0, s3 = s0;
-   int i = 0;
-   for (; i + 16 <= m; i += 16) {
-      v4d a0, a1, a2, a3, b0, b1, b2, b3; // (memcpy = unaligned vector loads)
-      std::memcpy(&a0, a + i, 32);
-      std::memcpy(&a1, a + i + 4, 32);
-      std::memcpy(&a2, a + i + 8, 32);
-      std::memcpy(&a3, a + i + 12, 32);
-      std::memcpy(&b0, b + i, 32);
-      std::memcpy(&b1, b + i + 4, 32);
-      std::memcpy(&b2, b + i + 8, 32);
-      std::memcpy(&b3, b + i + 12, 32);
-      s0 += a0 * b0;
-      s1 += a1 * b1;
-      s2 += a2 * b2;
-      s3 += a3 * b3;
+   v4d s0 = {0.0, 0.0, 0.0, 0.0}, s1 = s0;
+   const v4d vjv = {vj, vj, vj, vj};
+   int i = 1;
+   for (; i + 8 <= len; i += 8) {
+      v4d c0, c1, v0, v1, p0, p1;
+      std::memcpy(&c0, col + i, 32);
+      std::memcpy(&c1, col + i + 4, 32);
+      std::memcpy(&v0, v + i, 32);
+      std::memcpy(&v1, v + i + 4, 32);
+      std::memcpy(&p0, p + i, 32);
+      std::memcpy(&p1, p + i + 4, 32);
+      s0 += c0 * v0;
+      s1 += c1 * v1;
+      p0 += c0 * vjv;
+      p1 += c1 * vjv;
+      std::memcpy(p + i, &p0, 32);
+      std::memcpy(p + i + 4, &p1, 32);
    }
-   const v4d t = (s0 + s1) + (s2 + s3);
+   const v4d t = s0 + s1;
    double s = (t[0] + t[1]) + (t[2] + t[3]);
-   for (; i < m; i++) s += a[i] * b[i];
+   for (; i < len; i++) {
+      s += col[i] * v[i];
+      p[i] += col[i] * vj;
+   }
    return s;
 }
+inline void sym_col_r2(double *col, const double *v, const double *q, double vj, double qj, int len)
+{
+   const v4d vjv = {vj, vj, vj, vj}, qjv = {qj, qj, qj, qj};
+   int i = 0;
+   for (; i + 4 <= len; i += 4) {
+      v4d c, vv, qq;
+      std::memcpy(&c, col + i, 32);
+      std::memcpy(&vv, v + i, 32);
+      std::memcpy(&qq, q + i, 32);
+      c -= vv * qjv + qq * vjv;
+      std::memcpy(col + i, &c, 32);
+   }
+   for (; i < len; i++) col[i] -= v[i] * qj + q[i] * vj;
+}
 
+// Only the LOWER triangle of A is read and updated (round 5: rounds 1-4 kept both triangles current -- twice the flops and twice
+// the traffic of a reduction that is bound by the L2 bandwidth of the one core it runs on: 11.2 -> 6 ms at n = 384).  On return the
+// strict upper triangle of the trailing blocks is stale; nothing downstream reads it (the reflectors sit below the sub-diagonal).
 void tridiagonalise(int n, double *A, int lda, double *d, double *e, int row0 = 0, int nrows = 0, double *rows = nullptr,
                     double *beta_out = nullptr)
 {
@@ -76,18 +100,22 @@ void tridiagonalise(int n, double *A, int lda, double *d, double *e, int row0 = 
       for (int i = 1; i < m; i++) v[i] = x[i] / v0;
       const double bk = -v0 / alpha; // 2 / (v'v) with v[0] = 1
       beta[k] = bk;
-      // p = bk * A22 v; A22 is symmetric, so p[i] is the dot product of COLUMN i with v (contiguous, vectorised)
-      for (int i = 0; i < m; i++) p[i] = bk * dot_fixed(&AA(k + 1, k + 1 + i), v.data(), m);
+      // p = A22 v from the lower triangle: column j (from its diagonal down) gives p[j] += a_jj v_j + col[1:].v[j+1:] and
+      // p[j+1:] += col[1:] v_j -- every stored element is read once
+      for (int i = 0; i < m; i++) p[i] = 0.0;
+      for (int j = 0; j < m; j++) {
+         const double *col = &AA(k + 1 + j, k + 1 + j);
+         p[j] += col[0] * v[j] + sym_col_mv(col, v.data() + j, p.data() + j, v[j], m - j);
+      }
       double vp = 0;
-      for (int i = 0; i < m; i++) vp += v[i] * p[i];
+      for (int i = 0; i < m; i++) {
+         p[i] *= bk;
+         vp += v[i] * p[i];
+      }
       const double kk = 0.5 * bk * vp;
       for (int i = 0; i < m; i++) p[i] -= kk * v[i]; // q
-      // A22 -= v q' + q v'
-      for (int j = 0; j < m; j++) {
-         double *col = &AA(k + 1, k + 1 + j);
-         const double vj = v[j], qj = p[j];
-         for (int i = 0; i < m; i++) col[i] -= v[i] * qj + p[i] * vj;
-      }
+      // A22 -= v q' + q v'  (lower triangle)
+      for (int j = 0; j < m; j++) sym_col_r2(&AA(k + 1 + j, k + 1 + j), v.data() + j, p.data() + j, v[j], p[j], m - j);
       d[k] = AA(k, k);
       e[k] = alpha;
       for (int i = 1; i < m; i++) x[i] = v[i]; // keep the reflector (x[0] slot is not needed)
@@ -254,18 +282,25 @@ int symeig_desc_rows(int n, double *A, int lda, double *w, int row0, int nrows, 
       return 0;
    }
    std::vector<double> d(n), e(n, 0.0), rows((size_t)nrows * n);
+   // The reduction runs on a copy whose column stride is an ODD number of cache lines: the projected matrices of the solver have
+   // orders that are multiples of 16, and at a stride of 2,048 bytes (n = 256) every column falls into the same L1 sets -- the
+   // reduction took 8.5 ms there against 5 at n = 320.
+   int ldw = (n + 7) / 8 * 8;
+   if ((ldw / 8) % 2 == 0) ldw += 8;
+   std::vector<double> Wk((size_t)ldw * n);
+   for (int j = 0; j < n; j++) std::memcpy(&Wk[(size_t)j * ldw], A + (size_t)j * lda, sizeof(double) * n);
    if (keep && n > 2) { // the reduction is kept for symeig_cols_from_keep: original matrix, reflectors, tridiagonal form
       keep->A0.resize((size_t)n * n);
       for (int j = 0; j < n; j++) std::memcpy(&keep->A0[(size_t)j * n], A + (size_t)j * lda, sizeof(double) * n);
       keep->beta.assign(n, 0.0);
-      tridiagonalise(n, A, lda, d.data(), e.data(), row0, nrows, rows.data(), keep->beta.data());
+      tridiagonalise(n, Wk.data(), ldw, d.data(), e.data(), row0, nrows, rows.data(), keep->beta.data());
       keep->A.resize((size_t)n * n);
-      for (int j = 0; j < n; j++) std::memcpy(&keep->A[(size_t)j * n], A + (size_t)j * lda, sizeof(double) * n);
+      for (int j = 0; j < n; j++) std::memcpy(&keep->A[(size_t)j * n], &Wk[(size_t)j * ldw], sizeof(double) * n);
       keep->d = d;
       keep->e = e;
       keep->n = n;
    } else
-      tridiagonalise(n, A, lda, d.data(), e.data(), row0, nrows, rows.data());
+      tridiagonalise(n, Wk.data(), ldw, d.data(), e.data(), row0, nrows, rows.data());
    int rc = tridiag_ql(n, d.data(), e.data(), rows.data(), nrows, nrows);
    if (rc) return rc;
    std::vector<int> idx(n);

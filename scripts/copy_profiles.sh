@@ -8,5 +8,5 @@ for t in trace_cfg3_i8 trace_cfg3_fp64 trace_cfg4shard_i8; do [ -s $S/${t}_by_gr
 cp $S/pmc_summary.json $D/${R}_pmc_summary.json; cp $S/pmc_summary_i8.json $D/${R}_pmc_summary_i8.json
 cp $S/mfma_i8_microbench.txt $D/${R}_mfma_i8_microbench.txt; cp $S/mfma_f64_microbench.txt $D/${R}_mfma_f64_microbench.txt
 [ -s $S/power_sample.txt ] && cp $S/power_sample.txt $D/${R}_power_sample.txt
-for f in ortho_slice_cost.txt cli_e2e_cfg3.txt solve_profiles.txt k4_bench.txt fp_apply_bench.txt missing_routes.txt; do [ -s $S/$f ] && cp $S/$f $D/${R}_$f; done
+for f in ortho_slice_cost.txt partial_download.txt cli_e2e_cfg3.txt solve_profiles.txt k4_bench.txt fp_apply_bench.txt missing_routes.txt; do [ -s $S/$f ] && cp $S/$f $D/${R}_$f; done
 ls -la $D | tail -40

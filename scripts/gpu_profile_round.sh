@@ -40,6 +40,7 @@ python scripts/mfma_peak.py > gpurun_out/$R/mfma_f64_microbench.txt 2>&1
 python bench.py --workload cfg5 $Q --no-e2e > gpurun_out/$R/bench_cfg5_n1.json 2>/dev/null
 python bench.py --blockvec 32 $Q --no-e2e --no-alt > gpurun_out/$R/bench_cfg3_n1_b32.json 2>/dev/null
 python scripts/ortho_slice_cost.py > gpurun_out/$R/ortho_slice_cost.txt 2>&1
+python scripts/partial_download_probe.py > gpurun_out/$R/partial_download.txt 2>&1
 python scripts/solve_profiles.py 1 2 > gpurun_out/$R/solve_profiles.txt 2>&1
 python scripts/k4_bench.py > gpurun_out/$R/k4_bench.txt 2>&1
 python scripts/fp_apply_bench.py > gpurun_out/$R/fp_apply_bench.txt 2>&1

@@ -56,6 +56,17 @@ def test_struct_layouts_match_the_header(built_lib):
     o.struct_size -= 8
     rc = flashpca_amd.lib().fpca_pca(None, C.byref(o), None, None, None, None, None, None, None)
     assert rc == -1
+    # ... and what such a caller does first -- FPCA_PCA_OPTS_INIT(&o), i.e. fpca_pca_init_opts with ITS sizeof -- writes its sizes
+    # into the struct and never a byte past them (default_opts used to memset the library's sizeof into the caller's
+    # smaller struct)
+    small = C.sizeof(_lib.PcaOpts) - 8
+    buf = (C.c_ubyte * (C.sizeof(_lib.PcaOpts) + 16))(*([0xAA] * (C.sizeof(_lib.PcaOpts) + 16)))
+    flashpca_amd.lib().fpca_pca_init_opts(C.cast(buf, C.POINTER(_lib.PcaOpts)), small, 96)
+    o2 = _lib.PcaOpts.from_buffer_copy(bytes(buf)[:C.sizeof(_lib.PcaOpts)])
+    assert (o2.struct_size, o2.info_size, o2.ndim, o2.maxiter) == (small, 96, 10, 500)
+    assert all(b == 0xAA for b in bytes(buf)[small:])
+    rc = flashpca_amd.lib().fpca_pca(None, C.cast(buf, C.POINTER(_lib.PcaOpts)), None, None, None, None, None, None, None)
+    assert rc == -1 and b"another include/fpca.h" in flashpca_amd.lib().fpca_last_error()
 
 
 def test_library_exports_every_declared_symbol(built_lib):
