@@ -215,11 +215,12 @@ void lut_from_meansd(const double *mean, const double *sd, uint64_t P_g, double 
 // The two GEMM kernels exist in two arithmetic flavours, selected by the context's `accum` setting:
 //   RT = double : v_mfma_f64_16x16x4_f64, everything in fp64 (default; FPCA_ACCUM_FP64)
 //   RT = float  : v_mfma_f32_16x16x4_f32 (twice the MFMA rate): the table of standardised values and the B / T tile
-//                 are rounded to fp32 in LDS, products and the accumulation WITHIN one LDS chunk (128 samples / 64 SNPs)
+//                 are rounded to fp32 in LDS, products and the accumulation within FOLD_EVERY = 4 LDS chunks (512 samples / 256 SNPs)
 //                 run in fp32, and every chunk's partial sums are added into fp64 accumulators, so the rounding error
 //                 does not grow with N or P (BASELINE config 5, "fp32 accumulate (tolerance study)"; FPCA_ACCUM_FP32)
 // Both MFMAs take A[i = lane&15][k = lane>>4] and B[k = lane>>4][j = lane&15], one value per lane; they differ in the
 // C/D map: fp64 register r holds row (lane>>4) + 4r, fp32 register r holds row 4 (lane>>4) + r.
+constexpr int FOLD_EVERY = 4; // mixed mode: LDS chunks between two folds of the fp32 partial sums into fp64 (power of two)
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -233,6 +234,17 @@ template <> struct Mma<float> {
    typedef f4 acc_t;
    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
    static __device__ __forceinline__ int row(int kq, int r) { return 4 * kq + r; }
+};
+
+// two table values fetched by one LDS read (pair decode of two consecutive samples)
+template <typename RT> struct Pair;
+template <> struct Pair<double> {
+   typedef d2 type;
+   static __device__ __forceinline__ d2 make(double a, double b) { return (d2){a, b}; }
+};
+template <> struct Pair<float> {
+   typedef f2 type;
+   static __device__ __forceinline__ f2 make(double a, double b) { return (f2){(float)a, (float)b}; }
 };
 
 // store a 16-byte piece of fp64 data (2 doubles) at logical element index 2*idx of an RT-typed LDS array
@@ -286,14 +298,28 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
    // The workgroup's table in LDS is laid out [16-SNP group][code][SNP in group]: the 16 lanes of an MFMA row group -- 16 different
    // SNPs, whatever their codes -- then read 16 consecutive words = every bank once.  (Rounds 1-4 kept the HBM layout [SNP][code]:
    // lanes li and li + 4 shared their banks whenever their codes agreed, 31-38 % of the LDS cycles of this kernel were conflicts.)
+   // 16 columns (PAIR): the table holds PAIRS of values indexed by the 4 bits of two consecutive samples' codes, so that one LDS
+   // read decodes two k-steps of an m-tile (see K3); [16-SNP group][pair index][SNP in group], conflict-free the same way.  Wider
+   // blocks keep the per-sample table: there every gather already feeds NT MFMAs, and 16 x the table would not leave room for
+   // three workgroups per CU.
+   typedef typename Pair<RT>::type pair_t;
+   constexpr bool PAIR = NT == 1;
+   pair_t *sLutP = reinterpret_cast<pair_t *>(sLut);
    if (tid < TILE) { // one SNP's 4-entry table per thread; visible after the first barrier of the chunk loop
       const d2 *lsrc = reinterpret_cast<const d2 *>(lut + ((uint64_t)blockIdx.x * TILE + tid) * 4);
       const d2 e01 = lsrc[0], e23 = lsrc[1];
-      RT *dst = sLut + (tid >> 4) * 64 + (tid & 15);
-      dst[0] = (RT)e01.x;
-      dst[16] = (RT)e01.y;
-      dst[32] = (RT)e23.x;
-      dst[48] = (RT)e23.y;
+      if (PAIR) {
+         const double l4[4] = {e01.x, e01.y, e23.x, e23.y};
+         pair_t *dst = sLutP + (tid >> 4) * 256 + (tid & 15);
+#pragma unroll
+         for (int idx = 0; idx < 16; idx++) dst[idx * 16] = Pair<RT>::make(l4[idx & 3], l4[idx >> 2]);
+      } else {
+         RT *dst = sLut + (tid >> 4) * 64 + (tid & 15);
+         dst[0] = (RT)e01.x;
+         dst[16] = (RT)e01.y;
+         dst[32] = (RT)e23.x;
+         dst[48] = (RT)e23.y;
+      }
    }
    const uint8_t *rowp[MT];
 #pragma unroll
@@ -325,7 +351,8 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
    if (c_begin < c_end) FPCA_XTB_ISSUE(c_begin);
 
    const RT *sB_lane = sB + (size_t)((KC / 4) * kq) * b + li;
-   const RT *sLut_lane = sLut + (size_t)(wave * MT) * 64 + li; // m-tile m, code c: sLut_lane[m * 64 + c * 16]
+   const RT *sLut_lane = sLut + (size_t)(wave * MT) * 64 + li;        // m-tile m, code c: sLut_lane[m * 64 + c * 16]
+   const pair_t *sLutP_lane = sLutP + (size_t)(wave * MT) * 256 + li; // PAIR: m-tile m, pair index i: sLutP_lane[m * 256 + i * 16]
 
    for (int c = c_begin; c < c_end; c++) {
       __syncthreads(); // every wave has finished reading the previous B tile
@@ -338,26 +365,58 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
          for (int h = 0; h < NW; h++) pk[m][h] = pk_next[m][h];
       __syncthreads();
       if (c + 1 < c_end) FPCA_XTB_ISSUE(c + 1);
-      // k-step t + 1's operands (B fragment, MT table gathers) are read while step t's MFMAs run (see K3)
-      RT av[2][MT], bv[2][NT];
+      // k-step t + 1's operands (B fragment, MT table gathers) are read while step t's MFMAs run (see K3); PAIR: two k-steps at a time
+      if constexpr (PAIR) {
+         RT av[2][2][MT], bv[2][2][NT];
+#define FPCA_XTB_FETCH2(tp_, slot_)                                                                                             \
+   {                                                                                                                            \
+      _Pragma("unroll") for (int w_ = 0; w_ < 2; w_++)                                                                          \
+         _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bv[slot_][w_][nt] = sB_lane[(size_t)(2 * (tp_) + w_) * b + nt * 16]; \
+      _Pragma("unroll") for (int m = 0; m < MT; m++)                                                                            \
+      {                                                                                                                         \
+         const pair_t pr_ = sLutP_lane[m * 256 + (((pk[m][(2 * (tp_)) / 16] >> (2 * ((2 * (tp_)) % 16))) & 15u) << 4)];         \
+         av[slot_][0][m] = pr_.x;                                                                                               \
+         av[slot_][1][m] = pr_.y;                                                                                               \
+      }                                                                                                                         \
+   }
+         FPCA_XTB_FETCH2(0, 0);
+#pragma unroll
+         for (int tp = 0; tp < 8 * NW; tp++) {
+            if (tp + 1 < 8 * NW) FPCA_XTB_FETCH2(tp + 1, (tp + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int w = 0; w < 2; w++)
+#pragma unroll
+               for (int m = 0; m < MT; m++)
+#pragma unroll
+                  for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(av[tp & 1][w][m], bv[tp & 1][w][nt], acc[m][nt]);
+            __builtin_amdgcn_sched_barrier(0);
+         }
+#undef FPCA_XTB_FETCH2
+      } else {
+         RT av[2][MT], bv[2][NT];
 #define FPCA_XTB_FETCH(tt_, slot_)                                                                                              \
    {                                                                                                                            \
       _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bv[slot_][nt] = sB_lane[(size_t)(tt_) * b + nt * 16];                   \
       _Pragma("unroll") for (int m = 0; m < MT; m++) av[slot_][m] = sLut_lane[m * 64 + (((pk[m][(tt_) / 16] >> (2 * ((tt_) % 16))) & 3u) << 4)]; \
    }
-      FPCA_XTB_FETCH(0, 0);
+         FPCA_XTB_FETCH(0, 0);
 #pragma unroll
-      for (int tt = 0; tt < 16 * NW; tt++) {
-         if (tt + 1 < 16 * NW) FPCA_XTB_FETCH(tt + 1, (tt + 1) & 1);
-         __builtin_amdgcn_sched_barrier(0);
+         for (int tt = 0; tt < 16 * NW; tt++) {
+            if (tt + 1 < 16 * NW) FPCA_XTB_FETCH(tt + 1, (tt + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-         for (int m = 0; m < MT; m++)
+            for (int m = 0; m < MT; m++)
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(av[tt & 1][m], bv[tt & 1][nt], acc[m][nt]);
-         __builtin_amdgcn_sched_barrier(0);
-      }
+               for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(av[tt & 1][m], bv[tt & 1][nt], acc[m][nt]);
+            __builtin_amdgcn_sched_barrier(0);
+         }
 #undef FPCA_XTB_FETCH
-      if (MIXED) { // fold this chunk's fp32 partial sums into the fp64 accumulators
+      }
+      // fold the fp32 partial sums into the fp64 accumulators every FOLD_EVERY chunks (and at the end): fp32 sums then run over at most
+      // 512 samples whatever N is -- the rounding error does not grow with N -- while the fold (4 converts + 4 fp64 adds per
+      // accumulator register, 5 % of the kernel when made every chunk; round 5) stays off the MFMA-bound path
+      if (MIXED && ((c & (FOLD_EVERY - 1)) == FOLD_EVERY - 1 || c + 1 == c_end)) {
 #pragma unroll
          for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -439,7 +498,7 @@ static void launch_xt_b(const uint8_t *packed, size_t pitch, const double *lut, 
    const int chunks_total = (int)(N_pad / KC);
    const int cps = (chunks_total + nsplit - 1) / nsplit;
    constexpr int MT = XtMt<RT, NT>::MT;
-   const size_t smem = ((size_t)KC * 16 * NT + 64 * MT * 4) * sizeof(RT);
+   const size_t smem = ((size_t)KC * 16 * NT + 64 * MT * (NT == 1 ? 32 : 4)) * sizeof(RT); // B tile + table (16 columns: [SNP][16] pairs)
    static bool attr_set = false;
    if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xt_b<RT, NT, MT, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -497,7 +556,11 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
    unsigned char *sP = smem_raw;                                        // [KCX][ROWB]
    RT *sT = reinterpret_cast<RT *>(smem_raw + KCX * ROWB);             // [KCX][b]
-   RT *sL = sT + KCX * b;                                              // [KCX][4]
+   // [KCX][16] PAIRS of table values, indexed by the 4 bits of two consecutive samples' codes (c0 | c1 << 2): one 16-byte (fp64) or
+   // 8-byte (fp32) LDS read decodes two samples -- half the gather instructions and address arithmetic of a per-sample lookup, and
+   // ds_read_b128 reaches its rate from one wave per SIMD where ds_read_b64 needs four (MI355X_MICROARCH.md, LDS)
+   typedef typename Pair<RT>::type pair_t;
+   pair_t *sL = reinterpret_cast<pair_t *>(sT + KCX * b);
 
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int li = lane & 15, kq = lane >> 4;
@@ -518,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
 
    u4 preg[NP];
    d2 treg[NTL];
-   d2 lreg;
+   d2 lreg[2]; // this thread's SNP (tid / 4) of the chunk: its four table values
 #define FPCA_XT_ISSUE(cc)                                                                                     \
    {                                                                                                           \
       const uint64_t snp_c0 = (uint64_t)(cc) * KCX;                                                           \
@@ -531,14 +594,18 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
       }                                                                                                        \
       const d2 *tsrc = reinterpret_cast<const d2 *>(T + snp_c0 * b);                                           \
       _Pragma("unroll") for (int r = 0; r < NTL; r++) treg[r] = tsrc[tid + 256 * r];                           \
-      if (tid < KCX * 2) lreg = reinterpret_cast<const d2 *>(lut + snp_c0 * 4)[tid];                          \
+      if (tid < KCX * 4) {                                                                                     \
+         const d2 *lsrc_ = reinterpret_cast<const d2 *>(lut + (snp_c0 + (tid >> 2)) * 4);                       \
+         lreg[0] = lsrc_[0];                                                                                   \
+         lreg[1] = lsrc_[1];                                                                                   \
+      }                                                                                                        \
    }
 
    if (c_begin < c_end) FPCA_XT_ISSUE(c_begin);
 
    const unsigned char *sP_lane = sP + (size_t)kq * ROWB + wave * (4 * MT) + li * (MT / 4);
    const RT *sT_lane = sT + (size_t)kq * b + li;
-   const RT *sL_lane = sL + (size_t)kq * 4;
+   const pair_t *sL_lane = sL + (size_t)kq * 16;
 
    for (int c = c_begin; c < c_end; c++) {
       __syncthreads();
@@ -548,7 +615,12 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
             if (tid + 256 * r < NPIECES) reinterpret_cast<u4 *>(sP)[tid + 256 * r] = preg[r];
 #pragma unroll
          for (int r = 0; r < NTL; r++) lds_put2(sT, tid + 256 * r, treg[r]);
-         if (tid < KCX * 2) lds_put2(sL, tid, lreg);
+         if (tid < KCX * 4) { // thread (SNP tid / 4, c1 = tid % 4) writes the four pairs (c0, c1), c0 = 0..3
+            const double l4[4] = {lreg[0].x, lreg[0].y, lreg[1].x, lreg[1].y};
+            const int c1 = tid & 3;
+#pragma unroll
+            for (int c0 = 0; c0 < 4; c0++) sL[(tid >> 2) * 16 + c1 * 4 + c0] = Pair<RT>::make(l4[c0], l4[c1]);
+         }
       }
       __syncthreads();
       if (c + 1 < c_end) FPCA_XT_ISSUE(c + 1);
@@ -569,9 +641,14 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
 #define FPCA_XT_FETCH(t_, slot_)                                                                                    \
    {                                                                                                                \
       const uint32_t h_ = hh[t_];                                                                                   \
-      const RT *lrow_ = sL_lane + (size_t)(4 * (t_)) * 4;                                                           \
+      const pair_t *lrow_ = sL_lane + (size_t)(4 * (t_)) * 16;                                                      \
       _Pragma("unroll") for (int nt = 0; nt < NT; nt++) tv[slot_][nt] = sT_lane[(size_t)(4 * (t_)) * b + nt * 16];  \
-      _Pragma("unroll") for (int m = 0; m < MT; m++) av[slot_][m] = lrow_[(h_ >> (2 * m)) & 3u];                    \
+      _Pragma("unroll") for (int m = 0; m < MT; m += 2)                                                             \
+      {                                                                                                             \
+         const pair_t pr_ = lrow_[(h_ >> (2 * m)) & 15u];                                                           \
+         av[slot_][m] = pr_.x;                                                                                      \
+         av[slot_][m + 1] = pr_.y;                                                                                  \
+      }                                                                                                             \
    }
       FPCA_XT_FETCH(0, 0);
 #pragma unroll
@@ -585,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
          __builtin_amdgcn_sched_barrier(0);
       }
 #undef FPCA_XT_FETCH
-      if (MIXED) {
+      if (MIXED && ((c & (FOLD_EVERY - 1)) == FOLD_EVERY - 1 || c + 1 == c_end)) { // (as in K2: fp32 sums over at most 256 SNPs)
 #pragma unroll
          for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -635,7 +712,7 @@ static void launch_x_t(const uint8_t *packed, size_t pitch, const double *lut, c
    constexpr int MT = XCfg<RT, NT>::MT, KCX = XCfg<RT, NT>::KCX;
    const int chunks_total = (int)(P_pad / KCX);
    const int cps = (chunks_total + nsplit - 1) / nsplit;
-   const size_t smem = (size_t)KCX * 16 * MT + ((size_t)KCX * 16 * NT + KCX * 4) * sizeof(RT);
+   const size_t smem = (size_t)KCX * 16 * MT + ((size_t)KCX * 16 * NT + KCX * 32) * sizeof(RT); // packed tile, T tile, [KCX][16] table pairs
    static bool attr_set = false;
    if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_x_t<RT, MT, NT, KCX>),

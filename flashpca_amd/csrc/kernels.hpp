@@ -22,7 +22,7 @@ void bed_stats(const uint8_t *packed, size_t pitch, uint64_t N, uint64_t P_g, in
 void lut_from_meansd(const double *mean, const double *sd, uint64_t P_g, double *lut, hipStream_t stream);
 
 // K2: Tpart[split][P_pad][b] = X^T B over the split's sample chunks.   b = 16*NT, NT in 1..4
-//   B: [N_pad][b] row-major.  nsplit==1 writes the final T directly.  fp32: v_mfma_f32 products / per-chunk fp32
+//   B: [N_pad][b] row-major.  nsplit==1 writes the final T directly.  fp32: v_mfma_f32 products / fp32 sums over at most 512 samples (4 chunks),
 //   accumulation folded into fp64 accumulators (FPCA_ACCUM_FP32), else everything fp64.
 void xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *B, double *Tpart, uint64_t N_pad,
           uint64_t P_pad, int b, int nsplit, bool fp32, hipStream_t stream);

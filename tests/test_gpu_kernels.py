@@ -178,7 +178,7 @@ def test_linearity_at_scale(fp):
 
 @pytest.mark.parametrize("name,b", [("data_chr1", 16), ("hapmap3_data", 32), ("hapmap3_data", 48), ("hapmap3_data", 64)])
 def test_fp32_mode_operator_tolerance(golden_dir, name, b, fp, orc):
-    """FPCA_ACCUM_FP32 (BASELINE config 5 "fp32 accumulate"): fp32 MFMA products, fp32 sums within a chunk, fp64 across
+    """FPCA_ACCUM_FP32 (BASELINE config 5 "fp32 accumulate"): fp32 MFMA products, fp32 sums within four chunks (512 samples / 256 SNPs), fp64 across
     chunks.  Tolerance: 2e-6 of the output scale per entry (fp32 rounding of the table and of B is 6e-8 relative per
     product; the observed error is ~1e-7)."""
     N = fp.count_fam_rows(os.path.join(golden_dir, name + ".fam"))
