@@ -379,6 +379,39 @@ def test_i8_hybrid_missing_route(S, fp, orc):
         assert np.array_equal(ctx.download_packed(), packed)  # the records whose missing calls were masked are back, bit for bit
 
 
+@pytest.mark.parametrize("mean,sigma,expect", [(0.02, 1.5, 4), (0.01, 2.0, 4), (0.02, 0.3, 0), (0.001, 0.5, 3)])
+def test_missing_route_follows_the_cost_model_on_lognormal_rates(mean, sigma, expect, fp, orc):
+    """Round 5: the route of the missing-call indicator is chosen from a cost model over K1's per-SNP counts (missing_routes.hip
+    hybrid_classify), and the generator has a profile between "uniform" and "5 % of the SNPs hold nearly everything": per-SNP rates
+    log-normally distributed.  A long tail (sigma 1.5-2) sends the shard down the hybrid route with a LARGE dense set -- 30-50 % of
+    the SNPs, far beyond round 4's "at most a quarter" -- a narrow spread around 2 % stays on the two-matrix kernels like a uniform
+    rate, a low rate on the sparse route; every product against the oracle's dense matrix (data.cpp:300-320: [1] -> 0) either way."""
+    N, P = 20000, 4096
+    with fp.Context.synthetic(N, P, n_pop=6, missing_rate=mean, missing_model=2, lognormal_sigma=sigma, accum="i8") as ctx:
+        packed = ctx.download_packed()
+        od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+        X = od.dense()
+        codes = np.stack([(packed.reshape(P, -1) >> (2 * s)) & 3 for s in range(4)], axis=-1).reshape(P, -1)[:, :N]
+        rate = (codes == 1).mean(axis=1)
+        assert abs(rate.mean() - mean) < 0.25 * mean and (sigma < 1 or rate.max() > 8 * np.median(rate))  # the profile is what it says
+        assert ctx.missing_mode(16) == expect, (ctx.missing_mode(16), rate.mean(), float(np.mean(rate > 0.0069)))
+        if expect == 4:
+            assert np.mean(rate > 0.0069) > (0.3 if mean >= 0.02 else 0.15)  # (round 4 admitted a dense set of at most a quarter, and only with the rest below 0.5 %)
+        rng = np.random.default_rng(int(1000 * sigma))
+        for b in (16, 32):
+            B = rng.standard_normal((N, b))
+            Tin = rng.standard_normal((P, b))
+            Z, T, Y = ctx.apply_xxt(B), ctx.apply_xt(B), ctx.apply_x(Tin)
+            Zr, Tr, Yr = X @ (X.T @ B), X.T @ B, X @ Tin
+            assert np.max(np.abs(Z - Zr)) <= 1e-11 * np.max(np.abs(Zr)), b
+            assert np.max(np.abs(T - Tr)) <= 1e-11 * np.max(np.abs(Tr)), b
+            assert np.max(np.abs(Y - Yr)) <= 1e-11 * np.max(np.abs(Yr)), b
+        assert np.array_equal(ctx.download_packed(), packed)
+        r = ctx.pca(ndim=5)
+        w = np.linalg.eigvalsh(X.T @ X if P < N else X @ X.T)[::-1][:5] / P
+        assert np.max(np.abs(r["d"] - w) / w) < 1e-8
+
+
 @pytest.mark.parametrize("N,P", [(1, 3), (5, 7), (257, 300), (2051, 129)])
 def test_i8_mode_ragged_shapes(N, P, fp, orc):
     rng = np.random.default_rng(N * 1000 + P)
