@@ -23,6 +23,32 @@ namespace {
 // With beta_out != nullptr Q is not formed: the reflectors stay below the sub-diagonal of A and their coefficients are
 // returned, for the caller to apply (symeig_desc_cols); rows are still produced when asked for.
 typedef double v4d __attribute__((vector_size(32)));
+// dot product in a fixed evaluation order (4 lanes x 4 accumulators): the same bits whoever computes it, and vector code where a
+// plain `s += a[i] * b[i]` loop is a 4-cycle dependency chain per element
+inline double dot_fixed(const double *a, const double *b, int m)
+{
+   v4d s0 = {0.0, 0.0, 0.0, 0.0}, s1 = s0, s2 = s0, s3 = s0;
+   int i = 0;
+   for (; i + 16 <= m; i += 16) {
+      v4d a0, a1, a2, a3, b0, b1, b2, b3; // (memcpy = unaligned vector loads)
+      std::memcpy(&a0, a + i, 32);
+      std::memcpy(&a1, a + i + 4, 32);
+      std::memcpy(&a2, a + i + 8, 32);
+      std::memcpy(&a3, a + i + 12, 32);
+      std::memcpy(&b0, b + i, 32);
+      std::memcpy(&b1, b + i + 4, 32);
+      std::memcpy(&b2, b + i + 8, 32);
+      std::memcpy(&b3, b + i + 12, 32);
+      s0 += a0 * b0;
+      s1 += a1 * b1;
+      s2 += a2 * b2;
+      s3 += a3 * b3;
+   }
+   const v4d t = (s0 + s1) + (s2 + s3);
+   double s = (t[0] + t[1]) + (t[2] + t[3]);
+   for (; i < m; i++) s += a[i] * b[i];
+   return s;
+}
 // One column of the symmetric matrix-vector product and of the rank-2 update on LOWER-triangle storage, fixed evaluation order
 // (4 lanes x 2 accumulators) so that every rank of a multi-GPU run gets the same bits:
 //   sym_col_mv:  returns col[1:].v[1:]  and adds col[1:] * vj to p[1:]      (column j of A22 from its diagonal down, length len)
@@ -479,7 +505,7 @@ int cols_core(int n, const double *A, int lda, const std::vector<double> &d, con
    // (per-thread scratch is allocated here, before anything is spawned; a thread body that throws reports 8, and whatever
    //  has been started is joined before this function is left -- by return or by an exception from thread creation: a
    //  non-zero return sends the caller to symeig_desc, nothing ends in std::terminate)
-   std::vector<std::vector<double>> scratch((size_t)T, std::vector<double>((size_t)n));
+   std::vector<std::vector<double>> scratch((size_t)T, std::vector<double>((size_t)8 * n)); // (a reflector; eight product columns)
    auto on_columns = [&](auto &&fn) { // fn(c0, c1, scratch) -> int
       std::vector<int> rcs((size_t)T, 0);
       std::vector<std::thread> th;
@@ -520,9 +546,7 @@ int cols_core(int n, const double *A, int lda, const std::vector<double> &d, con
          for (int i = 1; i < m; i++) v[i] = A[(size_t)(k + 1 + i) + (size_t)k * lda];
          for (int c = c0; c < c1; c++) {
             double *col = &y[(size_t)c * n + (k + 1)];
-            double sdot = 0;
-            for (int i = 0; i < m; i++) sdot += v[i] * col[i];
-            sdot *= beta[k];
+            const double sdot = beta[k] * dot_fixed(v.data(), col, m);
             for (int i = 0; i < m; i++) col[i] -= sdot * v[i];
          }
       }
@@ -533,22 +557,31 @@ int cols_core(int n, const double *A, int lda, const std::vector<double> &d, con
    double anorm = 0;
    for (size_t i = 0; i < A0.size(); i++) anorm = std::max(anorm, std::fabs(A0[i]));
    anorm = std::max(anorm * n, tnorm);
-   const int vrc = on_columns([&](int c0, int c1, std::vector<double> &r) {
+   // (A0 z for a thread's columns eight at a time: every column of A0 is read once per eight products, not once per product -- the
+   //  matrix does not fit in a core's L2 at restart sizes, and eight threads re-streaming it ten times each was most of this pass)
+   const int vrc = on_columns([&](int c0, int c1, std::vector<double> &R) {
+      for (int cb = c0; cb < c1; cb += 8) {
+         const int nc = std::min(8, c1 - cb);
+         std::fill(R.begin(), R.begin() + (size_t)nc * n, 0.0);
+         for (int j = 0; j < n; j++) {
+            const double *col = &A0[(size_t)j * n];
+            for (int q = 0; q < nc; q++) {
+               const double zj = y[(size_t)(cb + q) * n + j];
+               double *r = &R[(size_t)q * n];
+               for (int i = 0; i < n; i++) r[i] += col[i] * zj;
+            }
+         }
+         for (int q = 0; q < nc; q++) {
+            const double *z = &y[(size_t)(cb + q) * n], *r = &R[(size_t)q * n];
+            double res = 0;
+            for (int i = 0; i < n; i++) res = std::max(res, std::fabs(r[i] - w[cb + q] * z[i]));
+            if (!(res <= 1e-11 * anorm)) return 6;
+         }
+      }
       for (int c = c0; c < c1; c++) {
          const double *z = &y[(size_t)c * n];
-         std::fill(r.begin(), r.end(), 0.0);
-         for (int j = 0; j < n; j++) {
-            const double zj = z[j];
-            const double *col = &A0[(size_t)j * n];
-            for (int i = 0; i < n; i++) r[i] += col[i] * zj;
-         }
-         double res = 0;
-         for (int i = 0; i < n; i++) res = std::max(res, std::fabs(r[i] - w[c] * z[i]));
-         if (!(res <= 1e-11 * anorm)) return 6;
          for (int j = std::max(0, c - 64); j <= c; j++) {
-            const double *zj = &y[(size_t)j * n];
-            double dot = 0;
-            for (int i = 0; i < n; i++) dot += z[i] * zj[i];
+            const double dot = dot_fixed(z, &y[(size_t)j * n], n);
             if (!(std::fabs(dot - (j == c ? 1.0 : 0.0)) <= 1e-10)) return 7;
          }
       }
