@@ -106,6 +106,10 @@ struct fpca_ctx {
    int i8_Sc = 0;    // slices of the passes being made NOW when that is fewer than i8_S (the eigensolver's cheap passes), else 0
    int cur_S() const { return (i8_Sc > 0 && i8_Sc < i8_S) ? i8_Sc : i8_S; }
    bool i8_auto = false; // mode chosen by FPCA_ACCUM_AUTO: falls back to fp64 if the extra buffers do not fit
+   // FPCA_ACCUM_AUTO, the sample-major copy does not fit but everything else does: K2 (which reads the SNP-major matrix the
+   // context holds anyway) stays on the int8 matrix cores, K3 runs the FP64-MFMA kernel on the same matrix -- the largest inputs
+   // pay 5.5 + 23 ms per 16-column apply at 500,000 x 100,000 instead of 23 + 23
+   bool i8_k2_only = false;
    uint8_t *d_packedT = nullptr;
    size_t pitchT = 0;
    double *d_inv_sd = nullptr, *d_mu_inv_sd = nullptr, *d_i8w = nullptr;

@@ -39,8 +39,8 @@ bool ensure_i8(fpca_ctx *c, int b)
          char msg[640];
          std::snprintf(msg, sizeof(msg),
                        "the exact-integer arithmetic needs a second, sample-major copy of the packed genotypes (%.1f GiB) and its int8 operands; %.1f "
-                       "of %.1f GiB are free (%s).  What fits: --accum auto (falls back to the fp64 kernels, which need no second copy: same "
-                       "results, ~4x slower), --accum fp64, or the SNPs sharded over more GPUs (--gpus)",
+                       "of %.1f GiB are free (%s).  What fits: --accum auto (keeps X'B on the int8 cores and runs X T on the fp64 kernel, which "
+                       "needs no second copy: same results, ~2.6x slower per pass), --accum fp64, or the SNPs sharded over more GPUs (--gpus)",
                        copy * gb, (double)fr * gb, (double)tot * gb, e.what());
          throw Error(FPCA_ENOMEM, msg);
       }
@@ -59,6 +59,7 @@ bool ensure_i8(fpca_ctx *c, int b)
       c->i8ws_cap = 0;
       c->i8_ws_for_S = c->i8_ws_for_b = 0;
       c->i8_S = 0;
+      c->i8_k2_only = false;
       c->accum = FPCA_ACCUM_FP64;
       return false;
    }
@@ -71,12 +72,25 @@ void ensure_i8_alloc(fpca_ctx *c, int b)
    // exact int32 accumulation: |sum| <= 2 * 128 * K must stay below 2^31
    if (std::max(c->N_pad, c->P_pad) > (uint64_t)8380000)
       throw Error(FPCA_EINVAL, "the int8-sliced mode supports up to 8,380,000 samples and SNPs per GPU (int32 accumulation)");
-   if (!c->i8_transposed) {
+   if (!c->i8_transposed && !c->i8_k2_only) {
       c->pitchT = (size_t)c->P_pad / 4;
       if (!c->d_inv_sd) HIP_ALLOC(hipMalloc(&c->d_inv_sd, c->P_pad * sizeof(double)));
       if (!c->d_mu_inv_sd) HIP_ALLOC(hipMalloc(&c->d_mu_inv_sd, c->P_pad * sizeof(double)));
       if (!c->d_i8w) HIP_ALLOC(hipMalloc(&c->d_i8w, I8W_TOTAL * sizeof(double)));
-      HIP_ALLOC(hipMalloc(&c->d_packedT, c->pitchT * c->N_pad));
+      try {
+         if (FPCA_TEST_ENV("FPCA_DEBUG_I8_NOCOPY")) throw Error(FPCA_ENOMEM, "FPCA_DEBUG_I8_NOCOPY is set"); // exercises the K2-only state
+         HIP_ALLOC(hipMalloc(&c->d_packedT, c->pitchT * c->N_pad));
+      } catch (const Error &e) {
+         if (!c->i8_auto || e.code != FPCA_ENOMEM) throw;
+         (void)hipGetLastError();
+         std::fprintf(stderr, "[fpca] the sample-major copy of the packed genotypes (%.1f GiB) does not fit in device memory (%s): X'B stays on the int8 "
+                              "matrix cores, X T runs the fp64 kernels on the SNP-major matrix\n",
+                      (double)c->pitchT * (double)c->N_pad / (1024.0 * 1024.0 * 1024.0), e.what());
+         c->i8_k2_only = true;
+         c->hyb_failed = true; // (the hybrid route lives on a view of that copy)
+      }
+   }
+   if (!c->i8_transposed && !c->i8_k2_only) {
       // hybrid missing-indicator route (decided from K1's per-SNP counts, whatever b will be): the records of the dense SNPs are
       // copied out, their missing calls are rewritten to "dosage 0" for the duration of the transposition -- the sample-major
       // copy then IS the view the sparse lists and K3's G.M kernel want -- and the records are put back
@@ -320,6 +334,10 @@ void ensure_sparse(fpca_ctx *c, int b)
    HIP_CHECK(hipMemcpyAsync(c->d_snp_ptr, ptr.data(), (c->P_g + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
    kern::fill_missing(c->d_packed, c->pitch, c->N, c->P_g, c->d_snp_ptr, c->d_snp_idx, s);
    HIP_CHECK(hipStreamSynchronize(s)); // ptr is reused below
+   if (c->i8_k2_only) { // (no sample-major copy: X T runs the fp64 kernel, only the per-SNP lists of K2 exist)
+      c->sparse_ready = true;
+      return;
+   }
    uint32_t *d_cnt = nullptr;
    HIP_ALLOC(hipMalloc(&d_cnt, c->N * sizeof(uint32_t)));
    kern::count_missing(c->d_packedT, c->pitchT, c->P_g, c->N, d_cnt, s);

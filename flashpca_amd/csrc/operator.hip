@@ -19,6 +19,20 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
       c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
       if (ev) HIP_CHECK(hipEventRecord(ev[0], s));
       i8_zero_meta(c, s);
+      if (c->i8_k2_only) { // no sample-major copy (it did not fit): K2 on the int8 matrix cores, K3 on the FP64-MFMA kernel
+         xt_i8(c, dB, b, s, false, ev ? ev + 4 : nullptr);
+         if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
+         const int s3 = kern::x_t_splits(c->N_pad, c->P_pad, b, false);
+         if (s3 > 1) c->ensure(c->d_part, c->part_cap, (size_t)s3 * c->N_pad * b);
+         if (ev) HIP_CHECK(hipEventRecord(ev[6], s));
+         kern::x_t(c->d_packed, c->pitch, c->d_lut, c->d_T, s3 > 1 ? c->d_part : dY, c->N_pad, c->P_pad, b, s3, false, s);
+         if (ev) HIP_CHECK(hipEventRecord(ev[7], s));
+         if (s3 > 1) kern::reduce_sum(c->d_part, dY, (uint64_t)c->N_pad * b, s3, s);
+         if (ev) HIP_CHECK(hipEventRecord(ev[2], s));
+         if (reduce) allreduce_rows(c, dY, b, s);
+         if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
+         return;
+      }
       xt_i8(c, dB, b, s, true, ev ? ev + 4 : nullptr);
       if (ev) HIP_CHECK(hipEventRecord(ev[1], s));
       const int nch = reduce ? ar_chunks(c) : 1;
@@ -83,7 +97,7 @@ void apply_sharded(fpca_ctx *c, const RowShard &sh, const double *in_slice, int 
    c->all_gather(sh, in_slice, c->d_full_in, b, s);
    if (sh.nch > 1 && c->native_collectives() && c->comm_stream) {
       ensure_stats(c);
-      if (c->i8_S && ensure_i8(c, b)) {
+      if (c->i8_S && ensure_i8(c, b) && !c->i8_k2_only) {
          c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
          i8_zero_meta(c, s);
          xt_i8(c, c->d_full_in, b, s, true);
@@ -129,7 +143,7 @@ void xt_dev(fpca_ctx *c, const double *dB, int b, hipStream_t s)
 void x_dev(fpca_ctx *c, int b, double *dY, hipStream_t s)
 {
    ensure_stats(c);
-   if (c->i8_S && ensure_i8(c, b)) {
+   if (c->i8_S && ensure_i8(c, b) && !c->i8_k2_only) {
       i8_zero_meta(c, s);
       x_i8(c, b, dY, s, false);
       return;

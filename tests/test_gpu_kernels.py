@@ -412,6 +412,36 @@ def test_missing_route_follows_the_cost_model_on_lognormal_rates(mean, sigma, ex
         assert np.max(np.abs(r["d"] - w) / w) < 1e-8
 
 
+@pytest.mark.parametrize("kw,expect_mode", [(dict(missing_rate=0.001), 3), (dict(missing_rate=0.02), 0), (dict(realistic=True), 0), (dict(missing_rate=0.0), 2)])
+def test_auto_keeps_k2_on_the_int8_cores_when_only_the_second_copy_does_not_fit(kw, expect_mode, fp, orc, monkeypatch):
+    """FPCA_ACCUM_AUTO on the largest inputs (round 5): when the sample-major copy of the packed matrix is what does not fit, only
+    K3 -- the stage that reads it -- drops to the FP64-MFMA kernel; K2 reads the SNP-major matrix the context holds anyway and stays on
+    the int8 matrix cores (rounds 1-4 dropped BOTH stages: 4.6 x the time where the matrix is biggest).  Forced here by making that
+    one allocation fail (test build); all three products and a solve against the oracle, every missing-call route that state allows
+    (the hybrid route lives on a view of the copy: those data take the two-matrix K2)."""
+    N, P = 5003, 3001
+    with fp.Context.synthetic(N, P, n_pop=5, accum="fp64", **kw) as ref:
+        packed = ref.download_packed()
+    od = orc.OracleData(packed=packed, N=N, P=P, stand="binom2")
+    X = od.dense()
+    monkeypatch.setenv("FPCA_DEBUG_I8_NOCOPY", "1")
+    with fp.test_hooks(), fp.Context.synthetic(N, P, n_pop=5, accum="auto", **kw) as ctx:
+        rng = np.random.default_rng(11)
+        for b in (16, 32, 64, 20):
+            B = rng.standard_normal((N, b))
+            Tin = rng.standard_normal((P, b))
+            Z, T, Y = ctx.apply_xxt(B), ctx.apply_xt(B), ctx.apply_x(Tin)
+            Zr, Tr, Yr = X @ (X.T @ B), X.T @ B, X @ Tin
+            assert np.max(np.abs(Z - Zr)) <= 1e-11 * np.max(np.abs(Zr)), b
+            assert np.max(np.abs(T - Tr)) <= 1e-11 * np.max(np.abs(Tr)), b
+            assert np.max(np.abs(Y - Yr)) <= 1e-11 * np.max(np.abs(Yr)), b
+        assert ctx.accum == "i8x7" and ctx.missing_mode(16) == expect_mode  # still the exact-integer context: K2's route
+        r = ctx.pca(ndim=6)
+        w = np.linalg.eigvalsh(X.T @ X)[::-1][:6] / P
+        assert np.max(np.abs(r["d"] - w) / w) < 1e-8
+        assert np.array_equal(ctx.download_packed(), packed)
+
+
 @pytest.mark.parametrize("N,P", [(1, 3), (5, 7), (257, 300), (2051, 129)])
 def test_i8_mode_ragged_shapes(N, P, fp, orc):
     rng = np.random.default_rng(N * 1000 + P)
