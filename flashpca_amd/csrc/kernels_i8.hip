@@ -317,7 +317,11 @@ struct I8Cfg {
    static constexpr int ROWS = WR * MT * 32;            // workgroup rows
    static constexpr int COLS = WC * NT * 32 - (HALF ? 16 : 0); // workgroup columns of each operand
    static constexpr int LDQ = KC + 16;                  // operand tile row stride (bytes)
-   static constexpr int QTILE = COLS * LDQ;             // bytes of one operand tile
+   // HALF: the 16 rows of the remainder tile are read by ds_read_b128 with lanes l and l + 16 one 16-byte slot apart, which at
+   // the odd slot pitch of the full tiles puts two lanes of a 16-lane service group on one slot (LDS bank conflicts 8.7 % of the
+   // kernel's LDS cycles, round 4); those rows get an even pitch of 2 slots (mod 16) instead: slot = 2 j + (l >> 4 & 1)
+   static constexpr int LDQH = LDQ + (HALF ? 16 : 0);   // row stride of the remainder tile's rows
+   static constexpr int QTILE = COLS * LDQ + (HALF ? 16 * 16 : 0); // bytes of one operand tile
    static constexpr int STAGE = NQ * QTILE;
    static constexpr int SEGS = KC / 16, RSTEP = 256 / SEGS; // 16-byte segments per row; rows covered by 256 threads
    static constexpr int NP1 = COLS / RSTEP;             // pieces per thread per operand tile
@@ -333,6 +337,7 @@ struct I8Cfg {
    // so it asks for enough LDS to be two (the wider blocks are two or one by their registers: 224+ of 512).
    static constexpr int LDS_BYTES = (!TWO && NT <= 2 && LDS_NEED < 56 * 1024) ? 56 * 1024 : LDS_NEED;
    static_assert(COLS % RSTEP == 0 && NSTEP % 2 == 0 && LDS_BYTES <= 160 * 1024, "staging");
+   static_assert(!HALF || RSTEP == 16, "the remainder tile is the last staging piece");
 };
 
 // returns (MODE == I8_SKIP_EMPTY) whether any lane of the wave holds a missing genotype in this 32-row x 32-k block
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
    const uint8_t *prow = packed + row0 * pitch;
    const uint32_t aQ0 = lds_base + (uint32_t)(wc * 32 * NT + li) * LDQ + kh * (KC / 2);
    // HALF: lane (column j = lane & 15, quarter qd = lane >> 4) of the 16x16x64 operand reads k-half qd >> 1 of k-step 2 kp + (qd & 1)
-   const uint32_t aQh0 = lds_base + (uint32_t)(32 * NTF + (lane & 15)) * LDQ + ((lane >> 5) & 1) * (KC / 2) + ((lane >> 4) & 1) * 16;
+   const uint32_t aQh0 = lds_base + (uint32_t)(32 * NTF * LDQ + (lane & 15) * C::LDQH) + ((lane >> 5) & 1) * (KC / 2) + ((lane >> 4) & 1) * 16;
 
    u4 qreg[NP];
    u4 pk[MT][PW], pkn[MT][PW]; // packed words of the current / next chunk (one dword per k-step)
@@ -447,7 +452,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_i8(const uint8_t *__restrict__ 
    auto store_q = [&](auto rr, unsigned char *st) {
       constexpr int r = decltype(rr)::value, o = r / NP1, r1 = r % NP1;
       vm_wait<NP - 1 - r + NPK>(qreg[r]); // loads are issued in the order q[0..NP), p[..]
-      *reinterpret_cast<u4 *>(st + o * C::QTILE + r1 * C::RSTEP * LDQ) = qreg[r];
+      // (HALF: the last piece is the remainder tile's 16 rows, at their own pitch)
+      const int hoff = (HALF && r1 == NP1 - 1) ? (tid / C::SEGS) * (C::LDQH - LDQ) : 0;
+      *reinterpret_cast<u4 *>(st + o * C::QTILE + r1 * C::RSTEP * LDQ + hoff) = qreg[r];
    };
 
    // prologue: chunk c_begin
