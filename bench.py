@@ -926,8 +926,9 @@ def main():
             del rr_
 
     # ---- the same workload through the other exact path (fp64 MFMA kernels <-> int8 slices): timing and agreement ------
-    if world == 1 and args.accum in ("fp64", "i8") and not args.no_alt:
-        other = "fp64" if args.accum == "i8" else "i8"
+    # (the default run also carries the fp32-product twin: BASELINE configs[4]'s "fp32 accumulate" arithmetic, and with fp64 what
+    # FPCA_ACCUM_AUTO drops to stage by stage when the exact-integer mode's buffers do not fit)
+    for other in ((["fp64", "fp32"] if args.accum == "i8" else ["i8"]) if world == 1 and args.accum in ("fp64", "i8") and not args.no_alt else []):
         with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=min(2 * k, 64), device=local_rank, accum=other) as c2:
             c2.set_total_snps(P_total)
             Y2 = torch.zeros_like(Y)
@@ -948,6 +949,10 @@ def main():
                 ops = (1 if c2.missing_mode(b) in (2, 3, 4) else 2) * flops_launch * 7
                 rf = dict(bound="mfma", achieved=ops / (ms2 * 1e-3) / 1e12, peak=I8_MFMA_PEAK_TOPS, unit="TOP/s",
                           frac=ops / (ms2 * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, peak_measured_pure_mfma_stream=mfma_stream_peak(11))
+            elif other == "fp32":
+                rf = dict(bound="mfma", achieved=flops_launch / (ms2 * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                          frac=flops_launch / (ms2 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                          note="fp32 products and short sums on v_mfma_f32_16x16x4, folded into fp64 accumulators every 4th chunk")
             else:
                 rf = dict(bound="mfma", achieved=flops_launch / (ms2 * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                           frac=flops_launch / (ms2 * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, peak_measured_pure_mfma_stream=mfma_stream_peak(0))
@@ -961,7 +966,8 @@ def main():
                 alt["pca_block_applies"] = r2["info"]["block_applies"]
                 if "pca" in out:
                     alt["pca_eigenvalue_max_rel_diff_between_modes"] = float(max(abs(a - c) / abs(c) for a, c in zip(r2["d"], r["d"])))
-            out["fp64_mode" if other == "fp64" else "exact_int8_mode"] = alt
+            out[{"fp64": "fp64_mode", "fp32": "fp32_mode"}.get(other, "exact_int8_mode")] = alt
+            del Y2
 
     # ---- the whole program: `flashpca --bfile ... --ndim k --outload ... --outmeansd ...` on a fileset written to /tmp, the
     # reference's own process boundary (flashpca.cpp:589-604, 755-813): text parse, .bed upload, K1, solve, loadings, four
