@@ -61,7 +61,7 @@ STEPS = {"cfg2": 400, "tiny": 400, "cfg3": 80, "cfg5": 24, "cfg4shard": 200, "cf
 
 
 MISSING_PATH = {0: "dense (MFMA)", 1: "dense, empty blocks skipped", 2: "none missing", 3: "sparse fp64 gathers",
-                4: "hybrid: sparse fp64 gathers + a compacted dense sub-matrix (MFMA) for the SNPs above 0.5 % missing calls"}
+                4: "hybrid: sparse fp64 gathers + a compacted dense sub-matrix (MFMA) for the SNPs whose calls cost more to gather (above ~0.7 % missing at 7 slices; cost model over K1's counts)"}
 
 
 def solver_blockvec(k):

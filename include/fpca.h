@@ -140,8 +140,9 @@ int fpca_accum(const fpca_ctx *ctx);           /* the FPCA_ACCUM_* mode in effec
 /* how the exact-integer path treats the missing-call indicator for blocks of b columns (chosen from K1's counts of this
  * shard): 0 = both integer matrices on the matrix cores, 1 = the same, skipping blocks without a missing call, 2 = the
  * shard has no missing call (one matrix), 3 = one matrix on the matrix cores + the missing-call products as sparse fp64
- * gathers, 4 = hybrid: as 3 for most SNPs, while the few SNPs that hold most of the missing calls (above 0.5 % each: failed
- * assays) keep their indicator on the matrix cores as a compacted sub-matrix; -1 = not the exact-integer path.  Negative
+ * gathers, 4 = hybrid: as 3 for most SNPs, while the SNPs whose missing calls would cost more to gather than their indicator row
+ * costs on the matrix cores (above ~0.7 % each at 7 slices: failed assays, the tail of a log-normal rate profile) keep their
+ * indicator there as a compacted sub-matrix -- taken when the per-SNP minima beat both uniform routes; -1 = not the exact-integer path.  Negative
  * FPCA_E* on error. */
 int fpca_missing_mode(fpca_ctx *ctx, int b);
 /* row chunks of Y whose all-reduce the built-in communicator overlaps with the computation of the next chunk (1 = one
