@@ -632,13 +632,14 @@ def test_i8_forced_missing_modes(golden_dir, fp, orc, monkeypatch, mode):
 
 
 def test_randomised_parity_sweep(built_lib):
-    """scripts/fuzz_parity.py: 30 random (N, P, b, S, missing rate, forced missing-indicator path) cases, exact-integer
-    and fp64 kernels against dense numpy (all-missing and monomorphic SNPs mixed in)."""
+    """scripts/fuzz_parity.py: 30 random (N, P, b, S, missing profile -- uniform / concentrated / log-normal per SNP --, forced or
+    automatic missing-indicator route, with or without the sample-major copy) cases, exact-integer, fp64 and (one in four) fp32
+    kernels against dense numpy (all-missing and monomorphic SNPs mixed in)."""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k != "FPCA_I8_MODE"}
+    env = {k: v for k, v in os.environ.items() if k not in ("FPCA_I8_MODE", "FPCA_DEBUG_I8_NOCOPY")}
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_parity.py"), "30", "7"], capture_output=True, text=True, env=env,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
