@@ -201,7 +201,7 @@ def test_cli_gpus_launcher_rccl_shaped_exchange(tmp_path, built_lib):
     """The row-sharded solver with a transport that HAS all-gather / reduce-scatter (FPCA_CLI_TEST_TRANSPORT=shm2 installs
     fpca_set_collectives over host shared memory): the very call sequence of the RCCL path -- per row chunk, the reduce-scatter
     of chunk i on the communication stream under the K3 of chunk i + 1, the chunk-interleaved slice layout, chunks wholly behind
-    the last row skipped -- with 2 and 3 processes on one device and 1 / 2 / 4 row chunks (5,000 samples: 5,120 padded rows, so
+    the last row skipped -- with 2, 3, 4 and 8 processes on one device and 1 / 2 / 4 row chunks (5,000 samples: 5,120 padded rows, so
     the chunks are whole, clipped and empty).  The exchange self-test (HipBackend::exchange_selftest) runs inside every one of
     these; every output must equal the single-process run."""
     import flashpca_amd as fp
@@ -222,7 +222,8 @@ def test_cli_gpus_launcher_rccl_shaped_exchange(tmp_path, built_lib):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     e1 = np.loadtxt(d1 / "eigenvalues.txt")
     U1, V1, m1 = _tab(d1 / "eigenvectors.txt"), _tab(d1 / "load.txt"), _tab(d1 / "ms.txt")
-    for g, chunks in ((2, 1), (2, 4), (3, 2), (3, 4)):
+    # (8 processes = the shard plan of BASELINE configs[3] / [4]: the 5,120 padded rows in 1 / 2 / 4 chunks of 8 pieces each)
+    for g, chunks in ((2, 1), (2, 4), (3, 2), (3, 4), (4, 4), (8, 1), (8, 2), (8, 4)):
         d = tmp_path / ("g%dc%d" % (g, chunks))
         d.mkdir()
         env = dict(os.environ, FPCA_CLI_TEST_TRANSPORT="shm2", FPCA_AR_CHUNKS=str(chunks))
