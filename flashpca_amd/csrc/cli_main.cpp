@@ -975,6 +975,9 @@ int main(int argc, char *argv[])
                                                 "replicated (a collective of the row-sharded solve failed; started over)"};
             std::cout << timestamp() << "eigensolver layout over " << ngpus << " GPUs: " << names[info.solver_path >= 0 && info.solver_path <= 4 ? info.solver_path : 0]
                       << std::endl;
+            uint64_t ccalls = 0, cbytes = 0;
+            if (fpca_collective_stats(ctx, &ccalls, &cbytes) == FPCA_OK)
+               std::cout << timestamp() << "collectives on the data path: " << ccalls << " calls, " << cbytes << " bytes sent per rank" << std::endl;
          }
          std::cout << timestamp() << "PCA done" << std::endl;
       } else if (mode == MODE_CHECK) {
