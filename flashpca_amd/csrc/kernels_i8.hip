@@ -779,7 +779,8 @@ static I8Shape i8_shape(int S, int b, bool two, int mode = I8_FULL)
    sh.kc = 256;
    // b = 16 with S = 7 slices: 112 slice-columns = 3.5 tiles -- the one-matrix kernel (the default route up to 0.5 % missing
    // calls) takes the remainder as a half tile
-   sh.half = mode != I8_SKIP_EMPTY && sh.zb == 1 && sh.nt == 4 && S * b == 32 * sh.nt - 16;
+   // ... and so does b = 16 with S = 3 (48 slice-columns = 1.5 tiles: the eigensolver's cheap passes, one-matrix kernel only)
+   sh.half = mode != I8_SKIP_EMPTY && sh.zb == 1 && S * b == 32 * sh.nt - 16 && (sh.nt == 4 || (sh.nt == 2 && !two && mode == I8_NO_MISSING));
    if (sh.half) {
       sh.cols -= 16;
       sh.rows = 256; // (every half-tile instantiation is 4 waves x 64 rows, the two-matrix K2 one included)
@@ -978,7 +979,9 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
          }
       } else
 #endif
-      if (sh.half)
+      if (sh.half && sh.nt == 2)
+         launch_i8<I8Cfg<false, 2, 2, 4, 1, 256, 1, I8_NO_MISSING, 0, true>>(FPCA_I8_ARGS);
+      else if (sh.half)
          launch_i8<I8Cfg<false, 2, 4, 4, 1, 256, 1, I8_NO_MISSING, 0, true>>(FPCA_I8_ARGS);
       else if (sh.nt == 2 && sh.mt == 4)
          launch_i8<I8Cfg<false, 4, 2, 4, 1, 256, 1, I8_NO_MISSING>>(FPCA_I8_ARGS);

@@ -46,6 +46,15 @@ def test_bench_line_contract_single_rank():
     for leg in ("pca", "pca_hard_spectrum", "pca_realistic"):
         assert d[leg]["converged"] is True and d[leg]["wall_s"] > 0, leg
     assert d["pca_realistic"]["missing_call_path"].startswith("hybrid")
+    # the secondary results travel as scalars inside `roofline` (the object the driver keeps whole), equal to their side blocks
+    for key in ("fp64_frac", "fp32_frac", "cheap_pass_frac_mfma", "cheap_pass_frac_hbm", "cheap_pass_ms", "pca_s", "pca_realistic_s", "pca_hard_s",
+                "e2e_cli_warm_s", "power_w"):
+        assert key in rf, key
+    assert rf["pca_s"] == d["pca"]["wall_s"] and rf["pca_hard_s"] == d["pca_hard_spectrum"]["wall_s"] and rf["pca_realistic_s"] == d["pca_realistic"]["wall_s"]
+    assert rf["fp64_frac"] == d["fp64_mode"]["roofline"]["frac"] and rf["fp32_frac"] == d["fp32_mode"]["roofline"]["frac"]
+    assert rf["e2e_cli_warm_s"] is None  # (--no-e2e here; the driver's default run carries it)
+    if "cheap_pass" in d and "ms_per_step" in d["cheap_pass"]:
+        assert rf["cheap_pass_ms"] == d["cheap_pass"]["ms_per_step"]
 
 
 def test_bench_two_ranks_on_one_gpu_validates_itself():
