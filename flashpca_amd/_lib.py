@@ -130,7 +130,6 @@ SIGNATURES = {
     "fpca_set_total_snps": (_I, [_P, _U64]),
     "fpca_set_rank": (_I, [_P, _I, _I]),
     "fpca_collective_stats": (_I, [_P, C.POINTER(_U64), C.POINTER(_U64)]),
-    "fpca_pca_default_opts": (None, [C.POINTER(PcaOpts)]),
     "fpca_pca_init_opts": (None, [C.POINTER(PcaOpts), C.c_size_t, C.c_size_t]),
     "fpca_pca_row_ranges": (_I, [_P, C.POINTER(PcaOpts), C.POINTER(_U64), _I]),
     "fpca_pca": (_I, [_P, C.POINTER(PcaOpts), _P, _P, _P, _P, _P, _P, C.POINTER(PcaInfo)]),
@@ -149,7 +148,7 @@ SIGNATURES = {
     "fpca_debug_k4_bench": (_I, [_P, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)]),
 }
 
-ABI_VERSION = 3  # FPCA_ABI_VERSION of the include/fpca.h the structures above mirror
+ABI_VERSION = 4  # FPCA_ABI_VERSION of the include/fpca.h the structures above mirror
 
 _lib = None
 _loaded = {}

@@ -451,6 +451,8 @@ int fpca_comm_init_rank(fpca_ctx *ctx, int nranks, int rank, const uint8_t id[FP
       ctx->nranks = nranks;
       ctx->rank = rank;
       ctx->rank_known = true;
+      ctx->comm_dead = false;
+      reset_exchange_state(ctx);
       ctx->i8_ws_for_S = ctx->i8_ws_for_b = 0; // (the row chunks of the multi-rank K3 enter the workspace size)
       comm_streams(ctx);
       // self-test: sum of (rank+1) over ranks must be n(n+1)/2 on every rank
@@ -468,6 +470,8 @@ int fpca_set_allreduce(fpca_ctx *ctx, fpca_allreduce_fn fn, void *user)
    if (!ctx) return FPCA_EINVAL;
    ctx->ar_fn = fn;
    ctx->ar_user = user;
+   if (fn) ctx->comm_dead = false; // (a new transport)
+   reset_exchange_state(ctx);
    return FPCA_OK;
 }
 
@@ -479,6 +483,7 @@ int fpca_set_collectives(fpca_ctx *ctx, fpca_allgather_fn ag, fpca_reducescatter
       ctx->ag_fn = ag;
       ctx->rs_fn = rs;
       ctx->coll_user = user;
+      reset_exchange_state(ctx);
       if (ag) comm_streams(ctx); // the stream on which a chunk's reduce-scatter runs while K3 computes the next chunk
       ctx->i8_ws_for_S = ctx->i8_ws_for_b = 0;
    });
@@ -490,6 +495,7 @@ int fpca_set_rank(fpca_ctx *ctx, int nranks, int rank)
    ctx->nranks = nranks;
    ctx->rank = rank;
    ctx->rank_known = true;
+   reset_exchange_state(ctx);
    ctx->i8_ws_for_S = ctx->i8_ws_for_b = 0;
    return FPCA_OK;
 }
@@ -527,7 +533,6 @@ void fpca_pca_init_opts(fpca_pca_opts *o, size_t opts_size, size_t info_size)
    std::memcpy(o, &d, std::min(opts_size, sizeof(d)));
 }
 
-void fpca_pca_default_opts(fpca_pca_opts *o) { fpca_pca_init_opts(o, sizeof(fpca_pca_opts), sizeof(fpca_pca_info)); }
 
 int fpca_pca_row_ranges(fpca_ctx *ctx, const fpca_pca_opts *opts, uint64_t *ranges, int max_ranges)
 {
@@ -675,8 +680,9 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
          } catch (const Error &e) {
             if (e.code != FPCA_ECOMM) throw;
             why = e.what();
-            (void)hipStreamSynchronize(ctx->stream);
-            if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+            // (the collectives this rank enqueued before the failure may wait for peers that are elsewhere: bounded)
+            if (!(bounded_sync(ctx, ctx->stream) && (!ctx->comm_stream || bounded_sync(ctx, ctx->comm_stream))))
+               abandon_comm(ctx, why + "; the collectives enqueued before the failure never completed");
             (void)hipGetLastError();
          }
          const double bad = agree_sum(ctx, why.empty() ? 0.0 : 1.0);
@@ -689,6 +695,14 @@ int fpca_pca(fpca_ctx *ctx, const fpca_pca_opts *opts, double *U, double *d, dou
             const RowShard sh = HipBackend::plan_shard(ctx, HipBackend::ROWSHARD);
             ctx->exchange_failed = ((long)sh.G * 8 + sh.nch) * 128 + b; // (not tried again on this context)
             ctx->exchange_failed_path = FPCA_SOLVER_REPLICATED_FAILURE;
+            // the unwound row-sharded backend has returned its slice-sized blocks to the pool, where the replicated retry (whole
+            // blocks) cannot reuse them; at the largest inputs they are the memory the retry needs
+            for (auto &pb : ctx->block_pool) (void)hipFree(pb.second);
+            ctx->block_pool.clear();
+            if (ctx->d_full_in) (void)hipFree(ctx->d_full_in);
+            if (ctx->d_full_out) (void)hipFree(ctx->d_full_out);
+            ctx->d_full_in = ctx->d_full_out = nullptr;
+            ctx->full_in_cap = ctx->full_out_cap = 0;
             solve(true);
          }
       }

@@ -236,6 +236,8 @@ void fpca_ok(int rc)
 static_assert(std::atomic<int>::is_always_lock_free, "the SIGCHLD handler touches these atomics: they must be lock-free");
 struct MultiShared {
    std::atomic<int> created, failed, id_ready, bar_count, bar_sense;
+   std::atomic<int> op_kind[64];             // test transport: the call every rank is in (shm_same_call)
+   std::atomic<unsigned long long> op_count[64];
    uint8_t id[FPCA_UNIQUE_ID_BYTES];
    char msg[512];
 };
@@ -366,13 +368,29 @@ bool multi_barrier(Multi &m)
 // sharding and the gather of the outputs on a one-GPU box, where RCCL refuses two ranks on one device.  The shipped CLI
 // has no such path: its only transport is RCCL.
 #ifdef FPCA_TEST_HOOKS
+// the hook contract of fpca.h: a collective fails on every rank or on none.  Every rank announces (call kind, count) before the
+// first rendezvous and checks after it that all ranks are in the SAME call -- ranks out of step (one of them took an error path
+// the others did not) all see the mismatch and all return non-zero.
+static bool shm_same_call(Multi &m, int kind, uint64_t count)
+{
+   m.sh->op_kind[m.rank].store(kind);
+   m.sh->op_count[m.rank].store(count);
+   if (!multi_barrier(m)) return false;
+   for (int r = 0; r < m.ngpus; r++)
+      if (m.sh->op_kind[r].load() != kind || m.sh->op_count[r].load() != count) {
+         std::fprintf(stderr, "[fpca-cli] rank %d: the ranks are not in the same collective (rank %d: kind %d count %llu; here kind %d count %llu)\n", m.rank, r,
+                      m.sh->op_kind[r].load(), (unsigned long long)m.sh->op_count[r].load(), kind, (unsigned long long)count);
+         return false;
+      }
+   return true;
+}
 int shm_allreduce(void *user, double *dbuf, uint64_t count, void *stream)
 {
    Multi &m = *static_cast<Multi *>(user);
    if (count > m.slot_cap) return -1;
    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
    if (hipMemcpy(m.slots + (size_t)m.rank * m.slot_cap, dbuf, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-   if (!multi_barrier(m)) return -1;
+   if (!shm_same_call(m, 1, count)) return -1;
    std::vector<double> sum(count, 0.0);
    for (int r = 0; r < m.ngpus; r++) {
       const double *p = m.slots + (size_t)r * m.slot_cap;
@@ -389,7 +407,7 @@ int shm_allgather(void *user, const double *send, double *recv, uint64_t count, 
    if (count > m.slot_cap) return -1;
    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
    if (hipMemcpy(m.slots + (size_t)m.rank * m.slot_cap, send, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-   if (!multi_barrier(m)) return -1;
+   if (!shm_same_call(m, 2, count)) return -1;
    for (int r = 0; r < m.ngpus; r++)
       if (hipMemcpy(recv + (size_t)r * count, m.slots + (size_t)r * m.slot_cap, count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return -1;
    return multi_barrier(m) ? 0 : -1;
@@ -400,7 +418,7 @@ int shm_reducescatter(void *user, const double *send, double *recv, uint64_t cou
    if (count * (uint64_t)m.ngpus > m.slot_cap) return -1;
    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
    if (hipMemcpy(m.slots + (size_t)m.rank * m.slot_cap, send, count * m.ngpus * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-   if (!multi_barrier(m)) return -1;
+   if (!shm_same_call(m, 3, count)) return -1;
    std::vector<double> sum(count, 0.0);
    for (int r = 0; r < m.ngpus; r++) {
       const double *p = m.slots + (size_t)r * m.slot_cap + (size_t)m.rank * count;

@@ -4,6 +4,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 
 #include "ctx.hpp"
 
@@ -28,6 +30,8 @@ RcclApi &rccl()
       api.AllGather = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
       api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+      api.CommAbort = (decltype(api.CommAbort))dlsym(api.handle, "ncclCommAbort");
+      api.CommGetAsyncError = (decltype(api.CommGetAsyncError))dlsym(api.handle, "ncclCommGetAsyncError");
       if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.ReduceScatter || !api.AllGather || !api.CommDestroy)
          throw Error(FPCA_ECOMM, "librccl is missing expected symbols");
    }
@@ -36,8 +40,14 @@ RcclApi &rccl()
 
 } // namespace fpca
 
+static void refuse_dead(const fpca_ctx *c)
+{
+   if (c->comm_dead) throw Error(FPCA_ECOMM, "the transport of this context was abandoned after its ranks fell out of step; no further collective is issued");
+}
+
 void fpca_ctx::all_gather(const RowShard &sh, const double *slice, double *full, int b, hipStream_t s)
 {
+   refuse_dead(this);
    const size_t piece = (size_t)sh.plen * b, chunk = (size_t)sh.L * b;
    if (native_collectives()) {
       for (int c = 0; c < sh.nch; c++) {
@@ -59,10 +69,12 @@ void fpca_ctx::all_gather(const RowShard &sh, const double *slice, double *full,
 
 void fpca_ctx::reduce_scatter(const RowShard &sh, double *full, double *slice, int b, hipStream_t s, int only_chunk)
 {
+   refuse_dead(this);
    const size_t piece = (size_t)sh.plen * b, chunk = (size_t)sh.L * b;
    // (test builds: the n-th reduce-scatter of this context fails -- on every rank, the call sequence being the same everywhere)
+   // (FPCA_DEBUG_RS_FAIL_RANK = r: on rank r ONLY -- the asymmetric failure the hook contract forbids: the job must end, not hang)
    if (const char *inj = FPCA_TEST_ENV("FPCA_DEBUG_RS_FAIL"))
-      if (++dbg_rs_calls == atol(inj)) throw Error(FPCA_ECOMM, "injected failure of reduce-scatter call " + std::to_string(dbg_rs_calls) + " (FPCA_DEBUG_RS_FAIL)");
+      if (++dbg_rs_calls == atol(inj) && (!FPCA_TEST_ENV("FPCA_DEBUG_RS_FAIL_RANK") || atoi(FPCA_TEST_ENV("FPCA_DEBUG_RS_FAIL_RANK")) == rank)) throw Error(FPCA_ECOMM, "injected failure of reduce-scatter call " + std::to_string(dbg_rs_calls) + " (FPCA_DEBUG_RS_FAIL)");
    if (native_collectives()) {
       for (int c = 0; c < sh.nch; c++) {
          if (only_chunk >= 0 && c != only_chunk) continue;
@@ -82,6 +94,7 @@ void fpca_ctx::reduce_scatter(const RowShard &sh, double *full, double *slice, i
 
 void fpca_ctx::allreduce(double *dbuf, uint64_t count, hipStream_t s)
 {
+   refuse_dead(this);
    coll_calls++;
    coll_bytes += count * sizeof(double);
    if (ar_fn) { // a caller-supplied hook wins over the built-in communicator (set after a failed / partial RCCL init)
@@ -205,8 +218,12 @@ std::string exchange_selftest(fpca_ctx *c_, const RowShard &sh_, int b_)
          finish();
          throw;
       }
-      (void)hipStreamSynchronize(s);
-      if (c_->comm_stream) (void)hipStreamSynchronize(c_->comm_stream);
+      // (what this rank had enqueued before the failure may be waiting for peers that failed elsewhere: bounded)
+      const bool drained = bounded_sync(c_, s) && (!c_->comm_stream || bounded_sync(c_, c_->comm_stream));
+      if (!drained) {
+         finish();
+         abandon_comm(c_, std::string("rank ") + std::to_string(sh_.rank) + ": " + e.what() + "; the collectives enqueued before it never completed");
+      }
       if (why.empty()) why = std::string("rank ") + std::to_string(sh_.rank) + ": " + e.what();
    } catch (...) {
       finish();
@@ -221,15 +238,82 @@ std::string exchange_selftest(fpca_ctx *c_, const RowShard &sh_, int b_)
 // One number summed over all ranks through the context's plainest collective -- an all-reduce of a single double, RCCL's
 // most-trodden call -- so that a decision taken from a rank-local observation (the self-test's verdict, a collective that failed)
 // is the SAME decision everywhere.  Not counted in fpca_collective_stats (it is not on the data path).
+// time limit of a step on which the ranks must agree (seconds).  Generous: a peer may legitimately arrive late by a whole
+// block apply plus its own error handling -- but never by minutes.
+static double agree_limit_s()
+{
+   if (const char *e = FPCA_TEST_ENV("FPCA_AGREE_TIMEOUT_S"))
+      if (atof(e) > 0) return atof(e);
+   return 120.0;
+}
+
+void reset_exchange_state(fpca_ctx *c)
+{
+   c->exchange_tested = c->exchange_failed = -1;
+   c->exchange_failed_path = 0;
+   c->last_solver_path = 0;
+}
+
+void abandon_comm(fpca_ctx *c, const std::string &why)
+{
+   c->comm_dead = true;
+   if (c->comm) {
+      // ncclCommAbort tears down the kernels of this rank that spin on peers which will never arrive (CommDestroy would wait for them)
+      try {
+         if (rccl().CommAbort) (void)rccl().CommAbort(c->comm);
+      } catch (...) {
+      }
+      c->comm = nullptr;
+   }
+   throw Error(FPCA_ECOMM, why + " -- the transport of this context is abandoned (this rank returns FPCA_ECOMM; the launcher ends the job)");
+}
+
+bool bounded_sync(fpca_ctx *c, hipStream_t s)
+{
+   const auto t0 = std::chrono::steady_clock::now();
+   const double limit = agree_limit_s();
+   for (long it = 0;; it++) {
+      hipError_t q = hipStreamQuery(s);
+      // (test builds: FPCA_DEBUG_AGREE_STALL makes the stream look pending for ever -- the peers that never arrive)
+      if (q == hipSuccess && FPCA_TEST_ENV("FPCA_DEBUG_AGREE_STALL")) q = hipErrorNotReady;
+      if (q == hipSuccess) return true;
+      if (q != hipErrorNotReady) {
+         (void)hipGetLastError();
+         throw Error(FPCA_EHIP, std::string("hipStreamQuery failed: ") + hipGetErrorString(q));
+      }
+      if (c->comm && rccl().CommGetAsyncError && it % 256 == 255) { // an error RCCL noticed on its own: do not wait the limit out
+         ncclResult_t ar = ncclSuccess;
+         if (rccl().CommGetAsyncError(c->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) return false;
+      }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return false;
+      std::this_thread::sleep_for(std::chrono::microseconds(it < 2000 ? 50 : 1000));
+   }
+}
+
+// One number summed over all ranks through the context's plainest collective -- an all-reduce of a single double, RCCL's
+// most-trodden call -- so that a decision taken from a rank-local observation (the self-test's verdict, a collective that failed)
+// is the SAME decision everywhere.  Not counted in fpca_collective_stats (it is not on the data path).
+// TIME-BOUNDED: the step is only safe when every rank reaches it -- a collective that failed on ALL ranks, or a
+// verdict every rank computes.  A failure on ONE rank only (forbidden by the hook contract of fpca.h, possible with RCCL) leaves
+// this rank here and its peers inside the collective that failed for it: the all-reduce below then never completes.  Instead of
+// blocking for ever the rank gives up after agree_limit_s(), aborts the communicator and returns FPCA_ECOMM, which the
+// launcher turns into the end of the job (flashpca --gpus: SIGCHLD -> the other ranks are killed).
 double agree_sum(fpca_ctx *c, double mine)
 {
    if (!c->multi()) return mine;
    const uint64_t calls0 = c->coll_calls, bytes0 = c->coll_bytes;
    double v = mine;
    HIP_CHECK(hipMemcpyAsync(c->d_small + 80, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
-   c->allreduce(c->d_small + 80, 1, c->stream);
+   try {
+      c->allreduce(c->d_small + 80, 1, c->stream);
+   } catch (const Error &e) {
+      if (e.code != FPCA_ECOMM || c->comm_dead) throw;
+      abandon_comm(c, std::string("the all-reduce on which the ranks agree failed (") + e.what() + ")");
+   }
    HIP_CHECK(hipMemcpyAsync(&v, c->d_small + 80, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-   HIP_CHECK(hipStreamSynchronize(c->stream));
+   if (!bounded_sync(c, c->stream))
+      abandon_comm(c, "the ranks did not agree within " + std::to_string((int)agree_limit_s()) +
+                         " s on how to continue: a collective failed on this rank while its peers are elsewhere");
    c->coll_calls = calls0;
    c->coll_bytes = bytes0;
    return v;

@@ -47,6 +47,8 @@ struct RcclApi {
    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                         // optional
+   ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr; // optional
    const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -172,6 +174,10 @@ struct fpca_ctx {
    // the transport has real all-gather / reduce-scatter (RCCL, or the caller's): the chunked, overlapped exchange of the
    // row-sharded solver; otherwise both are built from the caller's sum
    bool native_collectives() const { return (comm && !ar_fn) || (ar_fn && ag_fn && rs_fn); }
+   // The transport was ABANDONED: a step on which the ranks must agree did not complete within its time limit (a collective had
+   // failed on this rank only, the peers are somewhere else), or RCCL reported an asynchronous error.  Every later collective of
+   // this context fails with FPCA_ECOMM at once -- nothing is ever sent into a communicator whose ranks are out of step.
+   bool comm_dead = false;
    bool rank_known = false; // nranks / rank are meaningful (fpca_comm_init_rank, or fpca_set_rank beside a caller's all-reduce)
    // row-sharded solver (backend.hpp RowShard): whole [full_rows][b] blocks either side of the operator
    double *d_full_in = nullptr, *d_full_out = nullptr;
@@ -188,7 +194,7 @@ struct fpca_ctx {
    bool prof_on = false;
 
    void ensure(double *&p, size_t &cap, size_t need); // grow a device workspace of doubles (context.hip)
-   bool multi() const { return comm != nullptr || ar_fn != nullptr; }
+   bool multi() const { return comm != nullptr || ar_fn != nullptr || comm_dead; }
    // the three data-path collectives over whichever transport is installed (comm.hip)
    // slice [sh.slice_rows()][b] -> full [sh.full_rows()][b] on every rank
    void all_gather(const RowShard &sh, const double *slice, double *full, int b, hipStream_t s);
@@ -227,7 +233,12 @@ uint64_t ar_chunk_begin(const fpca_ctx *c, int nchunks, int i);
 void allreduce_rows(fpca_ctx *c, double *dY, int b, hipStream_t s);
 // all-gather + reduce-scatter of the row-sharded solver on a block of known content: this rank's verdict (empty = right)
 std::string exchange_selftest(fpca_ctx *c, const RowShard &sh, int b);
-double agree_sum(fpca_ctx *c, double mine); // sum over ranks of one number (decisions from rank-local observations)
+double agree_sum(fpca_ctx *c, double mine); // sum over ranks of one number (decisions from rank-local observations); time-bounded
+// wait for a stream on which collectives may be pending, at most the agreement time limit: false = still pending (a peer is not
+// there); the caller abandons the transport
+bool bounded_sync(fpca_ctx *c, hipStream_t s);
+void abandon_comm(fpca_ctx *c, const std::string &why); // marks the transport dead, aborts the RCCL communicator, throws FPCA_ECOMM
+void reset_exchange_state(fpca_ctx *c);                 // a new transport / rank: nothing known about its exchange any more
 void comm_streams(fpca_ctx *c); // the communication stream and its events, once
 
 // ---- operator.hip -----------------------------------------------------------------------------------------

@@ -273,6 +273,9 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
    // are RESERVED while cheap passes run -- when only they are left, the cheap passes end whatever their estimates say, so that
    // a budget that runs out returns Rayleigh-Ritz pairs of the exact operator (and "converged" if the rule holds on them), never
    // a half-rebuilt T.  ritz_prefix: V[0 .. ritz_prefix) ARE the Ritz blocks of the last compression (until the next test).
+   // (One exception, by construction a NOT-CONVERGED result: a budget that ends between the compression and the first test on the
+   //  rebuilt T returns those Ritz blocks with res.evals of the last test of the cheap passes -- ESTIMATES within the cheap
+   //  arithmetic's noise of the Rayleigh quotients, ~1e-9 relative at 4 slices, not exact ones; `n < k` branch below.)
    const int reserve = kb;
    int ritz_prefix = 0;
 
@@ -357,7 +360,9 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
             }
          }
       };
-      auto update_with = [&](const std::vector<double> &Mx) { // W <- (W - V C) Mx : coefficients [-C_q Mx ; Mx]
+      // W <- (W - V C) Mx : coefficients [-C_q Mx ; Mx]; gram != null: the launch also leaves W'W of the block it writes there
+      // (BlockBackend::gemm_gram: no second pass over W, no second round trip)
+      auto update_with = [&](const std::vector<double> &Mx, double *gram = nullptr) {
          for (size_t qp = 0; qp < (size_t)M * b; qp++) {
             const double *row = &C[qp * b];
             double *out = &negC[qp * b];
@@ -370,7 +375,10 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
             }
          }
          std::copy(Mx.begin(), Mx.end(), negC.begin() + (long)cnt);
-         be.gemm(VW.data(), M + 1, negC.data(), -1, W);
+         if (gram)
+            be.gemm_gram(VW.data(), M + 1, negC.data(), -1, W, gram);
+         else
+            be.gemm(VW.data(), M + 1, negC.data(), -1, W);
       };
       std::fill(H.begin(), H.begin() + (long)cnt, 0.0);
       gram_vw();
@@ -415,31 +423,15 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          light3 = upper && pmin > 0 && cmax / pmin < 1e4;
       }
       // pass 2's update -- and, when pass 3 will only re-normalise, the Gram matrix of the block it writes from the same launch
-      // (BlockBackend::gemm_gram: no second pass over W, no second round trip)
-      {
-         const std::vector<double> &Mx = M1;
-         for (size_t qp = 0; qp < (size_t)M * b; qp++) {
-            const double *row = &C[qp * b];
-            double *out = &negC[qp * b];
-            for (int c = 0; c < b; c++) out[c] = 0.0;
-            for (int j = 0; j < b; j++) {
-               const double x = -row[j];
-               if (x == 0.0) continue;
-               const double *mj = &Mx[(size_t)j * b];
-               for (int c = 0; c < b; c++) out[c] += x * mj[c];
-            }
-         }
-         std::copy(Mx.begin(), Mx.end(), negC.begin() + (long)cnt);
-         if (light3) {
-            Gw.assign((size_t)b * b, 0.0);
-            be.gemm_gram(VW.data(), M + 1, negC.data(), -1, W, Gw.data());
-         } else
-            be.gemm(VW.data(), M + 1, negC.data(), -1, W);
-      }
+      if (light3) {
+         Gw.assign((size_t)b * b, 0.0);
+         update_with(M1, Gw.data());
+      } else
+         update_with(M1);
       phase(PH_SVQB);
       int nd2;
       if (light3) {
-         std::vector<double> &G3 = Gw; // (left there by the fused update + Gram launch of pass 2, below)
+         std::vector<double> &G3 = Gw; // (left there by the fused update + Gram launch of pass 2, just above)
          t0 = clk::now();
          nd2 = svqb_factor(b, G3, 0.0, M2, R2, dead2);
          host_s += since(t0);

@@ -39,7 +39,7 @@ extern "C" {
  *     reference's restarts (it was a cap on block applies in 0.1.0 -- use max_applies for that).
  *   3 (library 0.3.0): fpca_pca_opts.partial_rows, fpca_pca_info.solver_path; the struct sizes are the CALLER's
  *     (FPCA_PCA_OPTS_INIT / fpca_pca_init_opts); fpca_pca_row_ranges. */
-#define FPCA_ABI_VERSION 3
+#define FPCA_ABI_VERSION 4
 
 /* standardisation methods: same numeric values as the reference (util.h:34-38); the packed-genotype constructors
  * accept BINOM / BINOM2 like the CLI (flashpca.cpp:336-349), fpca_create_dense accepts all five */
@@ -189,7 +189,18 @@ int fpca_synchronize(fpca_ctx *ctx);
 int fpca_comm_unique_id(uint8_t id[FPCA_UNIQUE_ID_BYTES]);
 int fpca_comm_init_rank(fpca_ctx *ctx, int nranks, int rank, const uint8_t id[FPCA_UNIQUE_ID_BYTES]);
 /* (b) caller-supplied in-place sum all-reduce of `count` fp64 at device pointer `dbuf`, ordered on `stream`
- * (e.g. torch.distributed over RCCL).  Must return 0 on success. */
+ * (e.g. torch.distributed over RCCL).  Must return 0 on success.
+ * CONTRACT OF EVERY HOOK BELOW (all-reduce, all-gather, reduce-scatter): a collective fails AS A WHOLE -- a non-zero return must
+ * be reported on EVERY rank for the same call, and must leave no collective of that call outstanding on any rank.  The
+ * library reacts to a failed collective of the row-sharded solve by making the decision common (one all-reduce of a flag through
+ * this hook) and starting over on the replicated solver; a hook that fails on one rank only leaves that rank in the
+ * agreement while its peers are still inside the collective that failed for it.  A transport that cannot guarantee this by
+ * construction should check that all ranks have entered the SAME call before moving data (tag + count; the CLI's test transport
+ * does) and fail on all of them otherwise.  What the library does on its side: every step on which the ranks must agree is
+ * time-bounded (120 s) -- a rank that does not get its answer aborts the built-in RCCL communicator (ncclCommAbort; RCCL's
+ * asynchronous errors are polled meanwhile), marks the transport of the context dead (every later collective returns
+ * FPCA_ECOMM at once) and returns FPCA_ECOMM, for the launcher to end the job.  A hook that BLOCKS inside the caller's own
+ * code cannot be bounded from here. */
 typedef int (*fpca_allreduce_fn)(void *user, double *dbuf, uint64_t count, void *stream);
 int fpca_set_allreduce(fpca_ctx *ctx, fpca_allreduce_fn fn, void *user);
 /* ... and, optionally beside it, the caller's all-gather and reduce-scatter (sum) of fp64 on device buffers, ordered on `stream`:
@@ -288,9 +299,8 @@ typedef struct fpca_pca_info {
  * against another revision of this header: never more than opts_size bytes are written.  C callers use the macro. */
 void fpca_pca_init_opts(fpca_pca_opts *opts, size_t opts_size, size_t info_size);
 #define FPCA_PCA_OPTS_INIT(o) fpca_pca_init_opts((o), sizeof(*(o)), sizeof(fpca_pca_info))
-/* The same with the LIBRARY's own sizes: only for bindings that mirror the structs of this very header field by field
- * and check fpca_abi_version() first (flashpca_amd/_lib.py). */
-void fpca_pca_default_opts(fpca_pca_opts *opts);
+/* (Revision 4 removed fpca_pca_default_opts, which wrote the LIBRARY's sizeof into the caller's struct: a binary built against an
+ * older header now fails to resolve the symbol at load time instead of being overrun by 8 bytes.) */
 /* partial_rows = 1: the row ranges [begin, end) of U / Px this rank writes -- ranges[2 i], ranges[2 i + 1], at most max_ranges of
  * them are stored, the count is returned (<= 4; negative FPCA_E* on error).  After an fpca_pca call the answer reflects the
  * layout that call ended on (a demotion to the replicated solver changes the ranges). */

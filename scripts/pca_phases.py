@@ -26,7 +26,7 @@ with fp.Context.synthetic(N, P, n_pop=min(2 * k, 64), accum="auto") as ctx:
     keep = None
     for i in range(4):
         T = [time.perf_counter()]
-        o = PcaOpts(); lib().fpca_pca_default_opts(C.byref(o)); o.ndim = k
+        o = PcaOpts(); lib().fpca_pca_init_opts(C.byref(o), C.sizeof(PcaOpts), C.sizeof(PcaInfo)); o.ndim = k
         U = np.empty((N, k), order="F"); d = np.empty(k); Px = np.empty((N, k), order="F"); pve = np.empty(k); ms = np.empty((P, 2), order="F")
         info = PcaInfo()
         T.append(time.perf_counter())

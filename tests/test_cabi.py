@@ -43,12 +43,14 @@ def test_drop_in_header_carries_no_lab_bench():
 
 def test_struct_layouts_match_the_header(built_lib):
     """The ctypes mirrors of fpca_pca_opts / fpca_pca_info have the sizes the compiled library reports (struct_size /
-    info_size, written by fpca_pca_default_opts), and the ABI revision is the header's."""
+    info_size), and the ABI revision is the header's.  (fpca_pca_default_opts, which wrote the library's own sizes into whatever
+    struct the caller had, is gone since ABI 4: fpca_pca_init_opts with the CALLER's sizes is the only initialiser.)"""
     import flashpca_amd
     from flashpca_amd import _lib
 
     o = _lib.PcaOpts()
-    flashpca_amd.lib().fpca_pca_default_opts(C.byref(o))
+    assert not hasattr(flashpca_amd.lib(), "fpca_pca_default_opts")
+    flashpca_amd.lib().fpca_pca_init_opts(C.byref(o), C.sizeof(_lib.PcaOpts), C.sizeof(_lib.PcaInfo))
     assert (o.struct_size, o.info_size) == (C.sizeof(_lib.PcaOpts), C.sizeof(_lib.PcaInfo))
     hdr = open(os.path.join(ROOT, "include", "fpca.h")).read()
     assert int(re.search(r"#define FPCA_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION == flashpca_amd.lib().fpca_abi_version()
@@ -141,10 +143,10 @@ def test_no_cpu_fallback(built_lib):
 
 def test_default_opts_match_reference_cli(built_lib):
     import flashpca_amd as fp
-    from flashpca_amd._lib import PcaOpts
+    from flashpca_amd._lib import PcaInfo, PcaOpts
 
     o = PcaOpts()
-    fp.lib().fpca_pca_default_opts(C.byref(o))
+    fp.lib().fpca_pca_init_opts(C.byref(o), C.sizeof(PcaOpts), C.sizeof(PcaInfo))
     # flashpca.cpp:325 (ndim 10), :426 (maxiter 500), :440 (tol 1e-6), :484 (div p), :276 (seed 1)
     assert (o.ndim, o.maxiter, o.tol, o.divisor, o.seed) == (10, 500, 1e-6, 2, 1)
     assert o.max_applies == 0  # no cap beyond the budget --maxiter implies

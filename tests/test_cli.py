@@ -309,6 +309,15 @@ def test_cli_gpus_launcher_failures_do_not_hang(tmp_path, built_lib, golden_dir)
         assert r.returncode == 1 and text in r.stderr, (victim, r.stdout[-800:], r.stderr[-800:])
         assert time.time() - t0 < 60
         assert not os.path.exists(tmp_path / "eigenvalues.txt")
+    # A collective that fails on ONE rank only (forbidden by the hook contract of fpca.h): rank 1 leaves its 3rd
+    # reduce-scatter for the agreement while ranks 0 and 2 are inside that reduce-scatter.  The transport sees ranks in different
+    # calls and fails on all of them, the agreement cannot complete, every rank returns FPCA_ECOMM: the run ends -- promptly, with a
+    # message and a non-zero status, no output files -- instead of hanging or, worse, summing unrelated buffers.
+    t0 = time.time()
+    r = subprocess.run([fp.HOOKS_CLI_PATH, "--bfile", data, "--ndim", "5", "--gpus", "3", "--solver", "rowshard"], cwd=tmp_path, capture_output=True, text=True,
+                       env=dict(os.environ, FPCA_CLI_TEST_TRANSPORT="shm2", FPCA_DEBUG_RS_FAIL="3", FPCA_DEBUG_RS_FAIL_RANK="1"), timeout=120)
+    assert r.returncode == 1 and "not in the same collective" in r.stderr and "abandoned" in r.stderr, (r.stdout[-800:], r.stderr[-1500:])
+    assert time.time() - t0 < 60 and not os.path.exists(tmp_path / "eigenvalues.txt")
     # refused before the fork: ndim limit, .bim / .bed mismatch when a file with SNP row names is asked for
     r = subprocess.run([fp.HOOKS_CLI_PATH, "--bfile", data, "--ndim", "500", "--gpus", "3"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=60)
     assert r.returncode == 1 and "You asked for 500 dimensions, but only 478allowed" in r.stderr

@@ -759,6 +759,29 @@ def test_row_sharded_exchange_failure_demotes_to_the_replicated_solver(fp, monke
         monkeypatch.delenv("FPCA_DEBUG_RS_FAIL", raising=False)
         r2 = c.pca(ndim=k)  # the failed layout is remembered: straight to the replicated solver, no second self-test
         assert r2["info"]["solver_path"] == (3 if fault == "selftest" else 4) and np.max(np.abs(r2["d"] - r0["d"]) / r0["d"]) < 1e-12
+    if fault == "reduce_scatter":
+        # ... and when the ranks CANNOT agree (the collective failed on this rank only, its peers never reach the agreement
+        # -- here: the stream of the agreement's all-reduce looks pending for ever) the step is time-bounded: FPCA_ECOMM after the
+        # limit instead of a hang, the communicator aborted, and every later collective of the context refused at once
+        import time
+
+        monkeypatch.setenv("FPCA_DEBUG_RS_FAIL", "9")
+        monkeypatch.setenv("FPCA_DEBUG_AGREE_STALL", "1")
+        monkeypatch.setenv("FPCA_AGREE_TIMEOUT_S", "1.5")
+        with fp.test_hooks(), fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:
+            c.comm_init_rank(1, 0, fp.Context.comm_unique_id())
+            t0 = time.time()
+            with pytest.raises(Exception, match="did not agree within|never completed"):
+                c.pca(ndim=k)
+            assert 1.0 < time.time() - t0 < 30
+            monkeypatch.delenv("FPCA_DEBUG_RS_FAIL")
+            monkeypatch.delenv("FPCA_DEBUG_AGREE_STALL")
+            with pytest.raises(Exception, match="abandoned"):
+                c.apply_xxt(np.zeros((N, 16)))
+            # a new transport revives the context (fpca_comm_init_rank resets what was known about the old one)
+            c.comm_init_rank(1, 0, fp.Context.comm_unique_id())
+            r3 = c.pca(ndim=k)
+            assert r3["info"]["solver_path"] == 1 and np.max(np.abs(r3["d"] - r0["d"]) / r0["d"]) < 1e-10
     with fp.test_hooks(), fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:  # nothing injected: the sharded path itself
         c.comm_init_rank(1, 0, fp.Context.comm_unique_id())
         r = c.pca(ndim=k, partial_rows=True)
