@@ -300,9 +300,13 @@ int fpca_debug_census(int nwg, uint64_t lds_bytes, uint32_t *out)
 int fpca_debug_mfma_peak(int waves_per_simd, int iters, int pattern, double *tflops)
 {
    return guarded([&] {
-      if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 10 || pattern < 0 || (pattern > 3 && (pattern < 10 || pattern > 13)) || !tflops)
+      if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 10 || pattern < 0 || (pattern > 3 && (pattern < 10 || pattern > 13) && (pattern < 20 || pattern > 25) && pattern < 1000) || !tflops)
          throw Error(FPCA_EINVAL, "bad argument");
-      if (pattern >= 12) // the b = 16 column remainder: 12 = four 32-wide tiles (half of the last one padding), 13 = three + 16x16x64
+      if (pattern >= 1000) // 1000 + 100 LDS reads per MFMA + 10 VALU per MFMA + (1: bursts): v_mfma_f32_16x16x4_f32 with filler instructions
+         *tflops = kern::mfma_valu_mix_tflops((pattern - 1000) % 100 / 10, (pattern & 1) != 0, (pattern - 1000) / 100, waves_per_simd, iters, nullptr);
+      else if (pattern >= 20) // 20 / 21 v_mfma_f32_16x16x4_f32, 22 / 23 v_mfma_f32_32x32x2_f32, 24 / 25 v_mfma_f64_16x16x4_f64: zero / random operands
+         *tflops = kern::mfma_fp_peak_tflops((pattern - 20) / 2, waves_per_simd, iters, (pattern & 1) ? 0x1234567u : 0u, nullptr);
+      else if (pattern >= 12) // the b = 16 column remainder: 12 = four 32-wide tiles (half of the last one padding), 13 = three + 16x16x64
          *tflops = kern::mfma_i8_mix_tops(pattern - 12, iters, nullptr);
       else if (pattern >= 10) // v_mfma_i32_32x32x32_i8 (TOP/s): 10 = zero operands, 11 = random operands
          *tflops = kern::mfma_i8_peak_tops(waves_per_simd, iters, pattern == 11 ? 0x1234567u : 0u, nullptr);

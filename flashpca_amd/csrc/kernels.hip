@@ -17,6 +17,9 @@
 // A wave is 64 lanes; a workgroup is 4 waves (one per SIMD); 2 workgroups per CU hide the staging.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -254,6 +257,28 @@ __device__ __forceinline__ void lds_put2(float *base, int idx, d2 v)
    reinterpret_cast<f2 *>(base)[idx] = (f2){(float)v.x, (float)v.y};
 }
 
+// Table gather of the pair decode with a TWO-instruction address (v_bfe_u32 + v_lshl_add_u32; the compiler's own form is shift, and,
+// add).  Round 6 measured what plain VALU / LDS instructions cost a matrix-instruction stream (profiles/r06_mfma_valu_mix.txt):
+// ~0.6 issue slots of 4 cycles each -- of a 32-cycle fp32 MFMA -- even with four waves per SIMD taking turns, and ~1.2 more per switch
+// from MFMAs to other instructions; the FP kernels are bound by exactly that, not by power or memory (1,300 W, 2.38 GHz).
+// base = LDS byte address of the lane's row 0 of the table; entry (nibble at bit `off` of w) is SH bytes-log2 apart.
+template <typename PT, int SH, int OFF, int IMM>
+__device__ __forceinline__ PT lds_pair_gather(uint32_t base, uint32_t w)
+{
+   uint32_t a;
+   asm("v_bfe_u32 %0, %1, %2, 4\n\tv_lshl_add_u32 %0, %0, %3, %4" : "=&v"(a) : "v"(w), "n"(OFF), "n"(SH), "v"(base));
+   return *reinterpret_cast<const __attribute__((address_space(3))) PT *>((uintptr_t)(a + IMM));
+}
+template <class F, int... I>
+__device__ __forceinline__ void sfor_impl(F &&f, std::integer_sequence<int, I...>)
+{
+   (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor(F &&f)
+{
+   sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
 #define FPCA_ENV_INT(name, dflt) ((FPCA_TEST_ENV(name) && *FPCA_TEST_ENV(name)) ? atoi(FPCA_TEST_ENV(name)) : (dflt))
 
 // ------------------------------------------------------------------------------------------------
@@ -321,10 +346,16 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
          dst[48] = (RT)e23.y;
       }
    }
+   // SUPER-CHUNKS (round 6; KC = 128 only): a lane's packed words of TWO consecutive chunks are one 16-byte load -- lane group kq owns
+   // bytes [16 kq, 16 kq + 16) of the row's 64-byte segment -- i.e. half the load instructions, each touching 16 rows x 64 B instead
+   // of 16 x 32 B (the packed-word loads were 0.7 ms of the 13.3 ms fp32 launch, profiles/r06_fp_k2_ablation.txt).  Sub-chunk s of
+   // super-chunk S then holds, for lane group kq, samples S 2KC + kq KC/2 + s KC/4 + [0, KC/4): the B tile of a sub-chunk is four
+   // 32-row segments of B instead of one contiguous piece, still 4 KB each.
+   constexpr int SUP = (NW == 2) ? 2 : 1;
+   constexpr int LB = SUP * KC / 16; // bytes per lane per super-chunk
    const uint8_t *rowp[MT];
 #pragma unroll
-   for (int m = 0; m < MT; m++)
-      rowp[m] = packed + (snp0 + m * 16 + li) * pitch + kq * (KC / 16); // lane group kq owns samples kq*KC/4 .. +KC/4
+   for (int m = 0; m < MT; m++) rowp[m] = packed + (snp0 + m * 16 + li) * pitch + kq * LB;
 
    acc_t acc[MT][NT];
    d4 acc64[MIXED ? MT : 1][MIXED ? NT : 1];
@@ -336,98 +367,158 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
          if (MIXED) acc64[m][nt] = (d4){0.0, 0.0, 0.0, 0.0};
       }
 
-   uint32_t pk_next[MT][NW];
+   uint32_t pk_next[MT][NW * SUP];
    d2 breg[NLOAD];
-#define FPCA_XTB_ISSUE(cc)                                                                                  \
-   {                                                                                                         \
-      _Pragma("unroll") for (int m = 0; m < MT; m++)                                                         \
-      {                                                                                                      \
-         const uint32_t *pp = reinterpret_cast<const uint32_t *>(rowp[m] + (size_t)(cc) * (KC / 4));         \
-         _Pragma("unroll") for (int h = 0; h < NW; h++) pk_next[m][h] = pp[h];                               \
-      }                                                                                                      \
-      const d2 *src = reinterpret_cast<const d2 *>(B + (size_t)(cc) * KC * b);                               \
-      _Pragma("unroll") for (int r = 0; r < NLOAD; r++) breg[r] = src[tid + 256 * r];                        \
+   auto issue_p = [&](int sc) { // packed words of super-chunk sc
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+         const uint32_t *pp = reinterpret_cast<const uint32_t *>(rowp[m] + (size_t)sc * (SUP * KC / 4));
+         if constexpr (NW * SUP == 4) {
+            const u4 w = *reinterpret_cast<const u4 *>(pp);
+            pk_next[m][0] = w.x, pk_next[m][1] = w.y, pk_next[m][2] = w.z, pk_next[m][3] = w.w;
+         } else {
+#pragma unroll
+            for (int h = 0; h < NW * SUP; h++) pk_next[m][h] = pp[h];
+         }
+      }
+   };
+   auto issue_b = [&](int cc) { // B tile of chunk cc (sub-chunk cc % SUP of super-chunk cc / SUP)
+      if constexpr (SUP == 1) {
+         const d2 *src = reinterpret_cast<const d2 *>(B + (size_t)cc * KC * b);
+#pragma unroll
+         for (int r = 0; r < NLOAD; r++) breg[r] = src[tid + 256 * r];
+      } else {
+         constexpr int RPR = 512 / b; // tile rows per 256-thread pass; a pass stays inside one 32-row segment
+         static_assert((KC / 4) % RPR == 0, "B tile passes and lane-group segments");
+         const size_t row0 = (size_t)(cc / SUP) * (SUP * KC) + (size_t)(cc % SUP) * (KC / 4);
+#pragma unroll
+         for (int r = 0; r < NLOAD; r++) {
+            const int k0 = r * RPR; // first tile row of this pass: lane group k0 / (KC/4), row k0 % (KC/4) of its segment
+            const d2 *src = reinterpret_cast<const d2 *>(B + (row0 + (size_t)(k0 / (KC / 4)) * (SUP * KC / 4) + k0 % (KC / 4)) * b);
+            breg[r] = src[tid];
+         }
+      }
+   };
+   if (c_begin < c_end) {
+      issue_p(c_begin / SUP);
+      issue_b(c_begin);
    }
-   if (c_begin < c_end) FPCA_XTB_ISSUE(c_begin);
 
    const RT *sB_lane = sB + (size_t)((KC / 4) * kq) * b + li;
    const RT *sLut_lane = sLut + (size_t)(wave * MT) * 64 + li;        // m-tile m, code c: sLut_lane[m * 64 + c * 16]
    const pair_t *sLutP_lane = sLutP + (size_t)(wave * MT) * 256 + li; // PAIR: m-tile m, pair index i: sLutP_lane[m * 256 + i * 16]
 
-   for (int c = c_begin; c < c_end; c++) {
-      __syncthreads(); // every wave has finished reading the previous B tile
+   uint32_t pk[MT][NW * SUP];
+   for (int c0 = c_begin; c0 < c_end; c0 += SUP) { // (c_begin and c_end are multiples of SUP: launch_xt_b)
+      sfor<SUP>([&](auto subc) {
+         constexpr int sub = decltype(subc)::value;
+         const int c = c0 + sub;
+         __syncthreads(); // every wave has finished reading the previous B tile
 #pragma unroll
-      for (int r = 0; r < NLOAD; r++) lds_put2(sB, tid + 256 * r, breg[r]);
-      uint32_t pk[MT][NW];
-#pragma unroll
-      for (int m = 0; m < MT; m++)
-#pragma unroll
-         for (int h = 0; h < NW; h++) pk[m][h] = pk_next[m][h];
-      __syncthreads();
-      if (c + 1 < c_end) FPCA_XTB_ISSUE(c + 1);
-      // k-step t + 1's operands (B fragment, MT table gathers) are read while step t's MFMAs run (see K3); PAIR: two k-steps at a time
-      if constexpr (PAIR) {
-         RT av[2][2][MT], bv[2][2][NT];
-#define FPCA_XTB_FETCH2(tp_, slot_)                                                                                             \
-   {                                                                                                                            \
-      _Pragma("unroll") for (int w_ = 0; w_ < 2; w_++)                                                                          \
-         _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bv[slot_][w_][nt] = sB_lane[(size_t)(2 * (tp_) + w_) * b + nt * 16]; \
-      _Pragma("unroll") for (int m = 0; m < MT; m++)                                                                            \
-      {                                                                                                                         \
-         const pair_t pr_ = sLutP_lane[m * 256 + (((pk[m][(2 * (tp_)) / 16] >> (2 * ((2 * (tp_)) % 16))) & 15u) << 4)];         \
-         av[slot_][0][m] = pr_.x;                                                                                               \
-         av[slot_][1][m] = pr_.y;                                                                                               \
-      }                                                                                                                         \
-   }
-         FPCA_XTB_FETCH2(0, 0);
-#pragma unroll
-         for (int tp = 0; tp < 8 * NW; tp++) {
-            if (tp + 1 < 8 * NW) FPCA_XTB_FETCH2(tp + 1, (tp + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int w = 0; w < 2; w++)
-#pragma unroll
-               for (int m = 0; m < MT; m++)
-#pragma unroll
-                  for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(av[tp & 1][w][m], bv[tp & 1][w][nt], acc[m][nt]);
-            __builtin_amdgcn_sched_barrier(0);
-         }
-#undef FPCA_XTB_FETCH2
-      } else {
-         RT av[2][MT], bv[2][NT];
-#define FPCA_XTB_FETCH(tt_, slot_)                                                                                              \
-   {                                                                                                                            \
-      _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bv[slot_][nt] = sB_lane[(size_t)(tt_) * b + nt * 16];                   \
-      _Pragma("unroll") for (int m = 0; m < MT; m++) av[slot_][m] = sLut_lane[m * 64 + (((pk[m][(tt_) / 16] >> (2 * ((tt_) % 16))) & 3u) << 4)]; \
-   }
-         FPCA_XTB_FETCH(0, 0);
-#pragma unroll
-         for (int tt = 0; tt < 16 * NW; tt++) {
-            if (tt + 1 < 16 * NW) FPCA_XTB_FETCH(tt + 1, (tt + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
+         for (int r = 0; r < NLOAD; r++) lds_put2(sB, tid + 256 * r, breg[r]);
+         if constexpr (sub == 0) {
 #pragma unroll
             for (int m = 0; m < MT; m++)
 #pragma unroll
-               for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(av[tt & 1][m], bv[tt & 1][nt], acc[m][nt]);
-            __builtin_amdgcn_sched_barrier(0);
+               for (int h = 0; h < NW * SUP; h++) pk[m][h] = pk_next[m][h];
          }
-#undef FPCA_XTB_FETCH
+         __syncthreads();
+         if (c + 1 < c_end) issue_b(c + 1);
+         if (sub == SUP - 1 && c0 + SUP < c_end) issue_p(c0 / SUP + 1);
+         constexpr int H0 = sub * NW; // first packed dword of this sub-chunk
+         // k-step t + 1's operands (B fragment, MT table gathers) are read while step t's MFMAs run (see K3); PAIR: two k-steps at a time
+         if constexpr (PAIR) {
+            // (round 6) gathers first, the B fragment LAST: the first MFMA of a burst needs the B value, so ONE s_waitcnt -- for the
+            // youngest load of its batch -- precedes the burst and none interrupts it (LDS answers in order); two-instruction addresses
+            RT av[2][2][MT], bv[2][2][NT];
+            constexpr int PSH = sizeof(pair_t) == 8 ? 7 : 8; // log2 bytes between the rows of two pair indices: 16 pairs per row
+            const uint32_t lut_base = (uint32_t)(size_t)(const __attribute__((address_space(3))) pair_t *)sLutP_lane;
+            // FPCA_XTB_SPLIT: the fetch group of a pair of k-steps in two halves, one before each half of its 2 MT MFMAs (shorter
+            // groups: 13.35 -> 13.2 ms at fp32 / 16 columns, like K3's; profiles/r06_fp_kernels.txt)
+#ifndef FPCA_XTB_SPLIT
+#define FPCA_XTB_SPLIT 1
+#endif
+            auto fetch2 = [&](auto tpc, auto slotc, auto halfc) {
+               constexpr int tp_ = decltype(tpc)::value, slot_ = decltype(slotc)::value, half_ = decltype(halfc)::value; // half_: 0 / 1 = first / second half of the group, 2 = all
+               constexpr int M0 = half_ == 1 ? MT / 2 : 0, M1 = half_ == 0 ? MT / 2 : MT;
+#ifndef FPCA_XTB_BFIRST
+#define FPCA_XTB_BFIRST 0
+#endif
+               if constexpr (FPCA_XTB_BFIRST && half_ != 1) {
+#pragma unroll
+                  for (int w_ = 0; w_ < 2; w_++)
+#pragma unroll
+                     for (int nt = 0; nt < NT; nt++) bv[slot_][w_][nt] = sB_lane[(size_t)(2 * tp_ + w_) * b + nt * 16];
+               }
+               sfor<M1 - M0>([&](auto mc) {
+                  constexpr int m = M0 + decltype(mc)::value;
+                  const pair_t pr_ = lds_pair_gather<pair_t, PSH, (4 * tp_) % 32, m * 256 * (int)sizeof(pair_t)>(lut_base, pk[m][H0 + (2 * tp_) / 16]);
+                  av[slot_][0][m] = pr_.x;
+                  av[slot_][1][m] = pr_.y;
+               });
+               if constexpr (!FPCA_XTB_BFIRST && half_ != 0) {
+#pragma unroll
+                  for (int w_ = 0; w_ < 2; w_++)
+#pragma unroll
+                     for (int nt = 0; nt < NT; nt++) bv[slot_][w_][nt] = sB_lane[(size_t)(2 * tp_ + w_) * b + nt * 16];
+               }
+            };
+            fetch2(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            sfor<8 * NW>([&](auto tpc) {
+               constexpr int tp = decltype(tpc)::value;
+               if constexpr (tp + 1 < 8 * NW)
+                  fetch2(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, (tp + 1) & 1>{}, std::integral_constant<int, FPCA_XTB_SPLIT ? 0 : 2>{});
+               __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+               for (int w = 0; w < 2; w++) {
+#pragma unroll
+                  for (int m = 0; m < MT; m++)
+#pragma unroll
+                     for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(av[tp & 1][w][m], bv[tp & 1][w][nt], acc[m][nt]);
+                  if (FPCA_XTB_SPLIT && w == 0) {
+                     __builtin_amdgcn_sched_barrier(0);
+                     if constexpr (tp + 1 < 8 * NW)
+                        fetch2(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, (tp + 1) & 1>{}, std::integral_constant<int, 1>{});
+                     __builtin_amdgcn_sched_barrier(0);
+                  }
+               }
+               __builtin_amdgcn_sched_barrier(0);
+            });
+         } else {
+            RT av[2][MT], bv[2][NT];
+#define FPCA_XTB_FETCH(tt_, slot_)                                                                                              \
+      {                                                                                                                            \
+         _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bv[slot_][nt] = sB_lane[(size_t)(tt_) * b + nt * 16];                   \
+         _Pragma("unroll") for (int m = 0; m < MT; m++) av[slot_][m] = sLut_lane[m * 64 + (((pk[m][H0 + (tt_) / 16] >> (2 * ((tt_) % 16))) & 3u) << 4)]; \
       }
-      // fold the fp32 partial sums into the fp64 accumulators every FOLD_EVERY chunks (and at the end): fp32 sums then run over at most
-      // 512 samples whatever N is -- the rounding error does not grow with N -- while the fold (4 converts + 4 fp64 adds per
-      // accumulator register, 5 % of the kernel when made every chunk; round 5) stays off the MFMA-bound path
-      if (MIXED && ((c & (FOLD_EVERY - 1)) == FOLD_EVERY - 1 || c + 1 == c_end)) {
+            FPCA_XTB_FETCH(0, 0);
 #pragma unroll
-         for (int m = 0; m < MT; m++)
+            for (int tt = 0; tt < 16 * NW; tt++) {
+               if (tt + 1 < 16 * NW) FPCA_XTB_FETCH(tt + 1, (tt + 1) & 1);
+               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
+               for (int m = 0; m < MT; m++)
 #pragma unroll
-               for (int r = 0; r < 4; r++) acc64[m][nt][r] += (double)acc[m][nt][r];
-               acc[m][nt] = (acc_t){0, 0, 0, 0};
+                  for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(av[tt & 1][m], bv[tt & 1][nt], acc[m][nt]);
+               __builtin_amdgcn_sched_barrier(0);
             }
-      }
+#undef FPCA_XTB_FETCH
+         }
+         // fold the fp32 partial sums into the fp64 accumulators every FOLD_EVERY chunks (and at the end): fp32 sums then run over at most
+         // 512 samples whatever N is -- the rounding error does not grow with N -- while the fold (4 converts + 4 fp64 adds per
+         // accumulator register, 5 % of the kernel when made every chunk; round 5) stays off the MFMA-bound path
+         if (MIXED && ((c & (FOLD_EVERY - 1)) == FOLD_EVERY - 1 || c + 1 == c_end)) {
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+               for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+                  for (int r = 0; r < 4; r++) acc64[m][nt][r] += (double)acc[m][nt][r];
+                  acc[m][nt] = (acc_t){0, 0, 0, 0};
+               }
+         }
+         });
    }
-#undef FPCA_XTB_ISSUE
 
    double *Tout = Tpart + (size_t)blockIdx.y * P_pad * b;
 #pragma unroll
@@ -496,7 +587,8 @@ static void launch_xt_b(const uint8_t *packed, size_t pitch, const double *lut, 
 {
    constexpr int KC = XtCfg<NT>::KC;
    const int chunks_total = (int)(N_pad / KC);
-   const int cps = (chunks_total + nsplit - 1) / nsplit;
+   int cps = (chunks_total + nsplit - 1) / nsplit;
+   if (KC == 128) cps += cps & 1; // super-chunks of two (k_xt_b): every split starts on an even chunk (N_pad is a multiple of 512)
    constexpr int MT = XtMt<RT, NT>::MT;
    const size_t smem = ((size_t)KC * 16 * NT + 64 * MT * (NT == 1 ? 32 : 4)) * sizeof(RT); // B tile + table (16 columns: [SNP][16] pairs)
    static bool attr_set = false;
@@ -530,6 +622,12 @@ void xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *
 #undef FPCA_CASE
 }
 
+// K3's fetch groups: 1 = round 5's (compiler-formed gather addresses, T fragment first, one wait per gather), 0 = round 6's
+// experiment (two-instruction addresses, T fragment last, one wait per group).  Measured on one box, fp32, 16 columns, 500,000 x
+// 100,000: 13.25 against 13.41 ms -- the staged waits let the first MFMA of a group start a gather earlier; round 5's stay.
+#ifndef FPCA_X_FETCH_R5
+#define FPCA_X_FETCH_R5 1
+#endif
 // ------------------------------------------------------------------------------------------------
 // K3 x_t:  Y[s][c] = sum_snp X[s][snp] T[snp][c]
 //   workgroup = 64*MT samples x all b columns, wave = 16*MT samples (MT m-tiles), K = SNPs.
@@ -637,6 +735,7 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
       // k-step t + 1's operands -- the T fragment and the MT table gathers -- are read while step t's MFMAs run: left to itself
       // the compiler funnels every gather through one register pair (ds_read, s_waitcnt 0, v_mfma, MT times over), and a 64-cycle
       // MFMA behind a ~100-cycle LDS round trip kept the pipe 74 % busy with four waves per SIMD taking turns (rounds 1-4)
+#if FPCA_X_FETCH_R5
       RT av[2][MT], tv[2][NT];
 #define FPCA_XT_FETCH(t_, slot_)                                                                                    \
    {                                                                                                                \
@@ -662,6 +761,50 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
          __builtin_amdgcn_sched_barrier(0);
       }
 #undef FPCA_XT_FETCH
+#else
+      // (round 6) gather addresses in two instructions, the T fragment read LAST so that a single s_waitcnt precedes the MFMAs of a
+      // k-step.  GS = k-steps per fetch group: measured at 500,000 x 100,000, fp32, 16 columns (profiles/r06_fp_kernels.txt): groups of
+      // 4 / 8 / 16 MFMAs 13.37 / 13.59 / 14.42 ms -- with four waves per SIMD taking turns the SHORT groups win (the opposite of what a
+      // single wave's instruction stream suggests, profiles/r06_mfma_valu_mix.txt), so one k-step per group stays
+#ifndef FPCA_X_GS
+#define FPCA_X_GS 4
+#endif
+      constexpr int GS = (MT * NT >= FPCA_X_GS) ? 1 : FPCA_X_GS / (MT * NT); // k-steps per group
+      constexpr int NGRP = KCX / 4 / GS;
+      static_assert(KCX / 4 % GS == 0, "k-step groups");
+      RT av[2][GS][MT], tv[2][GS][NT];
+      constexpr int LSH = sizeof(pair_t) == 8 ? 3 : 4; // log2 bytes of a pair
+      const uint32_t sl_base = (uint32_t)(size_t)(const __attribute__((address_space(3))) pair_t *)sL_lane;
+      auto fetch = [&](auto gc, auto slotc) {
+         constexpr int g_ = decltype(gc)::value, slot_ = decltype(slotc)::value;
+         sfor<GS>([&](auto uc) {
+            constexpr int u = decltype(uc)::value, t_ = g_ * GS + u;
+            sfor<MT / 2>([&](auto mc) {
+               constexpr int m = 2 * decltype(mc)::value;
+               const pair_t pr_ = lds_pair_gather<pair_t, LSH, 2 * m, 4 * t_ * 16 * (int)sizeof(pair_t)>(sl_base, hh[t_]);
+               av[slot_][u][m] = pr_.x;
+               av[slot_][u][m + 1] = pr_.y;
+            });
+         });
+#pragma unroll
+         for (int u = 0; u < GS; u++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) tv[slot_][u][nt] = sT_lane[(size_t)(4 * (g_ * GS + u)) * b + nt * 16];
+      };
+      fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      sfor<NGRP>([&](auto gc) {
+         constexpr int g = decltype(gc)::value;
+         if constexpr (g + 1 < NGRP) fetch(std::integral_constant<int, g + 1>{}, std::integral_constant<int, (g + 1) & 1>{});
+         __builtin_amdgcn_sched_barrier(0); // (the fetch group stays ahead of the MFMA group it does not feed)
+#pragma unroll
+         for (int u = 0; u < GS; u++)
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+               for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(av[g & 1][u][m], tv[g & 1][u][nt], acc[m][nt]);
+         __builtin_amdgcn_sched_barrier(0);
+      });
+#endif
       if (MIXED && ((c & (FOLD_EVERY - 1)) == FOLD_EVERY - 1 || c + 1 == c_end)) { // (as in K2: fp32 sums over at most 256 SNPs)
 #pragma unroll
          for (int m = 0; m < MT; m++)
@@ -690,12 +833,15 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
 
 // shape of K3 per (arithmetic, block width): fp64 -> 8 m-tiles for b <= 32 else 4, 64-SNP chunks; the mixed fp32 mode
 // carries fp32 + fp64 accumulators, so it uses 4 m-tiles and, for b >= 48, 32-SNP chunks (fewer prefetch registers)
+#ifndef FPCA_X_MT32
+#define FPCA_X_MT32 4 // m-tiles per wave of the fp32 K3 at 16 columns
+#endif
 template <typename RT, int NT> struct XCfg {
    static constexpr bool MIXED = sizeof(RT) == 4;
-   static constexpr int MT = MIXED ? 4 : (NT <= 2 ? 8 : 4);
+   static constexpr int MT = MIXED ? (NT == 1 ? FPCA_X_MT32 : 4) : (NT <= 2 ? 8 : 4);
    static constexpr int KCX = (MIXED && NT >= 3) ? 32 : 64;
 };
-static inline int x_t_mt(int b, bool fp32) { return fp32 ? 4 : (b <= 32 ? 8 : 4); }
+static inline int x_t_mt(int b, bool fp32) { return fp32 ? (b == 16 ? FPCA_X_MT32 : 4) : (b <= 32 ? 8 : 4); }
 static inline int x_t_kc(int b, bool fp32) { return (fp32 && b >= 48) ? 32 : 64; }
 
 int x_t_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32)
@@ -1791,6 +1937,190 @@ double mfma_peak_tflops(int waves_per_simd, int iters, int pattern, hipStream_t 
    (void)hipEventDestroy(e1);
    (void)hipFree(d);
    const double flops = (double)blocks * 4 /*waves*/ * (double)iters * 8 * 2048.0;
+   return flops / (ms * 1e-3) / 1e12;
+}
+
+// The same for the other matrix instructions the FP kernels could run on, with compiler-scheduled intrinsics (8 independent
+// accumulators, 4 A x 2 B operands in GEMM order, no memory traffic): KIND 0 v_mfma_f32_16x16x4_f32, 1 v_mfma_f32_32x32x2_f32,
+// 2 v_mfma_f64_16x16x4_f64.  fill = 0: zero operands (the issue-limited ceiling); else pseudo-random operands in (-1, 1) -- the
+// multipliers toggle like the real kernels' and the package power cap decides (round 6: the ceiling `fp32_frac` is read against).
+typedef float v16f __attribute__((ext_vector_type(16)));
+template <int KIND>
+__global__ __launch_bounds__(256, 1) void k_mfma_fp_peak(float *out, int iters, uint32_t fill)
+{
+   uint32_t h = (threadIdx.x + 1u) * 2654435761u ^ fill;
+   auto rnd = [&]() {
+      h = h * 1664525u + 1013904223u;
+      return fill ? (float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f : 0.0f;
+   };
+   if constexpr (KIND == 0) {
+      float a[4], b[2];
+      for (float &x : a) x = rnd();
+      for (float &x : b) x = rnd();
+      f4 acc[4][2];
+      for (auto &r : acc)
+         for (auto &x : r) x = (f4){0, 0, 0, 0};
+      for (int it = 0; it < iters; it++) {
+#pragma unroll
+         for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      float sum = 0;
+      for (auto &r : acc)
+         for (auto &x : r) sum += x[0] + x[1] + x[2] + x[3];
+      if (iters < 0) out[threadIdx.x] = sum;
+   } else if constexpr (KIND == 1) {
+      float a[2], b[2];
+      for (float &x : a) x = rnd();
+      for (float &x : b) x = rnd();
+      v16f acc[2][2];
+      for (auto &r : acc)
+         for (auto &x : r)
+            for (int q = 0; q < 16; q++) x[q] = 0;
+      for (int it = 0; it < iters; it++) {
+#pragma unroll
+         for (int rep = 0; rep < 2; rep++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+               for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      float sum = 0;
+      for (auto &r : acc)
+         for (auto &x : r)
+            for (int q = 0; q < 16; q++) sum += x[q];
+      if (iters < 0) out[threadIdx.x] = sum;
+   } else {
+      double a[4], b[2];
+      for (double &x : a) x = rnd();
+      for (double &x : b) x = rnd();
+      d4 acc[4][2];
+      for (auto &r : acc)
+         for (auto &x : r) x = (d4){0, 0, 0, 0};
+      for (int it = 0; it < iters; it++) {
+#pragma unroll
+         for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      double sum = 0;
+      for (auto &r : acc)
+         for (auto &x : r) sum += x[0] + x[1] + x[2] + x[3];
+      if (iters < 0) out[threadIdx.x] = (float)sum;
+   }
+}
+
+// How much matrix-pipe time do plain VALU instructions cost?  8 independent v_mfma_f32_16x16x4_f32 (32 cycles each) per iteration with
+// VPM independent v_add_u32 per MFMA, either interleaved (one MFMA, VPM adds, ...) or in bursts (8 MFMAs, then 8 VPM adds: the shape
+// of the GEMM kernels' software-pipelined steps).  LDSR > 0: additionally LDSR conflict-free ds_read_b64 per MFMA whose results are
+// waited for one iteration later.  Returns the MFMA rate in TFLOP/s (scripts/mfma_valu_mix.py).
+template <int VPM, bool BURST, int LDSR>
+__global__ __launch_bounds__(256, 1) void k_mfma_valu_mix(float *out, int iters)
+{
+   __shared__ float lds[4096];
+   for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = 0.f;
+   __syncthreads();
+   float a[4], b[2];
+   for (int i = 0; i < 4; i++) a[i] = 1.0f + i + threadIdx.x * 1e-3f;
+   for (int i = 0; i < 2; i++) b[i] = 0.5f + i;
+   f4 acc[8];
+   for (auto &x : acc) x = (f4){0, 0, 0, 0};
+   uint32_t v[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+   f2 ld[8];
+   for (auto &x : ld) x = (f2){0, 0};
+   const uint32_t laddr = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)lds + (threadIdx.x & 63) * 8;
+   for (int it = 0; it < iters; it++) {
+      if constexpr (BURST) {
+#pragma unroll
+         for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i & 3] + ld[i].x, b[i >> 2], acc[i], 0, 0, 0);
+         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+         for (int i = 0; i < 8 * LDSR; i++) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ld[i & 7]) : "v"(laddr), "n"((i & 7) * 512));
+#pragma unroll
+         for (int i = 0; i < 8 * VPM; i++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[i & 7]) : "v"(v[(i + 1) & 7]));
+         if constexpr (LDSR > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+         __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+         for (int i = 0; i < 8; i++) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i & 3] + ld[i].x, b[i >> 2], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < LDSR; r++) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ld[(i + 4) & 7]) : "v"(laddr), "n"(((i + 4) & 7) * 512));
+#pragma unroll
+            for (int j = 0; j < VPM; j++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[(i + j) & 7]) : "v"(v[(i + j + 1) & 7]));
+            if constexpr (LDSR > 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(LDSR * 3) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+         }
+      }
+   }
+   float sum = 0;
+   for (auto &x : acc) sum += x[0] + x[1] + x[2] + x[3];
+   for (auto x : v) sum += (float)x;
+   if (iters < 0) out[threadIdx.x] = sum;
+}
+
+double mfma_valu_mix_tflops(int vpm, bool burst, int ldsr, int waves_per_simd, int iters, hipStream_t stream)
+{
+   float *d = nullptr;
+   if (hipMalloc(&d, 1024) != hipSuccess) throw Error(-3, "hipMalloc failed");
+   const int blocks = 256 * waves_per_simd;
+   hipEvent_t e0, e1;
+   (void)hipEventCreate(&e0);
+   (void)hipEventCreate(&e1);
+   auto go = [&](int n) {
+#define FPCA_MIX(V_, B_, L_)                                                                                  \
+   if (vpm == V_ && burst == B_ && ldsr == L_) {                                                             \
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mfma_valu_mix<V_, B_, L_>), dim3(blocks), dim3(256), 0, stream, d, n); \
+      return;                                                                                                \
+   }
+      FPCA_MIX(0, false, 0) FPCA_MIX(1, false, 0) FPCA_MIX(2, false, 0) FPCA_MIX(3, false, 0) FPCA_MIX(4, false, 0) FPCA_MIX(6, false, 0) FPCA_MIX(8, false, 0)
+      FPCA_MIX(1, true, 0) FPCA_MIX(2, true, 0) FPCA_MIX(3, true, 0) FPCA_MIX(4, true, 0) FPCA_MIX(6, true, 0) FPCA_MIX(8, true, 0)
+      FPCA_MIX(0, false, 1) FPCA_MIX(2, false, 1) FPCA_MIX(3, false, 1) FPCA_MIX(0, true, 1) FPCA_MIX(2, true, 1) FPCA_MIX(3, true, 1)
+#undef FPCA_MIX
+      throw Error(-1, "mfma_valu_mix: variant not instantiated");
+   };
+   go(iters / 10);
+   (void)hipEventRecord(e0, stream);
+   go(iters);
+   (void)hipEventRecord(e1, stream);
+   (void)hipEventSynchronize(e1);
+   float ms = 0;
+   (void)hipEventElapsedTime(&ms, e0, e1);
+   (void)hipEventDestroy(e0);
+   (void)hipEventDestroy(e1);
+   (void)hipFree(d);
+   return (double)blocks * 4 * (double)iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
+}
+
+double mfma_fp_peak_tflops(int kind, int waves_per_simd, int iters, uint32_t fill, hipStream_t stream)
+{
+   float *d = nullptr;
+   if (hipMalloc(&d, 1024) != hipSuccess) throw Error(-3, "hipMalloc failed");
+   const int blocks = 256 * waves_per_simd;
+   hipEvent_t e0, e1;
+   (void)hipEventCreate(&e0);
+   (void)hipEventCreate(&e1);
+   auto go = [&](int n) {
+      if (kind == 0)
+         hipLaunchKernelGGL(k_mfma_fp_peak<0>, dim3(blocks), dim3(256), 0, stream, d, n, fill);
+      else if (kind == 1)
+         hipLaunchKernelGGL(k_mfma_fp_peak<1>, dim3(blocks), dim3(256), 0, stream, d, n, fill);
+      else
+         hipLaunchKernelGGL(k_mfma_fp_peak<2>, dim3(blocks), dim3(256), 0, stream, d, n, fill);
+   };
+   go(iters / 10);
+   (void)hipEventRecord(e0, stream);
+   go(iters);
+   (void)hipEventRecord(e1, stream);
+   (void)hipEventSynchronize(e1);
+   float ms = 0;
+   (void)hipEventElapsedTime(&ms, e0, e1);
+   (void)hipEventDestroy(e0);
+   (void)hipEventDestroy(e1);
+   (void)hipFree(d);
+   const double flops = (double)blocks * 4 * (double)iters * 8 * (kind == 1 ? 4096.0 : 2048.0);
    return flops / (ms * 1e-3) / 1e12;
 }
 

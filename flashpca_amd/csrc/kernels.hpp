@@ -137,6 +137,8 @@ void i8_rowscales(const double *mean, const double *sd, uint64_t P_g, uint64_t P
 void transpose_packed(const uint8_t *in, size_t pitch_in, uint64_t N_pad, uint64_t P_pad, uint8_t *out, size_t pitch_out,
                       hipStream_t stream);
 double mfma_i8_peak_tops(int waves_per_simd, int iters, uint32_t fill, hipStream_t stream);
+double mfma_valu_mix_tflops(int vpm, bool burst, int ldsr, int waves_per_simd, int iters, hipStream_t stream);
+double mfma_fp_peak_tflops(int kind, int waves_per_simd, int iters, uint32_t fill, hipStream_t stream); // 0 f32 16x16x4, 1 f32 32x32x2, 2 f64 16x16x4
 double mfma_i8_mix_tops(int mix, int iters, hipStream_t stream);
 void mfma_i8_probe(const int8_t *A, const int8_t *Bt, int *D, hipStream_t stream);
 

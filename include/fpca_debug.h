@@ -50,7 +50,9 @@ int fpca_debug_mfma_i8_probe(const int8_t *A, const int8_t *Bt, int32_t *D);
 /* diagnostic: sustained rate (TFLOP/s) of a pure v_mfma_f64_16x16x4_f64 stream with `waves_per_simd` (1..8) resident
  * waves per SIMD and no memory traffic; pattern 0..3 selects the operand-register sharing pattern (kernels.hip).  The
  * practical ceiling to read the GEMM kernels' roofline fraction against (72-74 TFLOP/s at 2 waves/SIMD vs 78.6 datasheet).
- * pattern 10 / 11: v_mfma_i32_32x32x32_i8 in TOP/s with zero / pseudo-random operands. */
+ * pattern 10 / 11: v_mfma_i32_32x32x32_i8 in TOP/s with zero / pseudo-random operands.
+ * pattern 20 / 21: v_mfma_f32_16x16x4_f32, 22 / 23: v_mfma_f32_32x32x2_f32, 24 / 25: v_mfma_f64_16x16x4_f64 -- zero / pseudo-random
+ * operands (compiler-scheduled intrinsics): with random operands the package power cap sets the ceiling. */
 int fpca_debug_mfma_peak(int waves_per_simd, int iters, int pattern, double *tflops);
 /* diagnostic (tests/test_gpu_kernels.py): the K4 helpers the eigensolver runs on its HBM-resident basis, on caller data and
  * through the very backend object the solver drives (HipBackend::gram incl. its split-K plane reduction, HipBackend::gemm).
