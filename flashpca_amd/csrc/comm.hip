@@ -67,6 +67,34 @@ void fpca_ctx::all_gather(const RowShard &sh, const double *slice, double *full,
    allreduce(full, (uint64_t)sh.full_rows() * b, s);
 }
 
+void fpca_ctx::all_gather_bytes(const RowShard &sh, const int8_t *slice, int8_t *full, size_t bytes_per_row, hipStream_t s)
+{
+   refuse_dead(this);
+   if (!native_collectives() || bytes_per_row % 8) throw Error(FPCA_ECOMM, "all_gather_bytes needs a transport with a real all-gather");
+   const size_t piece = (size_t)sh.plen * bytes_per_row, chunk = (size_t)sh.L * bytes_per_row;
+   for (int c = 0; c < sh.nch; c++) {
+      if (ag_fn) { // (the caller's all-gather moves doubles: any 8-byte words travel unchanged)
+         if (ag_fn(coll_user, reinterpret_cast<const double *>(slice + c * piece), reinterpret_cast<double *>(full + c * chunk), piece / 8, (void *)s) != 0)
+            throw Error(FPCA_ECOMM, "caller-supplied all-gather failed");
+      } else
+         RCCL_CHECK(rccl().AllGather(slice + c * piece, full + c * chunk, piece, ncclInt8, comm, s));
+      coll_calls++;
+      coll_bytes += piece;
+   }
+}
+
+void fpca_ctx::all_gather_small(const double *mine, double *all, size_t count, hipStream_t s)
+{
+   refuse_dead(this);
+   if (!native_collectives()) throw Error(FPCA_ECOMM, "all_gather_small needs a transport with a real all-gather");
+   if (ag_fn) {
+      if (ag_fn(coll_user, mine, all, count, (void *)s) != 0) throw Error(FPCA_ECOMM, "caller-supplied all-gather failed");
+   } else
+      RCCL_CHECK(rccl().AllGather(mine, all, count, ncclDouble, comm, s));
+   coll_calls++;
+   coll_bytes += count * sizeof(double);
+}
+
 void fpca_ctx::reduce_scatter(const RowShard &sh, double *full, double *slice, int b, hipStream_t s, int only_chunk)
 {
    refuse_dead(this);

@@ -135,7 +135,7 @@ void ctx_free(fpca_ctx *c)
    void *ptrs[] = {c->d_Xd, c->d_packed, c->d_lut, c->d_mean, c->d_sd,   c->d_sumsq, c->d_T,
                    c->d_part,   c->d_stage, c->d_io_a, c->d_io_b, c->d_small, c->d_packedT, c->d_inv_sd, c->d_mu_inv_sd,
                    c->d_i8w, c->d_Qb, c->d_Qg, c->d_Qm, c->d_i8ws, c->d_snp_ptr, c->d_snp_idx, c->d_smp_ptr, c->d_smp_idx, c->d_eplane,
-                   c->d_full_in, c->d_full_out, c->d_hyb_idx, c->d_packedE, c->d_packedET, c->d_hyb_T, c->d_hyb_plane, c->d_Qd};
+                   c->d_full_in, c->d_full_out, c->d_qrm_loc, c->d_qrm_full, c->d_xmeta, c->d_hyb_idx, c->d_packedE, c->d_packedET, c->d_hyb_T, c->d_hyb_plane, c->d_Qd};
    for (void *p : ptrs)
       if (p) (void)hipFree(p);
    for (auto &pb : c->block_pool) (void)hipFree(pb.second);

@@ -182,6 +182,12 @@ struct fpca_ctx {
    // row-sharded solver (backend.hpp RowShard): whole [full_rows][b] blocks either side of the operator
    double *d_full_in = nullptr, *d_full_out = nullptr;
    size_t full_in_cap = 0, full_out_cap = 0;
+   // row-sharded operand exchange in byte slices (operator.hip apply_sharded): this rank's rows / all rows, row-major [rows][S b] int8;
+   // xmeta: [I8_SHARDS][64] column maxima, 640 weights, 64 folded maxima to send, [nranks][64] gathered (8-byte words)
+   int8_t *d_qrm_loc = nullptr, *d_qrm_full = nullptr;
+   size_t qrm_loc_cap = 0, qrm_full_cap = 0;
+   double *d_xmeta = nullptr;
+   size_t xmeta_cap = 0;
    uint64_t coll_calls = 0, coll_bytes = 0; // data-path collectives issued by this context (calls, payload bytes)
    long exchange_tested = -1; // layout (ranks, chunks, width) whose all-gather / reduce-scatter have passed the self-test on ALL ranks
    long exchange_failed = -1; // ... or failed it somewhere: that layout is not tried again (fpca_pca takes the replicated solver)
@@ -201,6 +207,10 @@ struct fpca_ctx {
    // sum over ranks of full [sh.full_rows()][b]; rank r keeps its rows in slice.  only_chunk >= 0: that chunk only.
    void reduce_scatter(const RowShard &sh, double *full, double *slice, int b, hipStream_t s, int only_chunk = -1);
    void allreduce(double *dbuf, uint64_t count, hipStream_t s);
+   // native collectives only: `bytes_per_row` bytes per row of the slice (a multiple of 8) -> the same rows of every rank, chunk by
+   // chunk like all_gather; and a small all-gather of `count` doubles per rank
+   void all_gather_bytes(const RowShard &sh, const int8_t *slice, int8_t *full, size_t bytes_per_row, hipStream_t s);
+   void all_gather_small(const double *mine, double *all, size_t count, hipStream_t s);
 };
 
 namespace fpca {
@@ -220,8 +230,16 @@ constexpr int I8M_FULL = 0, I8M_SKIP = 1, I8M_NONE = 2, I8M_SPARSE = 3, I8M_HYBR
 bool ensure_i8(fpca_ctx *c, int b);
 int i8_mode(fpca_ctx *c, int b);
 void i8_zero_meta(fpca_ctx *c, hipStream_t s);
+// the operand of K2 already sliced elsewhere (row-sharded exchange): all rows' slices row-major, the column maxima / weights that go
+// with them, and an [N_pad][b] fp64 buffer the scaled operand may be written to for the sparse gathers of an exact pass
+struct PreSliced {
+   const int8_t *Qrm;
+   unsigned long long *maxbits;
+   double *colw;
+   double *dq64;
+};
 // T = X' B on slices of B (K2 stage); chain: the combine also leaves the column maxima of the two K3 operands
-void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipEvent_t *gev = nullptr);
+void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipEvent_t *gev = nullptr, const PreSliced *pre = nullptr);
 // Y = X T on slices of T/sd and mean T/sd (K3 stage), rows [r0, r1) of Y (r1 = 0: all)
 void x_i8(fpca_ctx *c, int b, double *dY, hipStream_t s, bool have_max, bool do_slice = true, uint64_t r0 = 0, uint64_t r1 = 0,
           hipEvent_t *gev = nullptr);

@@ -230,6 +230,160 @@ void i8_slice(const double *V, uint64_t rows_pad, uint64_t rows, int b, int S, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row-sharded operand exchange (round 6; operator.hip apply_sharded): every rank slices ITS rows of the block and the ranks
+// all-gather the SLICES -- S bytes per entry instead of the 8 of the fp64 block -- in a ROW-MAJOR layout Qrm[row][s*b + c]
+// (a rank's rows of a chunk are one contiguous piece, so the gathered buffer is simply [all rows][S*b] in global row order).
+//   k_maxbits_fold / k_maxbits_set   the column maxima: shards folded for the exchange / the maximum over all ranks' answers put back
+//   k_slice_rows                     V[rows][b] fp64 -> Qrm[rows][S*b] with the GLOBAL column scales; thread = (row, 16 columns)
+//   k_unpack_slices                  Qrm[rows_pad][S*b] -> Q[s*b + c][rows_pad] in the 16-row-group byte order of k_slice + the exact
+//                                    column sums of every slice; thread = (16 rows, slice, 16 columns)
+//   k_dequant_rows                   Qrm -> the scaled operand itself for the sparse gathers of the missing-call route: fp32 rows
+//                                    m 2^(1-F) (<= 4 slices) or fp64 rows m 2^(e-F); m = the (8S-2)-bit integer the slices spell --
+//                                    exactly the operand the GEMM multiplies
+__global__ void k_maxbits_fold(const unsigned long long *__restrict__ bits, double *__restrict__ out)
+{
+   if (threadIdx.x < 64) out[threadIdx.x] = __longlong_as_double((long long)maxbits_fold(bits, threadIdx.x));
+}
+__global__ void k_maxbits_set(const double *__restrict__ all, int G, unsigned long long *__restrict__ bits)
+{
+   if (threadIdx.x < 64) {
+      double m = 0.0;
+      for (int g = 0; g < G; g++) m = fmax(m, all[g * 64 + threadIdx.x]);
+      bits[threadIdx.x] = (unsigned long long)__double_as_longlong(m);
+      for (int k = 1; k < I8_SHARDS; k++) bits[k * 64 + threadIdx.x] = 0ull;
+   }
+}
+
+__global__ __launch_bounds__(256) void k_slice_rows(const double *__restrict__ V, uint64_t rows, int b, int S, int nsc_pad,
+                                                    const unsigned long long *__restrict__ maxbits, int8_t *__restrict__ Qrm,
+                                                    double *__restrict__ colw)
+{
+   __shared__ int sh_e[64];
+   const int F = 8 * S - 2;
+   if ((int)threadIdx.x < b) {
+      const int e = slice_exponent(maxbits_fold(maxbits, threadIdx.x));
+      sh_e[threadIdx.x] = e;
+      if (blockIdx.x == 0)
+         for (int s = 0; s < S; s++) colw[s * b + threadIdx.x] = ldexp(1.0, e - F + 8 * (S - 1 - s));
+   }
+   if (blockIdx.x == 0)
+      for (int t = S * b + threadIdx.x; t < nsc_pad; t += 256) colw[t] = 0.0;
+   __syncthreads();
+   const int gpr = b / 16; // 16-column groups per row
+   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, row = t / gpr;
+   const int g = (int)(t % gpr);
+   if (row >= rows) return;
+   long long m[16];
+#pragma unroll
+   for (int j = 0; j < 16; j++) m[j] = __double2ll_rn(ldexp(V[row * b + 16 * g + j], F - sh_e[16 * g + j]));
+   for (int s = S - 1; s >= 0; s--) {
+      u4 word = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+         const int d = (int)(signed char)(m[j] & 0xFF);
+         m[j] = (m[j] - d) >> 8;
+         word[j >> 2] |= ((uint32_t)d & 0xFFu) << (8 * (j & 3)); // byte j of the piece = column 16 g + j
+      }
+      *reinterpret_cast<u4 *>(Qrm + row * (uint64_t)(S * b) + s * b + 16 * g) = word;
+   }
+}
+
+__global__ __launch_bounds__(256) void k_unpack_slices(const int8_t *__restrict__ Qrm, uint64_t rows_pad, int b, int S,
+                                                        int8_t *__restrict__ Q, long long *__restrict__ colsum)
+{
+   __shared__ int ssum[16][256];
+   const int gpr = b / 16, s = blockIdx.y / gpr, g = blockIdx.y % gpr;
+   const uint64_t rg = (uint64_t)blockIdx.x * 256 + threadIdx.x, groups = rows_pad / 16;
+   int tot[16];
+#pragma unroll
+   for (int j = 0; j < 16; j++) tot[j] = 0;
+   if (rg < groups) {
+      u4 piece[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) piece[i] = *reinterpret_cast<const u4 *>(Qrm + (rg * 16 + i) * (uint64_t)(S * b) + s * b + 16 * g);
+#pragma unroll
+      for (int j = 0; j < 16; j++) { // column 16 g + j: byte j of every piece, row i -> word i % 4, byte i / 4 (k_slice's order)
+         u4 word = {0u, 0u, 0u, 0u};
+#pragma unroll
+         for (int i = 0; i < 16; i++) {
+            const uint32_t byte = (piece[i][j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            word[i & 3] |= byte << (8 * (i >> 2));
+            tot[j] += (int)(signed char)byte;
+         }
+         *reinterpret_cast<u4 *>(Q + (uint64_t)(s * b + 16 * g + j) * rows_pad + rg * 16) = word;
+      }
+   }
+   if (colsum) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) ssum[j][threadIdx.x] = tot[j];
+      __syncthreads();
+      if (threadIdx.x < 16) {
+         long long a = 0;
+         for (int k = 0; k < 256; k++) a += ssum[threadIdx.x][k];
+         if (a)
+            atomicAdd(reinterpret_cast<unsigned long long *>(&colsum[(blockIdx.x % I8_SHARDS) * I8_CS_STRIDE + s * b + 16 * g + threadIdx.x]),
+                      (unsigned long long)a);
+      }
+   }
+}
+
+__global__ __launch_bounds__(256) void k_dequant_rows(const int8_t *__restrict__ Qrm, uint64_t rows, int b, int S,
+                                                       const unsigned long long *__restrict__ maxbits, float *__restrict__ copy32,
+                                                       double *__restrict__ copy64)
+{
+   const int F = 8 * S - 2, gpr = b / 16;
+   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, row = t / gpr;
+   const int g = (int)(t % gpr);
+   if (row >= rows) return;
+   long long m[16];
+#pragma unroll
+   for (int j = 0; j < 16; j++) m[j] = 0;
+   for (int s = 0; s < S; s++) { // slice 0 = top byte
+      const u4 word = *reinterpret_cast<const u4 *>(Qrm + row * (uint64_t)(S * b) + s * b + 16 * g);
+#pragma unroll
+      for (int j = 0; j < 16; j++) m[j] = m[j] * 256 + (long long)(signed char)((word[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+   }
+#pragma unroll
+   for (int j = 0; j < 16; j++) {
+      const int c = 16 * g + j;
+      if (copy32) copy32[row * b + c] = (float)ldexp((double)m[j], 1 - F); // |.| < 2, like k_slice's copy32
+      if (copy64) copy64[row * b + c] = ldexp((double)m[j], slice_exponent(maxbits_fold(maxbits, c)) - F);
+   }
+}
+
+void i8_maxbits_fold(const unsigned long long *bits, double *out64, hipStream_t stream)
+{
+   hipLaunchKernelGGL(k_maxbits_fold, dim3(1), dim3(64), 0, stream, bits, out64);
+   HIP_CHECK_LAUNCH();
+}
+void i8_maxbits_set(const double *all, int G, unsigned long long *bits, hipStream_t stream)
+{
+   hipLaunchKernelGGL(k_maxbits_set, dim3(1), dim3(64), 0, stream, all, G, bits);
+   HIP_CHECK_LAUNCH();
+}
+void i8_slice_rows(const double *V, uint64_t rows, int b, int S, const SliceOp &op, int8_t *Qrm, hipStream_t stream)
+{
+   if (S > 8 || b > 64 || b % 16) throw Error(-1, "i8_slice_rows: S <= 8, b in {16, 32, 48, 64}");
+   if (!rows) return;
+   const uint64_t threads = rows * (b / 16);
+   hipLaunchKernelGGL(k_slice_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, V, rows, b, S, gemm_i8_nsc_pad(S, b), op.maxbits, Qrm, op.colw);
+   HIP_CHECK_LAUNCH();
+}
+void i8_unpack_slices(const int8_t *Qrm, uint64_t rows_pad, int b, int S, const SliceOp &op, hipStream_t stream)
+{
+   const uint64_t groups = rows_pad / 16;
+   hipLaunchKernelGGL(k_unpack_slices, dim3((unsigned)((groups + 255) / 256), (unsigned)(S * (b / 16))), dim3(256), 0, stream, Qrm, rows_pad, b, S, op.Q, op.colsum);
+   HIP_CHECK_LAUNCH();
+}
+void i8_dequant_rows(const int8_t *Qrm, uint64_t rows, int b, int S, const SliceOp &op, float *copy32, double *copy64, hipStream_t stream)
+{
+   if (!rows) return;
+   const uint64_t threads = rows * (b / 16);
+   hipLaunchKernelGGL(k_dequant_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, Qrm, rows, b, S, op.maxbits, copy32, copy64);
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2i / K3i core:  acc[row][sc] = sum_k A[row][k] * Q[sc][k]  for A in {G.M, M}
 //   `packed`: 2-bit records, one per output row (K2: the SNP-major stream, K = samples; K3: its sample-major copy,
 //   K = SNPs).  TWO = false (K2): both integer matrices multiply the same operand Q.  TWO = true (K3): G.M multiplies

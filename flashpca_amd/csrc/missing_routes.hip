@@ -467,9 +467,13 @@ void i8_zero_meta(fpca_ctx *c, hipStream_t s)
 
 // T = X' B : slices of B against the SNP-major stream, per-SNP mean / sd applied in the combine; with `chain` the
 // combine also leaves the column maxima of the two K3 operands (the meta region must have been zeroed by the caller)
-void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipEvent_t *gev)
+void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipEvent_t *gev, const PreSliced *pre)
 {
    kern::SliceOp ob = i8_op_b(c), ot[2];
+   if (pre) { // the slices were cut by the ranks that own the rows, with the column scales all ranks agreed on
+      ob.maxbits = pre->maxbits;
+      ob.colw = pre->colw;
+   }
    i8_ops_t(c, ot);
    int mode = i8_mode(c, b);
    const double *eplane = nullptr;
@@ -481,8 +485,18 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipE
    const bool hyb = mode == I8M_HYBRID;
    const bool g32 = (mode == I8M_SPARSE || hyb) && c->gather_f32();
    if (g32) ob.copy32 = static_cast<float *>(c->gather_src()); // the slicing pass leaves the fp32 rows the gather reads
-   kern::i8_colmax(dB, c->N, b, 1, &ob, s);
-   kern::i8_slice(dB, c->N_pad, c->N, b, c->cur_S(), 1, &ob, s);
+   if (pre) {
+      // column-major operand + exact column sums from the gathered rows; the gathers of the missing-call route read the operand
+      // the slices spell -- X' applied to exactly the rounded block, G and E terms alike
+      kern::i8_unpack_slices(pre->Qrm, c->N_pad, b, c->cur_S(), ob, s);
+      if (mode == I8M_SPARSE || hyb) {
+         kern::i8_dequant_rows(pre->Qrm, c->N, b, c->cur_S(), ob, g32 ? ob.copy32 : nullptr, g32 ? nullptr : pre->dq64, s);
+         if (!g32) dB = pre->dq64;
+      }
+   } else {
+      kern::i8_colmax(dB, c->N, b, 1, &ob, s);
+      kern::i8_slice(dB, c->N_pad, c->N, b, c->cur_S(), 1, &ob, s);
+   }
    if (hyb) // E_d' B of the dense SNPs on the matrix cores: their compacted records x the same slices of B -> [hyb_pad][b]
       kern::gemm_i8(c->d_packedE, c->pitch, c->d_Qb, c->d_Qb, ob.colw, ob.colw, nullptr, nullptr, nullptr, c->d_hyb_plane, c->d_i8ws, c->hyb_pad, c->N_pad,
                     c->hyb_n, I8M_NONE, nullptr, b, c->cur_S(), nullptr, s, nullptr, nullptr, true);

@@ -87,35 +87,102 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
    if (ev) HIP_CHECK(hipEventRecord(ev[3], s));
 }
 
-// The operator on a ROW-SHARDED block (the eigensolver's view, backend.hpp RowShard): all-gather the rows of the input block
-// (K2 sums over all samples), K2, K3 on the whole block, reduce-scatter the partial products -- the same bytes on the wire
-// as the all-reduce of apply_xxt_dev, but every rank ends up with only ITS rows of the sum, which is all the
-// orthogonalisation that follows needs.  With the built-in communicator and more than one chunk, K3 runs chunk by chunk
-// and the reduce-scatter of chunk i rides on the communication stream under the computation of chunk i + 1.
+// The operator on a ROW-SHARDED block (the eigensolver's view, backend.hpp RowShard): the rows of the input block go to every rank
+// (K2 sums over all samples), K2, K3 on the whole block, reduce-scatter of the partial products -- every rank ends up with only ITS
+// rows of the sum, which is all the orthogonalisation that follows needs.  With real all-gather / reduce-scatter and more than one
+// chunk, K3 runs chunk by chunk and the reduce-scatter of chunk i rides on the communication stream under the computation of chunk i + 1.
+//
+// What travels in the all-gather (round 6): in the exact-integer arithmetic the operand of K2 is S byte slices of the block, so each
+// rank cuts ITS rows into slices -- the column scales agreed through one all-gather of b maxima per rank -- and the ranks all-gather
+// the SLICES, row-major [rows][S b] int8: S N b bytes instead of 8 N b (half at the 4 slices of the eigensolver's cheap passes), and
+// nobody slices rows it does not own; what every rank still does for all N rows is a byte transposition into the GEMM's operand
+// layout (kernels_i8.hip k_unpack_slices).  The format depends on the REQUESTED arithmetic and the transport only, never on what
+// fitted on a rank: a rank that fell back to the fp64 kernels receives the same slices and multiplies the block they spell.
+static int exchange_slices_S(const fpca_ctx *c)
+{
+   if (c->i8_S_req <= 0 || !c->native_collectives() || FPCA_TEST_ENV("FPCA_EXCHANGE_FP64")) return 0;
+   return (c->i8_Sc > 0 && c->i8_Sc < c->i8_S_req) ? c->i8_Sc : c->i8_S_req;
+}
+
+constexpr size_t XM_MAX = 0, XM_COLW = 64 * kern::I8_SHARDS, XM_SEND = XM_COLW + 640, XM_ALL = XM_SEND + 64; // d_xmeta, 8-byte words
+
+static void exchange_slices(fpca_ctx *c, const RowShard &sh, const double *in_slice, int b, int S, hipStream_t s)
+{
+   const size_t SB = (size_t)S * b, need_loc = (size_t)sh.slice_rows() * SB, need_full = (size_t)sh.full_rows() * SB, need_meta = XM_ALL + 64 * (size_t)sh.G;
+   auto grow = [&](void **p, size_t &cap, size_t need) {
+      if (need <= cap) return;
+      HIP_CHECK(hipStreamSynchronize(s));
+      if (*p) HIP_CHECK(hipFree(*p));
+      *p = nullptr;
+      cap = 0;
+      HIP_ALLOC(hipMalloc(p, need));
+      cap = need;
+   };
+   grow((void **)&c->d_qrm_loc, c->qrm_loc_cap, need_loc);
+   grow((void **)&c->d_qrm_full, c->qrm_full_cap, need_full);
+   grow((void **)&c->d_xmeta, c->xmeta_cap, need_meta * sizeof(double));
+   unsigned long long *maxbits = reinterpret_cast<unsigned long long *>(c->d_xmeta + XM_MAX);
+   HIP_CHECK(hipMemsetAsync(maxbits, 0, 64 * kern::I8_SHARDS * sizeof(double), s));
+   kern::SliceOp ox{nullptr, maxbits, nullptr, c->d_xmeta + XM_COLW, nullptr, nullptr, nullptr};
+   kern::i8_colmax(in_slice, sh.slice_rows(), b, 1, &ox, s); // (rows >= N of a slice are zero)
+   kern::i8_maxbits_fold(maxbits, c->d_xmeta + XM_SEND, s);
+   c->all_gather_small(c->d_xmeta + XM_SEND, c->d_xmeta + XM_ALL, 64, s);
+   kern::i8_maxbits_set(c->d_xmeta + XM_ALL, sh.G, maxbits, s);
+   kern::i8_slice_rows(in_slice, sh.slice_rows(), b, S, ox, c->d_qrm_loc, s);
+   c->all_gather_bytes(sh, c->d_qrm_loc, c->d_qrm_full, SB, s);
+}
+
 void apply_sharded(fpca_ctx *c, const RowShard &sh, const double *in_slice, int b, double *out_slice, hipStream_t s)
 {
-   c->all_gather(sh, in_slice, c->d_full_in, b, s);
-   if (sh.nch > 1 && c->native_collectives() && c->comm_stream) {
+   const int S = exchange_slices_S(c);
+   const bool chunked = sh.nch > 1 && c->native_collectives() && c->comm_stream;
+   bool i8 = false;
+   PreSliced pre{nullptr, nullptr, nullptr, nullptr};
+   if (S) {
+      exchange_slices(c, sh, in_slice, b, S, s);
       ensure_stats(c);
-      if (c->i8_S && ensure_i8(c, b) && !c->i8_k2_only) {
-         c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
-         i8_zero_meta(c, s);
-         xt_i8(c, c->d_full_in, b, s, true);
-         for (int i = 0; i < sh.nch; i++) {
-            const uint64_t r0 = std::min<uint64_t>((uint64_t)i * sh.L, c->N_pad), r1 = std::min<uint64_t>((uint64_t)(i + 1) * sh.L, c->N_pad);
-            if (r1 <= r0 && i > 0) { // a chunk wholly behind the last row (the same on every rank): no K3, no collective, zeros out
-               HIP_CHECK(hipMemsetAsync(out_slice + (size_t)i * sh.plen * b, 0, (size_t)sh.plen * b * sizeof(double), s));
-               continue;
-            }
-            x_i8(c, b, c->d_full_out, s, true, i == 0, r0, r1); // (rows >= N_pad of d_full_out stay zero: nothing writes them)
-            HIP_CHECK(hipEventRecord(c->ev_chunk[i], s));
-            HIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_chunk[i], 0));
-            c->reduce_scatter(sh, c->d_full_out, out_slice, b, c->comm_stream, i);
-         }
-         HIP_CHECK(hipEventRecord(c->ev_comm_done, c->comm_stream));
-         HIP_CHECK(hipStreamWaitEvent(s, c->ev_comm_done, 0));
+      i8 = c->i8_S && ensure_i8(c, b);
+      kern::SliceOp ox{nullptr, reinterpret_cast<unsigned long long *>(c->d_xmeta + XM_MAX), nullptr, c->d_xmeta + XM_COLW, nullptr, nullptr, nullptr};
+      if (!i8) // this rank runs the fp64 kernels (its int8 buffers did not fit): the block the slices spell, in fp64
+         kern::i8_dequant_rows(c->d_qrm_full, c->N_pad, b, S, ox, nullptr, c->d_full_in, s);
+      else
+         pre = PreSliced{c->d_qrm_full, ox.maxbits, ox.colw, c->d_full_in};
+   } else {
+      c->all_gather(sh, in_slice, c->d_full_in, b, s);
+      if (chunked) {
+         ensure_stats(c);
+         i8 = c->i8_S && ensure_i8(c, b);
+      }
+   }
+   if (i8 && (S || (chunked && !c->i8_k2_only))) {
+      c->ensure(c->d_T, c->T_cap, (size_t)c->P_pad * b);
+      i8_zero_meta(c, s);
+      if (c->i8_k2_only) { // K3 on the fp64 kernel (no sample-major copy), whole block
+         xt_i8(c, c->d_full_in, b, s, false, nullptr, S ? &pre : nullptr);
+         x_dev(c, b, c->d_full_out, s);
+         c->reduce_scatter(sh, c->d_full_out, out_slice, b, s);
          return;
       }
+      xt_i8(c, c->d_full_in, b, s, true, nullptr, S ? &pre : nullptr);
+      if (!chunked) {
+         x_i8(c, b, c->d_full_out, s, true);
+         c->reduce_scatter(sh, c->d_full_out, out_slice, b, s);
+         return;
+      }
+      for (int i = 0; i < sh.nch; i++) {
+         const uint64_t r0 = std::min<uint64_t>((uint64_t)i * sh.L, c->N_pad), r1 = std::min<uint64_t>((uint64_t)(i + 1) * sh.L, c->N_pad);
+         if (r1 <= r0 && i > 0) { // a chunk wholly behind the last row (the same on every rank): no K3, no collective, zeros out
+            HIP_CHECK(hipMemsetAsync(out_slice + (size_t)i * sh.plen * b, 0, (size_t)sh.plen * b * sizeof(double), s));
+            continue;
+         }
+         x_i8(c, b, c->d_full_out, s, true, i == 0, r0, r1); // (rows >= N_pad of d_full_out stay zero: nothing writes them)
+         HIP_CHECK(hipEventRecord(c->ev_chunk[i], s));
+         HIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_chunk[i], 0));
+         c->reduce_scatter(sh, c->d_full_out, out_slice, b, c->comm_stream, i);
+      }
+      HIP_CHECK(hipEventRecord(c->ev_comm_done, c->comm_stream));
+      HIP_CHECK(hipStreamWaitEvent(s, c->ev_comm_done, 0));
+      return;
    }
    apply_xxt_dev(c, c->d_full_in, b, c->d_full_out, s, nullptr, false);
    c->reduce_scatter(sh, c->d_full_out, out_slice, b, s);

@@ -707,15 +707,22 @@ def test_row_sharded_solver_path_on_one_rank(fp, monkeypatch, nch, k):
     with fp.test_hooks(), fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:
         c.comm_init_rank(1, 0, fp.Context.comm_unique_id())
         assert c.allreduce_chunks() == nch
-        calls0, _ = c.collective_stats()
+        calls0, bytes0 = c.collective_stats()
         r = c.pca(ndim=k, do_loadings=True)
         calls, nbytes = c.collective_stats()
+        nbytes -= bytes0
         # (the two paths sum the Gram matrices in different row orders; at k = 20 the 45-pass solve crosses its cheap-pass threshold
         #  within 0.6 % of it -- 8.045e-7 against 8.0e-7 at pass 44 -- so a rounding-level difference may end it one pass earlier)
         assert r["info"]["converged"] == 1 and abs(r["info"]["block_applies"] - r0["info"]["block_applies"]) <= (1 if k == 20 else 0)
-        # per apply: nch all-gathers + nch reduce-scatters; + nch all-gathers each for the download and for the loadings block;
+        # per apply: nch all-gathers (of the operand's BYTE SLICES since round 6: S bytes per entry instead of 8) + one all-gather of
+        # the b column maxima per rank + nch reduce-scatters; + nch all-gathers each for the download and for the loadings block;
         # + the scalar all-reduce of the trace (one rank: the Gram sums stay local)
-        assert calls - calls0 == 2 * nch * r["info"]["block_applies"] + 2 * nch * kb + 1
+        A, Ac = r["info"]["block_applies"], r["info"]["cheap_applies"]
+        assert calls - calls0 == (2 * nch + 1) * A + 2 * nch * kb + 1
+        full = nch * (((c.block_rows() + nch - 1) // nch + 511) // 512 * 512)  # rows of a whole block in the padded chunk layout
+        S_sum = 7 * (A - Ac) + r["info"]["cheap_slices"] * Ac
+        assert nbytes == A * (64 * 8 + full * 16 * 8) + full * 16 * S_sum + 2 * kb * full * 16 * 8 + 8
+        assert nbytes < (A + kb) * full * 16 * 16  # (rounds 1-5: 8 + 8 bytes per entry and apply)
         assert np.max(np.abs(r["d"] - r0["d"]) / r0["d"]) < (1e-12 if r["info"]["block_applies"] == r0["info"]["block_applies"] else 1e-10)
         sg = np.sign(np.sum(r["U"] * r0["U"], axis=0))
         # the five structured pairs (6 sub-populations) are isolated: same vectors to rounding; the bulk pairs behind them are
@@ -726,6 +733,33 @@ def test_row_sharded_solver_path_on_one_rank(fp, monkeypatch, nch, k):
         err, mse, rmse = c.check(r["U"], r["d"])
         assert np.all(np.sqrt(err) <= 1.01e-6 * r["d"])
         assert np.max(np.abs(r["Px"] - r["U"] * np.sqrt(r["d"]))) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["fallback_rank", "fp64_exchange"])
+def test_row_sharded_exchange_format_does_not_depend_on_what_fitted_on_a_rank(fp, monkeypatch, case):
+    """The row-sharded apply all-gathers BYTE SLICES of the block (round 6).  The format is decided from the requested arithmetic and the
+    transport alone, so that every rank issues the same collectives: a rank whose int8 buffers did not fit (FPCA_ACCUM_AUTO falls back
+    to the fp64 kernels -- forced here) still sends slices of its rows, receives everybody's, and multiplies the block they spell with
+    the fp64 kernels; FPCA_EXCHANGE_FP64 (test build) is rounds 1-5's exchange of the fp64 block.  Same eigenvalues either way."""
+    N, P, k = 40000, 1500, 8
+    with fp.Context.synthetic(N, P, n_pop=6, accum="auto") as ref:
+        r0 = ref.pca(ndim=k)
+    monkeypatch.setenv("FPCA_AR_CHUNKS", "2")
+    monkeypatch.setenv("FPCA_FORCE_ROWSHARD", "1")
+    monkeypatch.setenv("FPCA_DEBUG_I8_NOMEM" if case == "fallback_rank" else "FPCA_EXCHANGE_FP64", "1")
+    with fp.test_hooks(), fp.Context.synthetic(N, P, n_pop=6, accum="auto") as c:
+        c.comm_init_rank(1, 0, fp.Context.comm_unique_id())
+        _, bytes0 = c.collective_stats()
+        r = c.pca(ndim=k, mixed=-1)
+        _, nbytes = c.collective_stats()
+        A = r["info"]["block_applies"]
+        full = 2 * (((c.block_rows() + 1) // 2 + 511) // 512 * 512)
+        assert r["info"]["solver_path"] == 1 and r["info"]["converged"] == 1
+        assert c.accum == ("fp64" if case == "fallback_rank" else "i8x7")
+        per_entry = 7 + 8 if case == "fallback_rank" else 8 + 8  # all-gather + reduce-scatter bytes per entry of the block and apply
+        assert A * full * 16 * per_entry <= nbytes - bytes0 <= A * full * 16 * per_entry + (A + 4) * 1024 + 2 * full * 16 * 8
+        assert np.max(np.abs(r["d"] - r0["d"]) / r0["d"]) < 1e-9
 
 
 @pytest.mark.gpu
