@@ -739,6 +739,17 @@ def main():
             sm["missing_call_rate"] = 0.02
             sm["slowdown_vs_value"] = sm["ms_per_step"] / (elapsed / args.steps * 1e3)
             out["apply_at_missing_2pct"] = sm
+        # ... and what the eigensolver's 4-slice passes cost there (round 6: the two-matrix kernels exist from 2 column tiles up with
+        # 64-row waves; rounds 2-5 multiplied two tiles of zero padding -- 15.3 ms per pass, profiles/r06_missing_cheap_probe.txt)
+        try:
+            with fp.Context.synthetic(N, P_rank, snp_begin=snp_begin, n_pop=min(2 * k, 64), missing_rate=0.02, device=local_rank, accum="i8x4") as cm4:
+                cm4.set_total_snps(P_total)
+                cm4.stats()
+                s4 = side_apply(cm4, b, max(4, args.steps // 4))
+                out["apply_at_missing_2pct"]["cheap_pass_ms_per_step"] = s4["ms_per_step"]
+                out["apply_at_missing_2pct"]["cheap_pass_speedup_vs_exact_step"] = sm["ms_per_step"] / s4["ms_per_step"]
+        except Exception as e:  # never lose the line over a side block
+            out["apply_at_missing_2pct"]["cheap_pass_error"] = str(e)[:200]
 
     # (c) ... and with the SAME 2 % of the calls missing, but per-SNP rates log-normally distributed (sd of ln(rate) 1.5: most SNPs below
     #     1 %, a long tail of poor assays) -- where real arrays sit, between "uniform" and the concentrated profile of pca_realistic.  The
@@ -1102,6 +1113,7 @@ def main():
     rl["power_w"] = _g(rl, "power", "watts_median")
     rl["cheap_pass_power_w"] = _g(out, "cheap_pass", "power", "watts_median")
     rl["missing_2pct_slowdown"] = _g(out, "apply_at_missing_2pct", "slowdown_vs_value")
+    rl["missing_2pct_cheap_pass_ms"] = _g(out, "apply_at_missing_2pct", "cheap_pass_ms_per_step")
 
     if rank == 0:
         # anything the C side buffered on stdout (RCCL prints a version banner there under NCCL_DEBUG=VERSION) goes out first:

@@ -916,15 +916,16 @@ struct I8Shape {
 static I8Shape i8_shape(int S, int b, bool two, int mode = I8_FULL)
 {
    const int tiles = (S * b + 31) / 32, cap = two ? 4 : 8; // largest instantiated block
-   // smallest instantiated block: 3 tiles (two operands) / 4 tiles; the one-matrix kernel also exists with 2 and 3 tiles
-   // (few slices of a narrow block: S = 4, b = 16 is 64 slice-columns)
-   int lo = two ? 3 : 4;
-   if (!two && mode == I8_NO_MISSING) lo = 2;
+   // smallest instantiated block: 2 tiles (few slices of a narrow block: S = 4, b = 16 is 64 slice-columns).  Rounds 2-5 had the
+   // two-matrix kernels from 4 (K2) / 3 (K3) tiles up only: the eigensolver's 4-slice passes on data whose missing calls take the dense
+   // route multiplied 2 / 1 tiles of zero padding per launch (profiles/r06_missing_routes.txt)
+   int lo = 2;
+   if (FPCA_TEST_ENV("FPCA_I8_LO_R5")) lo = two ? 3 : (mode == I8_NO_MISSING ? 2 : 4); // (A/B against round 5's shapes)
    I8Shape sh;
    sh.zb = (tiles + cap - 1) / cap;
    sh.nt = std::max(lo, (tiles + sh.zb - 1) / sh.zb);
    // one matrix only (I8_NO_MISSING): the freed accumulators go into a second row tile per wave (64 rows x NT tiles)
-   sh.rows = (two || mode == I8_NO_MISSING) ? 256 : 128;
+   sh.rows = (two || mode == I8_NO_MISSING || (sh.nt <= 3 && !FPCA_TEST_ENV("FPCA_I8_LO_R5") && !FPCA_TEST_ENV("FPCA_I8_NARROW_MT1"))) ? 256 : 128;
    if (!two && mode == I8_NO_MISSING && sh.nt <= 3 && FPCA_TEST_ENV("FPCA_I8_MT4")) { // experiment: 128 rows per wave
       sh.mt = 4;
       sh.rows = 512;
@@ -1075,8 +1076,12 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
    if (two && mode == I8_NO_MISSING) throw Error(-1, "gemm_i8: without missing genotypes both matrices share one operand (pass Qm == Qg)");
 #define FPCA_I8_K3(NT_, MODE_) launch_i8<I8Cfg<true, 2, NT_, 4, 1, 256, 1, MODE_>>(FPCA_I8_ARGS)
 #define FPCA_I8_K2(NT_, MODE_) launch_i8<I8Cfg<false, (MODE_ == I8_NO_MISSING ? 2 : 1), NT_, 4, 1, 256, (MODE_ == I8_NO_MISSING ? 1 : 2), MODE_>>(FPCA_I8_ARGS)
+// (narrow column blocks: 64-row waves for both matrices too -- the accumulators fit, the operand tile is staged for twice the rows)
+#define FPCA_I8_K2W(NT_, MODE_) launch_i8<I8Cfg<false, 2, NT_, 4, 1, 256, 1, MODE_>>(FPCA_I8_ARGS)
 #define FPCA_I8_K2_NT(MODE_)                                                                                 \
    switch (sh.nt) {                                                                                           \
+   case 2: if (sh.rows == 256) FPCA_I8_K2W(2, MODE_); else FPCA_I8_K2(2, MODE_); break;                       \
+   case 3: if (sh.rows == 256) FPCA_I8_K2W(3, MODE_); else FPCA_I8_K2(3, MODE_); break;                       \
    case 4: FPCA_I8_K2(4, MODE_); break;                                                                       \
    case 5: FPCA_I8_K2(5, MODE_); break;                                                                       \
    case 6: FPCA_I8_K2(6, MODE_); break;                                                                       \
@@ -1089,12 +1094,16 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
       launch_i8<I8Cfg<false, 2, 4, 4, 1, 256, 1, I8_FULL, 0, true>>(FPCA_I8_ARGS);
    else if (two) {
       if (mode == I8_SKIP_EMPTY) {
-         if (sh.nt == 3)
+         if (sh.nt == 2)
+            FPCA_I8_K3(2, I8_SKIP_EMPTY);
+         else if (sh.nt == 3)
             FPCA_I8_K3(3, I8_SKIP_EMPTY);
          else
             FPCA_I8_K3(4, I8_SKIP_EMPTY);
       } else {
-         if (sh.nt == 3)
+         if (sh.nt == 2)
+            FPCA_I8_K3(2, I8_FULL);
+         else if (sh.nt == 3)
             FPCA_I8_K3(3, I8_FULL);
          else
             FPCA_I8_K3(4, I8_FULL);
@@ -1153,6 +1162,7 @@ void gemm_i8(const uint8_t *packed, size_t pitch, const int8_t *Qg, const int8_t
       FPCA_I8_K2_NT(I8_FULL)
    }
 #undef FPCA_I8_K2_NT
+#undef FPCA_I8_K2W
 #undef FPCA_I8_K2
 #undef FPCA_I8_K3
 #undef FPCA_I8_ARGS
