@@ -20,6 +20,7 @@ constexpr int I8W_B = 0, I8W_G = 640, I8W_M = 1280, I8W_D = 1920, I8W_ZERO = 256
               I8W_CSM = I8W_CSB + kern::I8_CS_STRIDE * kern::I8_SHARDS, I8W_TOTAL = I8W_CSM + kern::I8_CS_STRIDE * kern::I8_SHARDS;
 
 
+constexpr double CHEAP_SPARSE_BREAK_EVEN = 0.002; // ... and for passes on <= 4 slices (i8_mode)
 constexpr double SPARSE_BREAK_EVEN = 0.005; // missing-call rate at which the gathers cost what the E half of the GEMMs costs (= M2_CELL S / G_CALL at S = 7)
 static void hybrid_classify(fpca_ctx *c);
 static void ensure_i8_alloc(fpca_ctx *c, int b);
@@ -282,7 +283,15 @@ int i8_mode(fpca_ctx *c, int b) // (classifies the SNPs the first time a rate ab
    // Measured at 500k x 100k (scripts/sparse_breakeven.py, profiles/r03_sparse_breakeven.txt; K2 / K3 stage in ms, sparse |
    // dense): b = 16: 0.3 % 6.8 / 7.4 | 9.0 / 9.8, 0.5 % 8.5 / 9.1 | 9.0 / 9.9, 1 % 12.6 / 13.0 | 9.0 / 9.8; b = 32: 0.3 % 12.7 / 13.7 |
    // 16.2 / 18.8, 0.5 % 15.9 / 16.8 | 16.1 / 18.8, 1 % 23.9 / 24.7 | 16.2 / 18.8 -- the lines cross at 0.51-0.63 % for both widths
-   if (sparse_ok && rate <= SPARSE_BREAK_EVEN) return I8M_SPARSE;
+   if (sparse_ok && rate <= SPARSE_BREAK_EVEN) {
+      // The eigensolver's cheap passes (fewer slices) cross over much earlier: the gathers cost the same whatever the slice count, the
+      // indicator's half of a 4-slice two-matrix launch does not -- measured at 500,000 x 100,000, 16 columns, 4 slices
+      // (profiles/r06_cheap_route_breakeven.txt; apply in ms, gathers | two-matrix): 0.10 % 8.6 | 10.2, 0.15 % 9.3 | 10.2, 0.20 % 10.2 | 10.2,
+      // 0.30 % 11.8 | 10.2, 0.50 % 14.1 | 10.2.  Both routes read the same resident matrices (the lists stay for the exact passes), so
+      // the choice is per pass.  (fpca_missing_mode reports the route of the exact passes.)
+      if (c->i8_Sc > 0 && c->i8_Sc < c->i8_S && c->i8_Sc <= 4 && rate > CHEAP_SPARSE_BREAK_EVEN && !c->hyb_view) return I8M_FULL;
+      return I8M_SPARSE;
+   }
    return rate < 3e-4 ? I8M_SKIP : I8M_FULL; // (block skipping: only where the sparse path does not apply)
 }
 
