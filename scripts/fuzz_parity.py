@@ -84,7 +84,12 @@ for case in range(ncases):
         os.environ["FPCA_I8_MODE"] = str(mode)
     else:
         os.environ.pop("FPCA_I8_MODE", None)
-    tol = {8: 1e-12, 7: 1e-12, 6: 3e-11, 5: 1e-8, 4: 2e-8}[S]
+    # `unit`: the expected size of the integer path's only rounding (the operand cut to 8 S - 2 bits below its column maximum) relative
+    # to the result scale; PASS_FACTOR x unit is the pass threshold of one stage (the factor covers column-scale spreads of the random
+    # operands and the numpy reference's own N eps), 10 x that for the composed operator.  The summary prints the worst error in units.
+    unit = {8: 1e-12, 7: 1e-12, 6: 3e-11, 5: 1e-8, 4: 2e-8}[S]
+    PASS_FACTOR = 50
+    tol = unit
     with32 = rng.random() < 0.25
     err32 = None
     try:
@@ -108,7 +113,7 @@ for case in range(ncases):
         return float(np.max(np.abs(a - r) / sc))
 
     errs = dict(T8=rel(T8, Tr), T64=rel(T64, Tr), Y8=rel(Y8, Yr), Y64=rel(Y64, Yr), Z8=rel(Z8, Zr))
-    ok = errs["T8"] <= tol * 50 and errs["Y8"] <= tol * 50 and errs["Z8"] <= tol * 500 and errs["T64"] <= 1e-11 and errs["Y64"] <= 1e-11
+    ok = errs["T8"] <= unit * PASS_FACTOR and errs["Y8"] <= unit * PASS_FACTOR and errs["Z8"] <= unit * PASS_FACTOR * 10 and errs["T64"] <= 1e-11 and errs["Y64"] <= 1e-11
     ok = ok and np.all(np.isfinite(Z8))
     if with32:  # fp32 products and short sums: ~1e-7 of sum |x||b|, measured against the largest entry of the column
         errs["T32"], errs["Y32"] = rel(T32, Tr), rel(Y32, Yr)
@@ -120,4 +125,4 @@ for case in range(ncases):
               " ".join("%s=%.1e" % kv for kv in errs.items()), "OK" if ok else "FAIL", flush=True)
     if not ok:
         sys.exit(1)
-print("all %d cases ok, worst err/tol %.3g, %.0f s" % (ncases, worst, time.time() - t0))
+print("all %d cases ok: worst stage error %.3g rounding units (pass threshold %d units), %.0f s" % (ncases, worst, 50, time.time() - t0))

@@ -18,21 +18,21 @@ python bench.py --workload cfg5shard --accum fp32 $Q --no-alt > gpurun_out/$R/be
 for a in i8 fp64; do
   # kernel trace of the driver's command line itself for the default mode (same flags), of --accum fp64 for the other
   if [ $a = i8 ]; then X=""; else X="--accum fp64 $Q --no-alt"; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg3_$a -o bench -- python bench.py $X > /dev/null 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg2_$a -o bench -- python bench.py --workload cfg2 --accum $a $Q --no-alt > /dev/null 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg3_$a -o bench -- python bench.py $X > /dev/null 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg2_$a -o bench -- python bench.py --workload cfg2 --accum $a $Q --no-alt > /dev/null 2>&1
   for wl in cfg2 cfg3; do
     st=3; [ $wl = cfg3 ] && st=2
     for kind in fetch write sq; do
       case $kind in fetch) C="FETCH_SIZE";; write) C="WRITE_SIZE";; sq) C="--kernel-trace $PMC_SQ";; esac
       if [ $kind = sq ]; then
-        rocprofv3 --kernel-trace --pmc $PMC_SQ --output-format csv -d gpurun_out/$R/pmc_${kind}_${wl}_$a -o pmc -- python bench.py --workload $wl --accum $a --steps $st --warmup 1 --no-cpu-baseline --no-pca --no-alt --no-e2e --traffic none > /dev/null 2>&1
+        timeout 400 rocprofv3 --kernel-trace --pmc $PMC_SQ --output-format csv -d gpurun_out/$R/pmc_${kind}_${wl}_$a -o pmc -- python bench.py --workload $wl --accum $a --steps $st --warmup 1 --no-cpu-baseline --no-pca --no-alt --no-e2e --traffic none > /dev/null 2>&1
       else
-        rocprofv3 --pmc $C --output-format csv -d gpurun_out/$R/pmc_${kind}_${wl}_$a -o pmc -- python bench.py --workload $wl --accum $a --steps $st --warmup 1 --no-cpu-baseline --no-pca --no-alt --no-e2e --traffic none > /dev/null 2>&1
+        timeout 400 rocprofv3 --pmc $C --output-format csv -d gpurun_out/$R/pmc_${kind}_${wl}_$a -o pmc -- python bench.py --workload $wl --accum $a --steps $st --warmup 1 --no-cpu-baseline --no-pca --no-alt --no-e2e --traffic none > /dev/null 2>&1
       fi
     done
   done
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg4shard_i8 -o bench -- python bench.py --workload cfg4shard $Q --no-alt > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace_cfg4shard_i8 -o bench -- python bench.py --workload cfg4shard $Q --no-alt > /dev/null 2>&1
 python scripts/summarise_pmc.py gpurun_out/$R _fp64 > gpurun_out/$R/pmc_summary.json
 python scripts/summarise_pmc.py gpurun_out/$R _i8 > gpurun_out/$R/pmc_summary_i8.json
 python scripts/mfma_i8_peak.py > gpurun_out/$R/mfma_i8_microbench.txt 2>&1
