@@ -288,42 +288,54 @@ __global__ __launch_bounds__(256) void k_slice_rows(const double *__restrict__ V
    }
 }
 
-__global__ __launch_bounds__(256) void k_unpack_slices(const int8_t *__restrict__ Qrm, uint64_t rows_pad, int b, int S,
+// One workgroup = TRG 16-row groups x all S b columns: the rows of a tile are one contiguous span of the row-major buffer, loaded
+// with coalesced 16-byte reads into LDS (row stride S b + 16, 16 more per row group: the 16 lanes of a ds_read_b128 group then hit
+// distinct banks); thread (row group fastest, slice, 16-column group) transposes a 16 x 16 byte block in registers and writes one
+// 16-byte piece per column -- adjacent threads = adjacent row groups = contiguous bytes of the same operand row.
+__global__ __launch_bounds__(256) void k_unpack_slices(const int8_t *__restrict__ Qrm, uint64_t rows_pad, int b, int S, int TRG,
                                                         int8_t *__restrict__ Q, long long *__restrict__ colsum)
 {
-   __shared__ int ssum[16][256];
-   const int gpr = b / 16, s = blockIdx.y / gpr, g = blockIdx.y % gpr;
-   const uint64_t rg = (uint64_t)blockIdx.x * 256 + threadIdx.x, groups = rows_pad / 16;
-   int tot[16];
-#pragma unroll
-   for (int j = 0; j < 16; j++) tot[j] = 0;
-   if (rg < groups) {
+   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
+   __shared__ int ssum[512];
+   const int SB = S * b, rstr = SB + 16, gstr = 16 * rstr + 16, ncg = SB / 16; // bytes per row / LDS strides / 16-column groups
+   const uint64_t rg0 = (uint64_t)blockIdx.x * TRG, groups = rows_pad / 16;
+   const int ng = (int)(groups - rg0 < (uint64_t)TRG ? groups - rg0 : TRG);
+   const u4 *src = reinterpret_cast<const u4 *>(Qrm + rg0 * 16 * (uint64_t)SB);
+   for (int p = threadIdx.x; p < ng * 16 * ncg; p += 256) { // piece p: row p / ncg of the tile, 16-byte piece p % ncg
+      const int row = p / ncg, pc = p % ncg;
+      *reinterpret_cast<u4 *>(tile + (row >> 4) * gstr + (row & 15) * rstr + pc * 16) = src[p];
+   }
+   for (int t = threadIdx.x; t < 512; t += 256) ssum[t] = 0;
+   __syncthreads();
+   for (int t = threadIdx.x; t < TRG * ncg; t += 256) {
+      const int rg = t % TRG, cg = t / TRG; // column group cg = s * (b / 16) + g covers slice-columns 16 cg .. 16 cg + 15
+      if (rg >= ng) continue;
       u4 piece[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) piece[i] = *reinterpret_cast<const u4 *>(Qrm + (rg * 16 + i) * (uint64_t)(S * b) + s * b + 16 * g);
+      for (int i = 0; i < 16; i++) piece[i] = *reinterpret_cast<const u4 *>(tile + rg * gstr + i * rstr + cg * 16);
+      int tot[16];
 #pragma unroll
-      for (int j = 0; j < 16; j++) { // column 16 g + j: byte j of every piece, row i -> word i % 4, byte i / 4 (k_slice's order)
+      for (int j = 0; j < 16; j++) { // column 16 cg + j: byte j of every piece, row i -> word i % 4, byte i / 4 (k_slice's order)
          u4 word = {0u, 0u, 0u, 0u};
+         tot[j] = 0;
 #pragma unroll
          for (int i = 0; i < 16; i++) {
             const uint32_t byte = (piece[i][j >> 2] >> (8 * (j & 3))) & 0xFFu;
             word[i & 3] |= byte << (8 * (i >> 2));
             tot[j] += (int)(signed char)byte;
          }
-         *reinterpret_cast<u4 *>(Q + (uint64_t)(s * b + 16 * g + j) * rows_pad + rg * 16) = word;
+         *reinterpret_cast<u4 *>(Q + (uint64_t)(16 * cg + j) * rows_pad + (rg0 + rg) * 16) = word;
+      }
+      if (colsum) {
+#pragma unroll
+         for (int j = 0; j < 16; j++) atomicAdd(&ssum[16 * cg + j], tot[j]); // (LDS; |sum| <= 128 x 16 x TRG)
       }
    }
    if (colsum) {
-#pragma unroll
-      for (int j = 0; j < 16; j++) ssum[j][threadIdx.x] = tot[j];
       __syncthreads();
-      if (threadIdx.x < 16) {
-         long long a = 0;
-         for (int k = 0; k < 256; k++) a += ssum[threadIdx.x][k];
-         if (a)
-            atomicAdd(reinterpret_cast<unsigned long long *>(&colsum[(blockIdx.x % I8_SHARDS) * I8_CS_STRIDE + s * b + 16 * g + threadIdx.x]),
-                      (unsigned long long)a);
-      }
+      for (int t = threadIdx.x; t < SB; t += 256)
+         if (ssum[t])
+            atomicAdd(reinterpret_cast<unsigned long long *>(&colsum[(blockIdx.x % I8_SHARDS) * I8_CS_STRIDE + t]), (unsigned long long)(long long)ssum[t]);
    }
 }
 
@@ -331,7 +343,10 @@ __global__ __launch_bounds__(256) void k_dequant_rows(const int8_t *__restrict__
                                                        const unsigned long long *__restrict__ maxbits, float *__restrict__ copy32,
                                                        double *__restrict__ copy64)
 {
+   __shared__ double sh_scale[64];
    const int F = 8 * S - 2, gpr = b / 16;
+   if ((int)threadIdx.x < b) sh_scale[threadIdx.x] = copy64 ? ldexp(1.0, slice_exponent(maxbits_fold(maxbits, threadIdx.x)) - F) : ldexp(1.0, 1 - F);
+   __syncthreads();
    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, row = t / gpr;
    const int g = (int)(t % gpr);
    if (row >= rows) return;
@@ -343,11 +358,23 @@ __global__ __launch_bounds__(256) void k_dequant_rows(const int8_t *__restrict__
 #pragma unroll
       for (int j = 0; j < 16; j++) m[j] = m[j] * 256 + (long long)(signed char)((word[j >> 2] >> (8 * (j & 3))) & 0xFFu);
    }
+   // power-of-two scales: exact.  copy32: m 2^(1-F), |.| < 2, like k_slice's copy32; copy64: m 2^(e_c - F)
+   if (copy32) {
 #pragma unroll
-   for (int j = 0; j < 16; j++) {
-      const int c = 16 * g + j;
-      if (copy32) copy32[row * b + c] = (float)ldexp((double)m[j], 1 - F); // |.| < 2, like k_slice's copy32
-      if (copy64) copy64[row * b + c] = ldexp((double)m[j], slice_exponent(maxbits_fold(maxbits, c)) - F);
+      for (int q = 0; q < 4; q++) {
+         float4 v;
+         v.x = (float)((double)m[4 * q] * sh_scale[16 * g + 4 * q]);
+         v.y = (float)((double)m[4 * q + 1] * sh_scale[16 * g + 4 * q + 1]);
+         v.z = (float)((double)m[4 * q + 2] * sh_scale[16 * g + 4 * q + 2]);
+         v.w = (float)((double)m[4 * q + 3] * sh_scale[16 * g + 4 * q + 3]);
+         *reinterpret_cast<float4 *>(copy32 + row * b + 16 * g + 4 * q) = v;
+      }
+   }
+   if (copy64) {
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+         *reinterpret_cast<d2 *>(copy64 + row * b + 16 * g + 2 * q) =
+            (d2){(double)m[2 * q] * sh_scale[16 * g + 2 * q], (double)m[2 * q + 1] * sh_scale[16 * g + 2 * q + 1]};
    }
 }
 
@@ -371,8 +398,17 @@ void i8_slice_rows(const double *V, uint64_t rows, int b, int S, const SliceOp &
 }
 void i8_unpack_slices(const int8_t *Qrm, uint64_t rows_pad, int b, int S, const SliceOp &op, hipStream_t stream)
 {
+   const int SB = S * b;
+   if (SB > 512 || SB % 16) throw Error(-1, "i8_unpack_slices: at most 512 slice-columns");
+   const int trg = SB <= 128 ? 32 : SB <= 272 ? 16 : 8; // 16-row groups per workgroup: 41 / 74 / 68 KB of LDS at the largest S b of each class
    const uint64_t groups = rows_pad / 16;
-   hipLaunchKernelGGL(k_unpack_slices, dim3((unsigned)((groups + 255) / 256), (unsigned)(S * (b / 16))), dim3(256), 0, stream, Qrm, rows_pad, b, S, op.Q, op.colsum);
+   const size_t lds = (size_t)trg * (16 * (SB + 16) + 16);
+   static bool attr_set = false;
+   if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_unpack_slices), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_set = true;
+   }
+   hipLaunchKernelGGL(k_unpack_slices, dim3((unsigned)((groups + trg - 1) / trg)), dim3(256), lds, stream, Qrm, rows_pad, b, S, trg, op.Q, op.colsum);
    HIP_CHECK_LAUNCH();
 }
 void i8_dequant_rows(const int8_t *Qrm, uint64_t rows, int b, int S, const SliceOp &op, float *copy32, double *copy64, hipStream_t stream)
