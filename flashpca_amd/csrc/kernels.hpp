@@ -110,7 +110,9 @@ void i8_slice(const double *V, uint64_t rows_pad, uint64_t rows, int b, int S, i
 void i8_maxbits_fold(const unsigned long long *bits, double *out64, hipStream_t stream);      // [I8_SHARDS][64] -> 64 doubles
 void i8_maxbits_set(const double *all, int G, unsigned long long *bits, hipStream_t stream);   // max over [G][64] -> shard 0
 void i8_slice_rows(const double *V, uint64_t rows, int b, int S, const SliceOp &op, int8_t *Qrm, hipStream_t stream); // -> Qrm[rows][S*b], op.colw
-void i8_unpack_slices(const int8_t *Qrm, uint64_t rows_pad, int b, int S, const SliceOp &op, hipStream_t stream);    // -> op.Q, op.colsum
+// -> op.Q, op.colsum; optionally the scaled operand itself (rows < rows_valid) for the sparse gathers: fp32 (copy32) or fp64 (copy64)
+void i8_unpack_slices(const int8_t *Qrm, uint64_t rows_pad, int b, int S, const SliceOp &op, hipStream_t stream, uint64_t rows_valid = 0,
+                      float *copy32 = nullptr, double *copy64 = nullptr);
 void i8_dequant_rows(const int8_t *Qrm, uint64_t rows, int b, int S, const SliceOp &op, float *copy32, double *copy64, hipStream_t stream);
 int gemm_i8_nsc_pad(int S, int b); // rows of a Q operand: S*b rounded up to the 256-column workgroup tile
 size_t gemm_i8_workspace_doubles(uint64_t rows_pad, uint64_t k_pad, int S, int b, bool two);

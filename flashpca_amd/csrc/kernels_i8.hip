@@ -292,9 +292,15 @@ __global__ __launch_bounds__(256) void k_slice_rows(const double *__restrict__ V
 // with coalesced 16-byte reads into LDS (row stride S b + 16, 16 more per row group: the 16 lanes of a ds_read_b128 group then hit
 // distinct banks); thread (row group fastest, slice, 16-column group) transposes a 16 x 16 byte block in registers and writes one
 // 16-byte piece per column -- adjacent threads = adjacent row groups = contiguous bytes of the same operand row.
+// The same pass can leave the scaled operand itself for the sparse gathers of the missing-call route (copy32: m 2^(1-F) in fp32, <= 4
+// slices; copy64: m 2^(e_c - F)), rows < rows_valid: lane = (row, 4 resp. 2 columns) reads one dword / one halfword per slice from the
+// LDS tile (conflict-free at the odd row stride) and writes 16 contiguous bytes -- a wave stores 1 KB runs.
 __global__ __launch_bounds__(256) void k_unpack_slices(const int8_t *__restrict__ Qrm, uint64_t rows_pad, int b, int S, int TRG,
-                                                        int8_t *__restrict__ Q, long long *__restrict__ colsum)
+                                                        int8_t *__restrict__ Q, long long *__restrict__ colsum,
+                                                        const unsigned long long *__restrict__ maxbits, uint64_t rows_valid,
+                                                        float *__restrict__ copy32, double *__restrict__ copy64)
 {
+   __shared__ double sh_scale[64];
    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
    __shared__ int ssum[512];
    const int SB = S * b, rstr = SB + 16, gstr = 16 * rstr + 16, ncg = SB / 16; // bytes per row / LDS strides / 16-column groups
@@ -306,7 +312,48 @@ __global__ __launch_bounds__(256) void k_unpack_slices(const int8_t *__restrict_
       *reinterpret_cast<u4 *>(tile + (row >> 4) * gstr + (row & 15) * rstr + pc * 16) = src[p];
    }
    for (int t = threadIdx.x; t < 512; t += 256) ssum[t] = 0;
+   if ((copy32 || copy64) && (int)threadIdx.x < b) {
+      const int F = 8 * S - 2;
+      sh_scale[threadIdx.x] = copy64 ? ldexp(1.0, slice_exponent(maxbits_fold(maxbits, threadIdx.x)) - F) : ldexp(1.0, 1 - F);
+   }
    __syncthreads();
+   if (copy32) { // thread = (row of the tile, group of 4 columns)
+      const int per_row = b / 4;
+      for (int t = threadIdx.x; t < ng * 16 * per_row; t += 256) {
+         const int row = t / per_row, q = t % per_row;
+         const uint64_t grow = rg0 * 16 + row;
+         if (grow >= rows_valid) continue;
+         const unsigned char *src_row = tile + (row >> 4) * gstr + (row & 15) * rstr + 4 * q;
+         long long m[4] = {0, 0, 0, 0};
+         for (int sl = 0; sl < S; sl++) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(src_row + sl * b);
+#pragma unroll
+            for (int j = 0; j < 4; j++) m[j] = m[j] * 256 + (long long)(signed char)((w >> (8 * j)) & 0xFFu);
+         }
+         float4 v;
+         v.x = (float)((double)m[0] * sh_scale[4 * q]);
+         v.y = (float)((double)m[1] * sh_scale[4 * q + 1]);
+         v.z = (float)((double)m[2] * sh_scale[4 * q + 2]);
+         v.w = (float)((double)m[3] * sh_scale[4 * q + 3]);
+         *reinterpret_cast<float4 *>(copy32 + grow * b + 4 * q) = v;
+      }
+   }
+   if (copy64) { // thread = (row of the tile, pair of columns)
+      const int per_row = b / 2;
+      for (int t = threadIdx.x; t < ng * 16 * per_row; t += 256) {
+         const int row = t / per_row, q = t % per_row;
+         const uint64_t grow = rg0 * 16 + row;
+         if (grow >= rows_valid) continue;
+         const unsigned char *src_row = tile + (row >> 4) * gstr + (row & 15) * rstr + 2 * q;
+         long long m0 = 0, m1 = 0;
+         for (int sl = 0; sl < S; sl++) {
+            const uint32_t w = *reinterpret_cast<const unsigned short *>(src_row + sl * b);
+            m0 = m0 * 256 + (long long)(signed char)(w & 0xFFu);
+            m1 = m1 * 256 + (long long)(signed char)((w >> 8) & 0xFFu);
+         }
+         *reinterpret_cast<d2 *>(copy64 + grow * b + 2 * q) = (d2){(double)m0 * sh_scale[2 * q], (double)m1 * sh_scale[2 * q + 1]};
+      }
+   }
    for (int t = threadIdx.x; t < TRG * ncg; t += 256) {
       const int rg = t % TRG, cg = t / TRG; // column group cg = s * (b / 16) + g covers slice-columns 16 cg .. 16 cg + 15
       if (rg >= ng) continue;
@@ -396,7 +443,8 @@ void i8_slice_rows(const double *V, uint64_t rows, int b, int S, const SliceOp &
    hipLaunchKernelGGL(k_slice_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, V, rows, b, S, gemm_i8_nsc_pad(S, b), op.maxbits, Qrm, op.colw);
    HIP_CHECK_LAUNCH();
 }
-void i8_unpack_slices(const int8_t *Qrm, uint64_t rows_pad, int b, int S, const SliceOp &op, hipStream_t stream)
+void i8_unpack_slices(const int8_t *Qrm, uint64_t rows_pad, int b, int S, const SliceOp &op, hipStream_t stream, uint64_t rows_valid, float *copy32,
+                      double *copy64)
 {
    const int SB = S * b;
    if (SB > 512 || SB % 16) throw Error(-1, "i8_unpack_slices: at most 512 slice-columns");
@@ -408,7 +456,8 @@ void i8_unpack_slices(const int8_t *Qrm, uint64_t rows_pad, int b, int S, const 
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_unpack_slices), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       attr_set = true;
    }
-   hipLaunchKernelGGL(k_unpack_slices, dim3((unsigned)((groups + trg - 1) / trg)), dim3(256), lds, stream, Qrm, rows_pad, b, S, trg, op.Q, op.colsum);
+   hipLaunchKernelGGL(k_unpack_slices, dim3((unsigned)((groups + trg - 1) / trg)), dim3(256), lds, stream, Qrm, rows_pad, b, S, trg, op.Q, op.colsum, op.maxbits,
+                      rows_valid, copy32, copy64);
    HIP_CHECK_LAUNCH();
 }
 void i8_dequant_rows(const int8_t *Qrm, uint64_t rows, int b, int S, const SliceOp &op, float *copy32, double *copy64, hipStream_t stream)

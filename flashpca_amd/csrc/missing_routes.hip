@@ -497,11 +497,9 @@ void xt_i8(fpca_ctx *c, const double *dB, int b, hipStream_t s, bool chain, hipE
    if (pre) {
       // column-major operand + exact column sums from the gathered rows; the gathers of the missing-call route read the operand
       // the slices spell -- X' applied to exactly the rounded block, G and E terms alike
-      kern::i8_unpack_slices(pre->Qrm, c->N_pad, b, c->cur_S(), ob, s);
-      if (mode == I8M_SPARSE || hyb) {
-         kern::i8_dequant_rows(pre->Qrm, c->N, b, c->cur_S(), ob, g32 ? ob.copy32 : nullptr, g32 ? nullptr : pre->dq64, s);
-         if (!g32) dB = pre->dq64;
-      }
+      const bool gathers = mode == I8M_SPARSE || hyb;
+      kern::i8_unpack_slices(pre->Qrm, c->N_pad, b, c->cur_S(), ob, s, c->N, (gathers && g32) ? ob.copy32 : nullptr, (gathers && !g32) ? pre->dq64 : nullptr);
+      if (gathers && !g32) dB = pre->dq64;
    } else {
       kern::i8_colmax(dB, c->N, b, 1, &ob, s);
       kern::i8_slice(dB, c->N_pad, c->N, b, c->cur_S(), 1, &ob, s);
