@@ -433,30 +433,18 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
             RT av[2][2][MT], bv[2][2][NT];
             constexpr int PSH = sizeof(pair_t) == 8 ? 7 : 8; // log2 bytes between the rows of two pair indices: 16 pairs per row
             const uint32_t lut_base = (uint32_t)(size_t)(const __attribute__((address_space(3))) pair_t *)sLutP_lane;
-            // FPCA_XTB_SPLIT: the fetch group of a pair of k-steps in two halves, one before each half of its 2 MT MFMAs (shorter
-            // groups: 13.35 -> 13.2 ms at fp32 / 16 columns, like K3's; profiles/r06_fp_kernels.txt)
-#ifndef FPCA_XTB_SPLIT
-#define FPCA_XTB_SPLIT 1
-#endif
+            // the fetch group of a pair of k-steps goes out in two halves, one before each half of its 2 MT MFMAs (shorter groups:
+            // 13.35 -> 13.2 ms at fp32 / 16 columns, like K3's; profiles/r06_fp_kernels.txt)
             auto fetch2 = [&](auto tpc, auto slotc, auto halfc) {
                constexpr int tp_ = decltype(tpc)::value, slot_ = decltype(slotc)::value, half_ = decltype(halfc)::value; // half_: 0 / 1 = first / second half of the group, 2 = all
                constexpr int M0 = half_ == 1 ? MT / 2 : 0, M1 = half_ == 0 ? MT / 2 : MT;
-#ifndef FPCA_XTB_BFIRST
-#define FPCA_XTB_BFIRST 0
-#endif
-               if constexpr (FPCA_XTB_BFIRST && half_ != 1) {
-#pragma unroll
-                  for (int w_ = 0; w_ < 2; w_++)
-#pragma unroll
-                     for (int nt = 0; nt < NT; nt++) bv[slot_][w_][nt] = sB_lane[(size_t)(2 * tp_ + w_) * b + nt * 16];
-               }
                sfor<M1 - M0>([&](auto mc) {
                   constexpr int m = M0 + decltype(mc)::value;
                   const pair_t pr_ = lds_pair_gather<pair_t, PSH, (4 * tp_) % 32, m * 256 * (int)sizeof(pair_t)>(lut_base, pk[m][H0 + (2 * tp_) / 16]);
                   av[slot_][0][m] = pr_.x;
                   av[slot_][1][m] = pr_.y;
                });
-               if constexpr (!FPCA_XTB_BFIRST && half_ != 0) {
+               if constexpr (half_ != 0) {
 #pragma unroll
                   for (int w_ = 0; w_ < 2; w_++)
 #pragma unroll
@@ -467,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
             sfor<8 * NW>([&](auto tpc) {
                constexpr int tp = decltype(tpc)::value;
                if constexpr (tp + 1 < 8 * NW)
-                  fetch2(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, (tp + 1) & 1>{}, std::integral_constant<int, FPCA_XTB_SPLIT ? 0 : 2>{});
+                  fetch2(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, (tp + 1) & 1>{}, std::integral_constant<int, 0>{});
                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                for (int w = 0; w < 2; w++) {
@@ -475,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void k_xt_b(const uint8_t *__restrict__ pac
                   for (int m = 0; m < MT; m++)
 #pragma unroll
                      for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(av[tp & 1][w][m], bv[tp & 1][w][nt], acc[m][nt]);
-                  if (FPCA_XTB_SPLIT && w == 0) {
+                  if (w == 0) {
                      __builtin_amdgcn_sched_barrier(0);
                      if constexpr (tp + 1 < 8 * NW)
                         fetch2(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, (tp + 1) & 1>{}, std::integral_constant<int, 1>{});
@@ -622,12 +610,9 @@ void xt_b(const uint8_t *packed, size_t pitch, const double *lut, const double *
 #undef FPCA_CASE
 }
 
-// K3's fetch groups: 1 = round 5's (compiler-formed gather addresses, T fragment first, one wait per gather), 0 = round 6's
-// experiment (two-instruction addresses, T fragment last, one wait per group).  Measured on one box, fp32, 16 columns, 500,000 x
-// 100,000: 13.25 against 13.41 ms -- the staged waits let the first MFMA of a group start a gather earlier; round 5's stay.
-#ifndef FPCA_X_FETCH_R5
-#define FPCA_X_FETCH_R5 1
-#endif
+// (Round 6 measured K3's fetch groups with two-instruction gather addresses, the T fragment last and one wait per group, and with 2 / 4
+// k-steps per group: 13.41 / 13.59 / 14.42 ms against 13.25 for the compiler-formed ones below at fp32 / 16 columns -- the staged waits
+// let the first MFMA of a group start a gather earlier, and with four waves per SIMD taking turns short groups win; r06_fp_kernels.txt.)
 // ------------------------------------------------------------------------------------------------
 // K3 x_t:  Y[s][c] = sum_snp X[s][snp] T[snp][c]
 //   workgroup = 64*MT samples x all b columns, wave = 16*MT samples (MT m-tiles), K = SNPs.
@@ -735,7 +720,6 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
       // k-step t + 1's operands -- the T fragment and the MT table gathers -- are read while step t's MFMAs run: left to itself
       // the compiler funnels every gather through one register pair (ds_read, s_waitcnt 0, v_mfma, MT times over), and a 64-cycle
       // MFMA behind a ~100-cycle LDS round trip kept the pipe 74 % busy with four waves per SIMD taking turns (rounds 1-4)
-#if FPCA_X_FETCH_R5
       RT av[2][MT], tv[2][NT];
 #define FPCA_XT_FETCH(t_, slot_)                                                                                    \
    {                                                                                                                \
@@ -761,50 +745,6 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
          __builtin_amdgcn_sched_barrier(0);
       }
 #undef FPCA_XT_FETCH
-#else
-      // (round 6) gather addresses in two instructions, the T fragment read LAST so that a single s_waitcnt precedes the MFMAs of a
-      // k-step.  GS = k-steps per fetch group: measured at 500,000 x 100,000, fp32, 16 columns (profiles/r06_fp_kernels.txt): groups of
-      // 4 / 8 / 16 MFMAs 13.37 / 13.59 / 14.42 ms -- with four waves per SIMD taking turns the SHORT groups win (the opposite of what a
-      // single wave's instruction stream suggests, profiles/r06_mfma_valu_mix.txt), so one k-step per group stays
-#ifndef FPCA_X_GS
-#define FPCA_X_GS 4
-#endif
-      constexpr int GS = (MT * NT >= FPCA_X_GS) ? 1 : FPCA_X_GS / (MT * NT); // k-steps per group
-      constexpr int NGRP = KCX / 4 / GS;
-      static_assert(KCX / 4 % GS == 0, "k-step groups");
-      RT av[2][GS][MT], tv[2][GS][NT];
-      constexpr int LSH = sizeof(pair_t) == 8 ? 3 : 4; // log2 bytes of a pair
-      const uint32_t sl_base = (uint32_t)(size_t)(const __attribute__((address_space(3))) pair_t *)sL_lane;
-      auto fetch = [&](auto gc, auto slotc) {
-         constexpr int g_ = decltype(gc)::value, slot_ = decltype(slotc)::value;
-         sfor<GS>([&](auto uc) {
-            constexpr int u = decltype(uc)::value, t_ = g_ * GS + u;
-            sfor<MT / 2>([&](auto mc) {
-               constexpr int m = 2 * decltype(mc)::value;
-               const pair_t pr_ = lds_pair_gather<pair_t, LSH, 2 * m, 4 * t_ * 16 * (int)sizeof(pair_t)>(sl_base, hh[t_]);
-               av[slot_][u][m] = pr_.x;
-               av[slot_][u][m + 1] = pr_.y;
-            });
-         });
-#pragma unroll
-         for (int u = 0; u < GS; u++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) tv[slot_][u][nt] = sT_lane[(size_t)(4 * (g_ * GS + u)) * b + nt * 16];
-      };
-      fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-      sfor<NGRP>([&](auto gc) {
-         constexpr int g = decltype(gc)::value;
-         if constexpr (g + 1 < NGRP) fetch(std::integral_constant<int, g + 1>{}, std::integral_constant<int, (g + 1) & 1>{});
-         __builtin_amdgcn_sched_barrier(0); // (the fetch group stays ahead of the MFMA group it does not feed)
-#pragma unroll
-         for (int u = 0; u < GS; u++)
-#pragma unroll
-            for (int m = 0; m < MT; m++)
-#pragma unroll
-               for (int nt = 0; nt < NT; nt++) acc[m][nt] = Mma<RT>::mma(av[g & 1][u][m], tv[g & 1][u][nt], acc[m][nt]);
-         __builtin_amdgcn_sched_barrier(0);
-      });
-#endif
       if (MIXED && ((c & (FOLD_EVERY - 1)) == FOLD_EVERY - 1 || c + 1 == c_end)) { // (as in K2: fp32 sums over at most 256 SNPs)
 #pragma unroll
          for (int m = 0; m < MT; m++)
@@ -833,15 +773,12 @@ __global__ __launch_bounds__(256, 2) void k_x_t(const uint8_t *__restrict__ pack
 
 // shape of K3 per (arithmetic, block width): fp64 -> 8 m-tiles for b <= 32 else 4, 64-SNP chunks; the mixed fp32 mode
 // carries fp32 + fp64 accumulators, so it uses 4 m-tiles and, for b >= 48, 32-SNP chunks (fewer prefetch registers)
-#ifndef FPCA_X_MT32
-#define FPCA_X_MT32 4 // m-tiles per wave of the fp32 K3 at 16 columns
-#endif
 template <typename RT, int NT> struct XCfg {
    static constexpr bool MIXED = sizeof(RT) == 4;
-   static constexpr int MT = MIXED ? (NT == 1 ? FPCA_X_MT32 : 4) : (NT <= 2 ? 8 : 4);
+   static constexpr int MT = MIXED ? 4 : (NT <= 2 ? 8 : 4);
    static constexpr int KCX = (MIXED && NT >= 3) ? 32 : 64;
 };
-static inline int x_t_mt(int b, bool fp32) { return fp32 ? (b == 16 ? FPCA_X_MT32 : 4) : (b <= 32 ? 8 : 4); }
+static inline int x_t_mt(int b, bool fp32) { return fp32 ? 4 : (b <= 32 ? 8 : 4); }
 static inline int x_t_kc(int b, bool fp32) { return (fp32 && b >= 48) ? 32 : 64; }
 
 int x_t_splits(uint64_t N_pad, uint64_t P_pad, int b, bool fp32)

@@ -92,16 +92,22 @@ void apply_xxt_dev(fpca_ctx *c, const double *dB, int b, double *dY, hipStream_t
 // rows of the sum, which is all the orthogonalisation that follows needs.  With real all-gather / reduce-scatter and more than one
 // chunk, K3 runs chunk by chunk and the reduce-scatter of chunk i rides on the communication stream under the computation of chunk i + 1.
 //
-// What travels in the all-gather (round 6): in the exact-integer arithmetic the operand of K2 is S byte slices of the block, so each
-// rank cuts ITS rows into slices -- the column scales agreed through one all-gather of b maxima per rank -- and the ranks all-gather
-// the SLICES, row-major [rows][S b] int8: S N b bytes instead of 8 N b (half at the 4 slices of the eigensolver's cheap passes), and
-// nobody slices rows it does not own; what every rank still does for all N rows is a byte transposition into the GEMM's operand
-// layout (kernels_i8.hip k_unpack_slices).  The format depends on the REQUESTED arithmetic and the transport only, never on what
+// What travels in the all-gather of a CHEAP pass (round 6): in the exact-integer arithmetic the operand of K2 is S byte slices of the
+// block, so each rank cuts ITS rows into slices -- the column scales agreed through one all-gather of b maxima per rank -- and the
+// ranks all-gather the SLICES, row-major [rows][S b] int8: S N b bytes instead of 8 N b (half at 4 slices), and nobody slices rows it
+// does not own; what every rank still does for all N rows is a byte transposition into the GEMM's operand layout, which also
+// leaves the operand the slices spell for the sparse gathers (kernels_i8.hip k_unpack_slices).  The format depends on the REQUESTED arithmetic and the transport only, never on what
 // fitted on a rank: a rank that fell back to the fp64 kernels receives the same slices and multiplies the block they spell.
+// Which passes: those on at most 4 slices -- the eigensolver's cheap passes, nine in ten of a long solve.  Measured per pass at 500,000
+// rows (profiles/r06_exchange_kernel_cost.txt): the transposition + fp32 operand of a 4-slice pass 58 us, + 6 us of own-row slicing at 8
+// ranks, against the 44 us of re-slicing they replace, for HALF the all-gather's bytes; on 7 slices the same pass costs 124 us (it also
+// writes the fp64 operand of the exact gathers) for an eighth fewer bytes -- a loss, so exact passes keep the fp64 all-gather, whose
+// block IS that operand.  (FPCA_EXCHANGE_SLICES=all, test builds: every pass, as first built.)
 static int exchange_slices_S(const fpca_ctx *c)
 {
    if (c->i8_S_req <= 0 || !c->native_collectives() || FPCA_TEST_ENV("FPCA_EXCHANGE_FP64")) return 0;
-   return (c->i8_Sc > 0 && c->i8_Sc < c->i8_S_req) ? c->i8_Sc : c->i8_S_req;
+   const int S = (c->i8_Sc > 0 && c->i8_Sc < c->i8_S_req) ? c->i8_Sc : c->i8_S_req;
+   return (S <= 4 || FPCA_TEST_ENV("FPCA_EXCHANGE_SLICES")) ? S : 0;
 }
 
 constexpr size_t XM_MAX = 0, XM_COLW = 64 * kern::I8_SHARDS, XM_SEND = XM_COLW + 640, XM_ALL = XM_SEND + 64; // d_xmeta, 8-byte words

@@ -267,6 +267,8 @@ def test_cli_gpus_solver_switch_and_fail_safe_demotion(tmp_path, built_lib):
         ("replicated", 2, "shm", ["--solver", "replicated"], {}, "eigensolver layout over 2 GPUs: replicated\n"),
         ("replicated3", 3, "shm2", ["--solver", "replicated"], {}, "eigensolver layout over 3 GPUs: replicated\n"),
         ("rowshard", 3, "shm2", ["--solver", "rowshard"], {}, "eigensolver layout over 3 GPUs: row-sharded\n"),
+        # (round 6: the all-gather of byte slices of the operand -- by default in the passes on <= 4 slices, here in every pass)
+        ("rowshard_slices", 3, "shm2", ["--solver", "rowshard"], {"FPCA_EXCHANGE_SLICES": "all"}, "eigensolver layout over 3 GPUs: row-sharded\n"),
         ("rsfail", 2, "shm2", [], {"FPCA_DEBUG_RS_FAIL": "7", "FPCA_AR_CHUNKS": "2"}, "a collective of the row-sharded solve failed"),
         ("rsfail3", 3, "shm2", [], {"FPCA_DEBUG_RS_FAIL": "5"}, "a collective of the row-sharded solve failed"),
         ("selftest1", 3, "shm2", [], {"FPCA_DEBUG_SELFTEST_FAIL": "1"}, "the self-test of the row-sharded exchange failed"),
@@ -284,7 +286,7 @@ def test_cli_gpus_solver_switch_and_fail_safe_demotion(tmp_path, built_lib):
         e, U, V, m = np.loadtxt(d / "eigenvalues.txt"), _tab(d / "eigenvectors.txt"), _tab(d / "load.txt"), _tab(d / "ms.txt")
         sg = np.sign(np.sum(U1 * U, axis=0))
         # the replicated solver follows the one-GPU iteration (whole blocks, same start block): eigenvalues to rounding
-        assert np.max(np.abs(e - e1) / e1) < (1e-10 if name == "rowshard" else 1e-12), (name, np.max(np.abs(e - e1) / e1))
+        assert np.max(np.abs(e - e1) / e1) < (1e-10 if name.startswith("rowshard") else 1e-12), (name, np.max(np.abs(e - e1) / e1))
         assert np.max(np.abs(U * sg - U1)) < 1e-8 and np.max(np.abs(V * sg - V1)) < 1e-8, name
         assert np.max(np.abs(_tab(d / "pcs.txt") * sg - _tab(d1 / "pcs.txt"))) < 1e-7, name
         assert np.array_equal(m, m1)
