@@ -208,6 +208,8 @@ int fpca_set_allreduce(fpca_ctx *ctx, fpca_allreduce_fn fn, void *user);
  * piece sits at offset r * count_per_rank of the long buffer.  With all three callbacks installed (and fpca_set_rank) the
  * row-sharded solver issues exactly the sequence of collectives it issues over RCCL -- per row chunk, the reduce-scatter of
  * chunk i on a second stream under the K3 of chunk i + 1 -- instead of building both from the sum (twice the bytes). */
+/* The all-gather must move its payload as OPAQUE 8-byte words: in the eigensolver's passes on <= 4 slices the words are byte slices
+ * of the operand (4 bytes per entry of the block instead of 8), not numbers -- no conversion, no reduction, no NaN canonicalisation. */
 typedef int (*fpca_allgather_fn)(void *user, const double *send, double *recv, uint64_t count_per_rank, void *stream);
 typedef int (*fpca_reducescatter_fn)(void *user, const double *send, double *recv, uint64_t count_per_rank, void *stream);
 int fpca_set_collectives(fpca_ctx *ctx, fpca_allgather_fn allgather, fpca_reducescatter_fn reducescatter, void *user);
