@@ -736,6 +736,24 @@ def test_row_sharded_solver_path_on_one_rank(fp, monkeypatch, nch, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ndim", [70, 130])  # 32- and 64-column blocks
+def test_row_sharded_exchange_in_slices_at_wider_blocks(fp, monkeypatch, ndim):
+    """The sliced exchange (k_slice_rows / k_unpack_slices) at the block widths the solver takes for more than 64 components: every pass
+    in slices (test switch), sparse missing-call route (its fp64 operand comes out of the unpack pass), against the plain solve."""
+    N, P = 20000, 1200
+    with fp.Context.synthetic(N, P, n_pop=6, accum="i8") as ref:
+        r0 = ref.pca(ndim=ndim, mixed=-1)
+    monkeypatch.setenv("FPCA_AR_CHUNKS", "2")
+    monkeypatch.setenv("FPCA_FORCE_ROWSHARD", "1")
+    monkeypatch.setenv("FPCA_EXCHANGE_SLICES", "all")
+    with fp.test_hooks(), fp.Context.synthetic(N, P, n_pop=6, accum="i8") as c:
+        c.comm_init_rank(1, 0, fp.Context.comm_unique_id())
+        r = c.pca(ndim=ndim, mixed=-1)
+        assert r["info"]["solver_path"] == 1 and r["info"]["converged"] == 1 and r["info"]["blockvec"] == (32 if ndim == 70 else 64)
+        assert np.max(np.abs(r["d"] - r0["d"]) / r0["d"]) < 1e-9
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["fallback_rank", "fp64_exchange"])
 def test_row_sharded_exchange_format_does_not_depend_on_what_fitted_on_a_rank(fp, monkeypatch, case):
     """The row-sharded apply all-gathers BYTE SLICES of the block (round 6; by default in the passes on <= 4 slices, here in all).  The format is decided from the requested arithmetic and the
