@@ -146,6 +146,8 @@ SIGNATURES = {
     "fpca_debug_k4": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "fpca_debug_variant": (_I, [_I, _I]),
     "fpca_debug_k4_bench": (_I, [_P, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)]),
+    "fpca_debug_k4_fused": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
+    "fpca_debug_k4_fused_bench": (_I, [_P, _I, _I, _I, C.POINTER(_D)]),
 }
 
 ABI_VERSION = 4  # FPCA_ABI_VERSION of the include/fpca.h the structures above mirror

@@ -74,6 +74,18 @@ class BlockBackend {
       gram(&out, 1, out, G);
    }
 
+   // gemm (out = init + sum_q A_q C_q), then Cg[q][p][c] = sum_s A_q[s][p] Out[s][c] for q < nq and Cg[nq] = Out'Out -- the update of the
+   // first Gram-Schmidt projection and the Gram matrices of the second from ONE pass over the basis where the backend can (host
+   // result => synchronises).  Default: the two calls.
+   virtual void gemm_gramvw(const int *a, int nq, const double *C, int init, int out, double *Cg)
+   {
+      gemm(a, nq, C, init, out);
+      int vw[1024];
+      for (int q = 0; q < nq && q < 1023; q++) vw[q] = a[q];
+      vw[nq] = out;
+      gram(vw, nq + 1, out, Cg);
+   }
+
    // first ncols columns of a block <-> host column-major N x ncols
    virtual void download(int h, int ncols, double *host, int64_t ld) = 0;
    virtual void upload(int h, int ncols, const double *host, int64_t ld) = 0;

@@ -214,6 +214,81 @@ int fpca_debug_k4(fpca_ctx *ctx, int b, int nq, const double *V, const double *W
    });
 }
 
+// HipBackend::gemm_gramvw through the backend object the solver drives: Out = W + sum_q V_q C_in[q], Cg[q] = V_q' Out (q < nq), Cg[nq] = Out' Out
+int fpca_debug_k4_fused(fpca_ctx *ctx, int b, int nq, const double *V, const double *W, const double *C_in, double *Out, double *Cg)
+{
+   return guarded([&] {
+      if (!ctx || !V || !W || !C_in || !Cg || nq < 1 || nq > 1000 || (b != 16 && b != 32 && b != 48 && b != 64)) throw Error(FPCA_EINVAL, "bad argument to fpca_debug_k4_fused");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      HipBackend be(ctx, b);
+      const int64_t N = (int64_t)ctx->N;
+      std::vector<int> hv(nq);
+      for (int q = 0; q < nq; q++) {
+         hv[q] = be.alloc_block();
+         be.upload(hv[q], b, V + (size_t)q * b * N, N);
+      }
+      const int hw = be.alloc_block();
+      be.upload(hw, b, W, N);
+      be.gemm_gramvw(hv.data(), nq, C_in, hw, hw, Cg); // (in place, as the solver calls it)
+      if (Out) be.download(hw, b, Out, N);
+      be.free_block(hw);
+      for (int h : hv) be.free_block(h);
+   });
+}
+
+// launch time of the fused update + Gram (kernel + plane reduction) against the two launches it replaces, nq random blocks
+int fpca_debug_k4_fused_bench(fpca_ctx *ctx, int b, int nq, int reps, double *ms_fused)
+{
+   return guarded([&] {
+      if (!ctx || nq < 1 || nq > 64 || reps < 1 || !ms_fused) throw Error(FPCA_EINVAL, "bad argument to fpca_debug_k4_fused_bench");
+      HIP_CHECK(hipSetDevice(ctx->device));
+      const uint64_t rows = ctx->N_pad;
+      const int planes = kern::update_gram_planes(rows, nq, b);
+      if (!planes) throw Error(FPCA_EINVAL, "no fused update + Gram kernel for this shape");
+      std::vector<double *> blk(nq + 1, nullptr);
+      const double **d_ptrs = nullptr;
+      double *d_C = nullptr, *d_part = nullptr;
+      hipEvent_t e[2] = {nullptr, nullptr};
+      auto cleanup = [&] {
+         for (double *p : blk)
+            if (p) (void)hipFree(p);
+         if (d_ptrs) (void)hipFree(d_ptrs);
+         if (d_C) (void)hipFree(d_C);
+         if (d_part) (void)hipFree(d_part);
+         for (hipEvent_t x : e)
+            if (x) (void)hipEventDestroy(x);
+      };
+      try {
+         hipStream_t s = ctx->stream;
+         for (int q = 0; q < nq + 1; q++) {
+            HIP_CHECK(hipMalloc(&blk[q], rows * b * sizeof(double)));
+            kern::fill_random(blk[q], ctx->N, rows, b, 100 + q, s);
+         }
+         HIP_CHECK(hipMalloc(&d_ptrs, (nq + 1) * sizeof(double *)));
+         HIP_CHECK(hipMemcpyAsync(d_ptrs, blk.data(), (nq + 1) * sizeof(double *), hipMemcpyHostToDevice, s));
+         const size_t cnt = (size_t)nq * b * b, cntg = (size_t)(nq + 1) * b * b;
+         HIP_CHECK(hipMalloc(&d_C, cnt * sizeof(double)));
+         HIP_CHECK(hipMalloc(&d_part, cntg * (planes + 1) * sizeof(double)));
+         HIP_CHECK(hipMemsetAsync(d_C, 0, cnt * sizeof(double), s)); // (zero coefficients: the block stays bounded over the repetitions)
+         for (hipEvent_t &x : e) HIP_CHECK(hipEventCreate(&x));
+         for (int r = -2; r < reps; r++) {
+            if (r == 0) HIP_CHECK(hipEventRecord(e[0], s));
+            kern::update_gram(d_ptrs, nq, d_C, blk[nq], blk[nq], rows, b, d_part + cntg, s);
+            kern::reduce_sum(d_part + cntg, d_part, cntg, planes, s);
+         }
+         HIP_CHECK(hipEventRecord(e[1], s));
+         HIP_CHECK(hipEventSynchronize(e[1]));
+         float ms = 0;
+         HIP_CHECK(hipEventElapsedTime(&ms, e[0], e[1]));
+         *ms_fused = ms / reps;
+      } catch (...) {
+         cleanup();
+         throw;
+      }
+      cleanup();
+   });
+}
+
 int fpca_debug_variant(int which, int variant)
 {
    if (which == 0)

@@ -221,6 +221,31 @@ void HipBackend::gemm_gram(const int *a, int nq, const double *C, int init, int 
    sec_other_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// the first projection's update and the second projection's Gram matrices in one pass over the basis (k_update_gram16)
+void HipBackend::gemm_gramvw(const int *a, int nq, const double *C, int init, int out, double *Cg)
+{
+   const int planes = kern::update_gram_planes(rows_, nq, b_);
+   if (!planes || init < 0) {
+      BlockBackend::gemm_gramvw(a, nq, C, init, out, Cg);
+      return;
+   }
+   auto t0 = std::chrono::steady_clock::now();
+   const size_t bb = (size_t)b_ * b_, cnt = (size_t)nq * bb, cntg = (size_t)(nq + 1) * bb;
+   grow(d_gpart_, gpart_cap_, cntg * planes + cntg);
+   grow(d_C_, C_cap_, std::max(cnt, (size_t)1024 * b_ * 4));
+   double *hc = pin_coeff(std::max(cnt, cntg));
+   std::memcpy(hc, C, cnt * sizeof(double));
+   push_ptrs(a, nq);
+   HIP_CHECK(hipMemcpyAsync(d_C_, hc, cnt * sizeof(double), hipMemcpyHostToDevice, c_->stream));
+   kern::update_gram(d_ptrs_, nq, d_C_, blocks_[init], blocks_[out], rows_, b_, d_gpart_ + cntg, c_->stream);
+   kern::reduce_sum(d_gpart_ + cntg, d_gpart_, cntg, planes, c_->stream);
+   if (sharded() && sh_.G > 1) c_->allreduce(d_gpart_, cntg, c_->stream);
+   HIP_CHECK(hipMemcpyAsync(hc, d_gpart_, cntg * sizeof(double), hipMemcpyDeviceToHost, c_->stream)); // (stream order: after the upload above was consumed)
+   HIP_CHECK(hipStreamSynchronize(c_->stream));
+   std::memcpy(Cg, hc, cntg * sizeof(double));
+   sec_other_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 void HipBackend::download2(int h, int ncols, double *host, int64_t ld, double *host2, int64_t ld2, const double *scale)
 {
    if (!host && !host2 && !sharded()) return;

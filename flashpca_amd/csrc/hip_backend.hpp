@@ -37,6 +37,7 @@ class HipBackend : public BlockBackend {
    void apply_begin(int in, int out) override;
    void apply_end() override;
    bool set_cheap(bool cheap) override;
+   void gemm_gramvw(const int *a, int nq, const double *C, int init, int out, double *Cg) override;
    void gram(const int *a, int nq, int w, double *C) override;
    void gemm(const int *a, int nq, const double *C, int init, int out) override;
    void gemm_gram(const int *a, int nq, const double *C, int init, int out, double *G) override;

@@ -1545,6 +1545,132 @@ void block_gemm(const double *const *blocks, int nq, const double *C, const doub
 }
 
 // ------------------------------------------------------------------------------------------------
+// K4 update + Gram in ONE pass over the basis (round 6; 16 columns):  Out = Init + sum_q A_q C_q  and then  G_q = A_q' Out (q < nq),
+// G_nq = Out' Out -- the first projection's update and the second projection's Gram of classical Gram-Schmidt twice, which read the
+// basis one after the other in rounds 1-5.  The second needs the COMPLETE updated tile, so a wave that owns a row tile alone
+// would have to keep every basis tile of it in registers (the nq + 1 accumulators beside them held round 5's attempt to one wave per
+// SIMD from 9 blocks on).  Here the four waves of a workgroup share ONE row tile and split the basis blocks (q = wave, wave + 4, ...):
+// each wave loads its blocks' tiles once, in the accumulator layout (lane (li, kq), register r = row kq + 4r, column li: what both
+// Gram operands want), turns each through a 2 KB LDS scratch into the row layout the update's A operand wants, accumulates ITS part
+// of the update; the four parts meet in LDS, every wave adds them (fixed order) to the tile of Init, wave 0 stores Out, and each wave
+// runs the Gram MFMAs of its blocks against the updated tile from the registers it still holds.  One partial plane [nq + 1][16][16] per
+// workgroup (summed by reduce_sum).
+template <int QW /* basis blocks per wave, at most */>
+__global__ __launch_bounds__(256) void k_update_gram16(const double *const *__restrict__ blocks, int nq, const double *__restrict__ C,
+                                                        const double *Init, double *Out, uint64_t N_pad, int tiles_per_wg,
+                                                        double *__restrict__ gpart)
+{
+   constexpr int b = 16, TS = 18 /* scratch row stride (doubles) */;
+   __shared__ __attribute__((aligned(16))) double Ts[4 * 16 * TS]; // one transposition scratch per wave
+   __shared__ double Ps[2][4 * 256];                               // the waves' parts of the update (two tiles in flight: one barrier per tile)
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int li = lane & 15, kq = lane >> 4;
+   const int nmine = (nq > wave) ? (nq - wave + 3) / 4 : 0; // basis blocks of this wave: q = wave + 4 qi
+   const bool own_w = (nq & 3) == wave;                     // ... and Out' Out with the wave that has room for it (index nq >> 2)
+   const double *bp[QW];
+#pragma unroll
+   for (int qi = 0; qi < QW; qi++) bp[qi] = qi < nmine ? blocks[wave + 4 * qi] : nullptr;
+   // the coefficients of a wave's blocks do not change from tile to tile: the B operands of its update MFMAs live in registers
+   // (C_q[p = 4 kq + t][c = li]) -- no LDS for them, so the workgroups per CU are bounded by registers alone
+   double cr[QW][4];
+#pragma unroll
+   for (int qi = 0; qi < QW; qi++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) cr[qi][t] = qi < nmine ? C[(size_t)(wave + 4 * qi) * (b * b) + (4 * kq + t) * b + li] : 0.0;
+   d4 G[QW + 1];
+#pragma unroll
+   for (int qi = 0; qi <= QW; qi++) G[qi] = (d4){0.0, 0.0, 0.0, 0.0};
+   double *ts = Ts + wave * 16 * TS;
+   const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, ntiles = N_pad / 16;
+   int pb = 0;
+   for (uint64_t tile = t0; tile < t0 + tiles_per_wg && tile < ntiles; tile++, pb ^= 1) {
+      const uint64_t s0 = tile * 16;
+      d4 v2[QW], w2;
+#pragma unroll
+      for (int qi = 0; qi < QW; qi++)
+         if (qi < nmine) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) v2[qi][r] = bp[qi][(s0 + kq + 4 * r) * b + li];
+         }
+#pragma unroll
+      for (int r = 0; r < 4; r++) w2[r] = Init ? Init[(s0 + kq + 4 * r) * b + li] : 0.0;
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int qi = 0; qi < QW; qi++)
+         if (qi < nmine) { // (wave-uniform)
+#pragma unroll
+            for (int r = 0; r < 4; r++) ts[(kq + 4 * r) * TS + li] = v2[qi][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const d2 a01 = *reinterpret_cast<const d2 *>(&ts[li * TS + 4 * kq]), a23 = *reinterpret_cast<const d2 *>(&ts[li * TS + 4 * kq + 2]);
+            acc = FPCA_MFMA(a01.x, cr[qi][0], acc);
+            acc = FPCA_MFMA(a01.y, cr[qi][1], acc);
+            acc = FPCA_MFMA(a23.x, cr[qi][2], acc);
+            acc = FPCA_MFMA(a23.y, cr[qi][3], acc);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier(); // (the scratch is rewritten by the next block)
+         }
+#pragma unroll
+      for (int r = 0; r < 4; r++) Ps[pb][wave * 256 + (kq + 4 * r) * 16 + li] = acc[r];
+      __syncthreads(); // (the other buffer is free again: every wave passed this point of the previous tile after reading it)
+      d4 w1;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+         const int e = (kq + 4 * r) * 16 + li;
+         w1[r] = w2[r] + ((Ps[pb][e] + Ps[pb][256 + e]) + (Ps[pb][512 + e] + Ps[pb][768 + e])); // the same order in every wave: identical tiles
+      }
+      if (wave == 0) {
+#pragma unroll
+         for (int r = 0; r < 4; r++) Out[(s0 + kq + 4 * r) * b + li] = w1[r];
+      }
+#pragma unroll
+      for (int qi = 0; qi < QW; qi++)
+         if (qi < nmine) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) G[qi] = FPCA_MFMA(v2[qi][r], w1[r], G[qi]);
+         }
+      if (own_w) {
+#pragma unroll
+         for (int qi = 0; qi <= QW; qi++)
+            if (qi == (nq >> 2)) {
+#pragma unroll
+               for (int r = 0; r < 4; r++) G[qi] = FPCA_MFMA(w1[r], w1[r], G[qi]);
+            }
+      }
+   }
+   double *gp = gpart + (size_t)blockIdx.x * (nq + 1) * (b * b);
+#pragma unroll
+   for (int qi = 0; qi <= QW; qi++) {
+      const int q = wave + 4 * qi;
+      if (q < nq || (q == nq && own_w)) {
+#pragma unroll
+         for (int r = 0; r < 4; r++) gp[(size_t)q * (b * b) + (kq + 4 * r) * b + li] = G[qi][r];
+      }
+   }
+}
+
+// workgroups of the fused launch = partial planes it leaves (0: no fused kernel for this shape)
+int update_gram_planes(uint64_t N_pad, int nq, int b)
+{
+   if (!g_k4_variant || b != 16 || nq < 1 || nq > 28 || N_pad < 16 * 512 || FPCA_TEST_ENV("FPCA_K4_NO_FUSED")) return 0;
+   return 512;
+}
+
+void update_gram(const double *const *blocks, int nq, const double *C, const double *Init, double *Out, uint64_t N_pad, int b, double *gpart,
+                 hipStream_t stream)
+{
+   const int planes = update_gram_planes(N_pad, nq, b);
+   if (!planes) throw Error(-1, "update_gram: no fused kernel for this shape");
+   const uint64_t ntiles = N_pad / 16;
+   const int tpw = (int)((ntiles + planes - 1) / planes);
+   if (nq <= 16)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_gram16<4>), dim3((unsigned)planes), dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad, tpw, gpart);
+   else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_gram16<7>), dim3((unsigned)planes), dim3(256), 0, stream, blocks, nq, C, Init, Out, N_pad, tpw, gpart);
+   HIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ void k_fill_random(double *blk, uint64_t N, uint64_t total, int b, uint64_t seed, uint64_t row0)
 {
    for (uint64_t il = (uint64_t)blockIdx.x * 256 + threadIdx.x; il < total; il += (uint64_t)gridDim.x * 256) {

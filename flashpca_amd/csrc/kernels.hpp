@@ -60,6 +60,11 @@ int gram_splits(uint64_t N_pad, int rows);
 void block_gemm(const double *const *blocks, int nq, const double *C, const double *Init, double *Out, uint64_t N_pad,
                 int b, hipStream_t stream, double *gram_part = nullptr);
 int block_gemm_gram_planes(uint64_t N_pad, int b);
+// Out = Init + sum_q A_q C_q, and from the same pass over the basis G_q = A_q' Out (q < nq), G_nq = Out' Out: update_gram_planes()
+// partial planes [nq + 1][b][b] in gpart (0 planes: no fused kernel for this shape -- 16 columns, nq <= 28 only)
+int update_gram_planes(uint64_t N_pad, int nq, int b);
+void update_gram(const double *const *blocks, int nq, const double *C, const double *Init, double *Out, uint64_t N_pad, int b, double *gpart,
+                 hipStream_t stream);
 // uniform(-0.5, 0.5) entries for rows < N, zero for rows in [N, N_pad)
 void fill_random(double *blk, uint64_t N, uint64_t rows, int b, uint64_t seed, hipStream_t stream, uint64_t row0 = 0);
 // *out_bits = max(*out_bits, bits of max |a - scale b|) over n doubles (NaN counts as +inf); out_bits zeroed by the caller

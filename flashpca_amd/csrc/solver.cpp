@@ -386,10 +386,11 @@ SolverResult block_krylov_schur(BlockBackend &be, const SolverOpts &o)
          negC[i] = -C[i];
          H[i] += C[i];
       }
-      be.gemm(V.data(), M, negC.data(), W, W);
+      // pass 1's update and pass 2's Gram matrices from one pass over the basis where the backend has it (BlockBackend::gemm_gramvw)
+      be.gemm_gramvw(V.data(), M, negC.data(), W, W, C.data());
+      Gw.assign(C.begin() + (long)cnt, C.begin() + (long)(cnt + (size_t)b * b));
       phase(PH_PROJ);
 
-      gram_vw();
       auto t0 = clk::now();
       if (scale == 0) {
          // first step: ||A|| estimate from the diagonal block H_00 (Rayleigh quotients)

@@ -68,6 +68,11 @@ int fpca_debug_k4(fpca_ctx *ctx, int b, int nq, const double *V, const double *W
  * fpca_debug_k4_bench: launch times of the K4 kernels on nq device-resident random basis blocks of this context's height: ms per
  * Gram (kernel + plane reduction) and per block GEMM (Out = Init + sum_q V_q C_q) */
 int fpca_debug_variant(int which, int variant);
+/* round 6: the first Gram-Schmidt projection's update and the second projection's Gram matrices from ONE pass over the basis
+ * (HipBackend::gemm_gramvw, k_update_gram16): Out (may be NULL) = W + sum_q V_q C_in[q]; Cg: [q][p][c] = sum_s V_q[s][p] Out[s][c] for
+ * q < nq, Cg[nq] = Out' Out -- (nq + 1) b b doubles; and its launch time (kernel + plane reduction) on nq random blocks */
+int fpca_debug_k4_fused(fpca_ctx *ctx, int b, int nq, const double *V, const double *W, const double *C_in, double *Out, double *Cg);
+int fpca_debug_k4_fused_bench(fpca_ctx *ctx, int b, int nq, int reps, double *ms_fused);
 int fpca_debug_k4_bench(fpca_ctx *ctx, int b, int nq, int reps, double *ms_gram, double *ms_gemm);
 /* diagnostic: placement census of an nwg-workgroup grid (256 threads, lds_bytes dynamic LDS each): out[2i] = HW_ID,
  * out[2i+1] = XCC_ID of workgroup i */

@@ -23,3 +23,10 @@ with fp.Context.synthetic(N, 512, n_pop=4, accum="fp64") as c:
                 line += "| v%d gram %.3f ms (%.2f TB/s)  gemm %.3f ms (%.2f TB/s) " % (variant, g.value, gb / g.value, m.value, gb / m.value)
             print(line, flush=True)
     L.fpca_debug_variant(0, 1)
+    # round 6: the update of the first projection + the Gram matrices of the second in one pass (k_update_gram16), against the two launches
+    for nq in (1, 2, 8, 14, 24, 27):
+        g, m, f = C.c_double(0), C.c_double(0), C.c_double(0)
+        assert L.fpca_debug_k4_bench(c.h, 16, nq, reps, C.byref(g), C.byref(m)) == 0
+        assert L.fpca_debug_k4_fused_bench(c.h, 16, nq, reps, C.byref(f)) == 0, fp.lib().fpca_last_error()
+        gb = nq * rows * 16 * 8 / 1e9
+        print("b=16 nq=%2d  update %.3f + Gram %.3f = %.3f ms   fused %.3f ms (%.2f TB/s over the basis once)" % (nq, m.value, g.value, m.value + g.value, f.value, gb / f.value), flush=True)

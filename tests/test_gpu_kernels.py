@@ -676,6 +676,32 @@ def test_k4_gram_and_block_gemm_at_full_height(fp, b, nq):
     assert np.max(np.abs(Cg - Gref)) <= 2e-13 * np.sqrt(N), np.max(np.abs(Cg - Gref))
 
 
+@pytest.mark.parametrize("nq", [1, 3, 4, 13, 24, 27])  # (27: the basis at its cap + the waiting blocks; nq % 4 decides which wave takes Out'Out)
+def test_k4_fused_update_and_gram_at_full_height(fp, nq):
+    """Round 6: HipBackend::gemm_gramvw -- the update of the first Gram-Schmidt projection and the Gram matrices of the second from ONE
+    pass over the basis (k_update_gram16: the four waves of a workgroup share a row tile and split the basis blocks) -- in place, as the
+    solver calls it, at N = 500,000 - 77 rows against numpy; 32 columns take the two launches it replaces (same entry point)."""
+    import ctypes as C
+
+    N = 500000 - 77
+    for b in ((16, 32) if nq == 3 else (16,)):
+        rng = np.random.default_rng(77 * b + nq)
+        V = np.asfortranarray(rng.standard_normal((N, nq * b)))
+        W = np.asfortranarray(rng.standard_normal((N, b)))
+        Cin = rng.standard_normal((nq, b, b)) * 1e-3
+        Cg = np.empty((nq + 1, b, b))
+        Out = np.empty((N, b), order="F")
+        with fp.Context.synthetic(N, 256, n_pop=4, accum="fp64") as ctx:
+            fp._lib.check(fp.lib().fpca_debug_k4_fused(ctx.h, b, nq, V.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p),
+                                                       Cin.ctypes.data_as(C.c_void_p), Out.ctypes.data_as(C.c_void_p), Cg.ctypes.data_as(C.c_void_p)))
+        ref = V @ Cin.reshape(nq * b, b) + W
+        assert np.max(np.abs(Out - ref)) <= 1e-12 * np.max(np.abs(ref))
+        Gref = np.concatenate([(V.T @ ref).reshape(nq, b, b), (ref.T @ ref)[None]], axis=0)
+        # V' Out: sums of N products of O(1) numbers (as in the test above); Out' Out: its diagonal is O(N)
+        assert np.max(np.abs(Cg[:nq] - Gref[:nq])) <= 2e-13 * np.sqrt(N) * max(1.0, np.max(np.abs(ref))), np.max(np.abs(Cg[:nq] - Gref[:nq]))
+        assert np.max(np.abs(Cg[nq] - Gref[nq])) <= 1e-13 * np.max(np.abs(Gref[nq])), np.max(np.abs(Cg[nq] - Gref[nq]))
+
+
 def test_thick_restart_at_full_height_keeps_an_orthonormal_basis(fp):
     """A forced thick restart (basis cap of 4 blocks) at N = 500,000: the compressed basis (Ritz rotation through
     k_block_gemm) must stay orthonormal and give the eigenpairs of the unrestricted solve; judged by a dense U'U on the host
